@@ -1,0 +1,206 @@
+"""ctypes binding of the C ABI in include/balm_hip.h (balm_amd/lib/libbalm_hip.so).
+
+This is the only way Python reaches the HIP path; there is no CPU fallback.  Loading fails loudly
+when the library has not been built (``python -m balm_amd.build``).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libbalm_hip.so")
+
+FORM_LEFT, FORM_RIGHT = 0, 1
+OK, ERR_ARG, ERR_HIP, ERR_STATE, ERR_TOO_FEW_PLANES, ERR_NUMERIC = range(6)
+FLAG_TIMING = 1
+T_MOMENTS, T_FACTORS, T_SYRK, T_ASSEMBLE, T_SOLVE, T_UPDATE, T_COUNT = range(7)
+TIMING_NAMES = ["moments", "factors", "syrk", "assemble", "solve", "update"]
+
+# every symbol include/balm_hip.h declares
+EXPORTS = ["balm_create", "balm_destroy", "balm_set_features", "balm_evaluate", "balm_only_residual",
+           "balm_solve_damped", "balm_damping_iter", "balm_build_clusters", "balm_set_allreduce",
+           "balm_get_timing", "balm_reset_timing", "balm_work_model", "balm_last_error", "balm_version"]
+
+
+class IterLog(C.Structure):
+    _fields_ = [("r1", C.c_double), ("r2", C.c_double), ("u", C.c_double), ("v", C.c_double),
+                ("q", C.c_double), ("q1", C.c_double), ("accepted", C.c_int), ("hess_evaluated", C.c_int)]
+
+
+class LMOpts(C.Structure):
+    _fields_ = [("form", C.c_int), ("u0", C.c_double), ("max_iter", C.c_int), ("rel_tol", C.c_double),
+                ("min_planes_per_pose", C.c_int), ("force_hess", C.c_int), ("no_stop", C.c_int),
+                ("verbose", C.c_int), ("reanchor", C.c_int)]
+
+
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_long, C.c_void_p)
+
+_LIB = None
+
+
+class BalmError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("balm_hip error %d: %s" % (code, msg))
+        self.code = code
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("libbalm_hip.so is not built (%s missing): run `python -m balm_amd.build`. "
+                              "There is no CPU fallback for the HIP path." % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        L.balm_create.restype = C.c_void_p
+        L.balm_create.argtypes = [C.c_int, C.c_int, C.c_int]
+        L.balm_destroy.restype = None
+        L.balm_destroy.argtypes = [C.c_void_p]
+        L.balm_set_features.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.balm_evaluate.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                    C.POINTER(C.c_double)]
+        L.balm_only_residual.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]
+        L.balm_solve_damped.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p,
+                                        C.POINTER(C.c_double)]
+        L.balm_damping_iter.argtypes = [C.c_void_p, C.POINTER(LMOpts), C.c_void_p, C.POINTER(IterLog),
+                                        C.POINTER(C.c_int)]
+        L.balm_build_clusters.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long,
+                                          C.c_void_p, C.c_void_p, C.c_void_p]
+        L.balm_set_allreduce.argtypes = [C.c_void_p, ALLREDUCE_FN, C.c_void_p]
+        L.balm_get_timing.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.balm_reset_timing.argtypes = [C.c_void_p]
+        L.balm_work_model.argtypes = [C.c_void_p, C.c_void_p]
+        L.balm_last_error.restype = C.c_char_p
+        L.balm_last_error.argtypes = [C.c_void_p]
+        L.balm_version.restype = C.c_char_p
+        _LIB = L
+    return _LIB
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _c(a, dtype=np.float64):
+    return None if a is None else np.ascontiguousarray(a, dtype=dtype)
+
+
+class Context:
+    """One balm_ctx: owns the HBM-resident problem for one GPU."""
+
+    def __init__(self, win_size, device=0, flags=0):
+        self.L = lib()
+        self.W = int(win_size)
+        self.n = 6 * self.W
+        self.h = self.L.balm_create(self.W, int(device), int(flags))
+        if not self.h:
+            raise BalmError(ERR_HIP, "balm_create(win_size=%d, device=%d) failed (no GPU, bad device, or "
+                                     "win_size out of range)" % (win_size, device))
+        self.F = 0
+        self._cb = None
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.balm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != OK:
+            raise BalmError(rc, self.L.balm_last_error(self.h).decode())
+
+    def set_features(self, clusters, fix, coeffs):
+        clusters, fix, coeffs = _c(clusters), _c(fix), _c(coeffs)
+        F = clusters.shape[0]
+        assert clusters.shape == (F, self.W, 10), clusters.shape
+        assert coeffs.shape == (F,)
+        assert fix is None or fix.shape == (F, 10)
+        self._check(self.L.balm_set_features(self.h, F, _p(clusters), _p(fix), _p(coeffs)))
+        self.F = F
+
+    def build_clusters(self, F, xyz, feat_id, pose_id, fix, coeffs, want_clusters=True):
+        xyz = _c(xyz, np.float32).reshape(-1, 3)
+        feat_id, pose_id = _c(feat_id, np.int32), _c(pose_id, np.int32)
+        fix, coeffs = _c(fix), _c(coeffs)
+        out = np.zeros((F, self.W, 10)) if want_clusters else None
+        self._check(self.L.balm_build_clusters(self.h, F, _p(xyz), _p(feat_id), _p(pose_id), xyz.shape[0],
+                                               _p(fix), _p(coeffs), _p(out)))
+        self.F = F
+        return out
+
+    def evaluate(self, form, poses, head=0, end=None, want_hess=True):
+        """-> (Hess [n,n] or None, JacT [n], residual)"""
+        poses = _c(poses)
+        end = self.F if end is None else end
+        H = np.zeros((self.n, self.n)) if want_hess else None
+        g = np.zeros(self.n)
+        r = C.c_double(0)
+        self._check(self.L.balm_evaluate(self.h, form, _p(poses), head, end, _p(H), _p(g), C.byref(r)))
+        if H is not None:
+            H = H.T.copy()    # column-major -> numpy [row, col]
+        return H, g, r.value
+
+    def only_residual(self, poses):
+        poses = _c(poses)
+        r = C.c_double(0)
+        self._check(self.L.balm_only_residual(self.h, _p(poses), C.byref(r)))
+        return r.value
+
+    def solve_damped(self, H, g, u):
+        Hc = _c(np.asarray(H).T)
+        g = _c(g)
+        dx = np.zeros(self.n)
+        q1 = C.c_double(0)
+        self._check(self.L.balm_solve_damped(self.h, _p(Hc), _p(g), u, _p(dx), C.byref(q1)))
+        return dx, q1.value
+
+    def damping_iter(self, poses, form=FORM_LEFT, u0=0.01, max_iter=10, rel_tol=1e-6, min_planes=0,
+                     force_hess=False, no_stop=False, verbose=False, reanchor=True):
+        """-> (poses_out [W,12], log [iters, 8]: r1 r2 u v q q1 accepted hess_evaluated)"""
+        out = _c(poses).copy()
+        o = LMOpts(form, u0, max_iter, rel_tol, min_planes, int(force_hess), int(no_stop), int(verbose),
+                   int(reanchor))
+        lg = (IterLog * max_iter)()
+        it = C.c_int(0)
+        self._check(self.L.balm_damping_iter(self.h, C.byref(o), _p(out), lg, C.byref(it)))
+        log = np.array([[e.r1, e.r2, e.u, e.v, e.q, e.q1, e.accepted, e.hess_evaluated]
+                        for e in lg[:it.value]]).reshape(-1, 8)
+        return out, log
+
+    def set_allreduce(self, fn):
+        """fn(dev_ptr: int, n_doubles: int) -> None; sums the device buffer across ranks in place."""
+        if fn is None:
+            self._cb = None
+            self._check(self.L.balm_set_allreduce(self.h, C.cast(None, ALLREDUCE_FN), None))
+            return
+
+        def tramp(ptr, n, _user):
+            try:
+                fn(ptr, n)
+                return 0
+            except Exception as e:   # never let an exception cross the C boundary
+                import traceback
+                traceback.print_exc()
+                return 1
+
+        self._cb = ALLREDUCE_FN(tramp)
+        self._check(self.L.balm_set_allreduce(self.h, self._cb, None))
+
+    def timing(self):
+        ms = np.zeros(T_COUNT)
+        cnt = np.zeros(T_COUNT, dtype=np.int64)
+        self._check(self.L.balm_get_timing(self.h, _p(ms), _p(cnt)))
+        return {TIMING_NAMES[k]: (float(ms[k]), int(cnt[k])) for k in range(T_COUNT)}
+
+    def reset_timing(self):
+        self._check(self.L.balm_reset_timing(self.h))
+
+    def work_model(self):
+        out = np.zeros(4)
+        self._check(self.L.balm_work_model(self.h, _p(out)))
+        return {"S": out[0], "B": out[1], "syrk_flops_algorithmic": out[2], "syrk_flops_issued": out[3]}

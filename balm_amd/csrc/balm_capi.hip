@@ -1,0 +1,466 @@
+// Host side of libbalm_hip.so: the C ABI of include/balm_hip.h.  Owns the HBM-resident problem
+// (per-feature SoA clusters, poses, Hessian), sequences the HIP kernels on one stream, and runs the
+// Levenberg-Marquardt loop of BALM2::damping_iter (src/benchmark/bavoxel.hpp:1069-1166) with every
+// matrix device-resident; only four scalars cross PCIe per iteration.
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+
+#include "balm_internal.h"
+
+using namespace balm;
+
+#define HIP_TRY(expr)                                                                              \
+  do {                                                                                             \
+    hipError_t e_ = (expr);                                                                        \
+    if (e_ != hipSuccess) {                                                                        \
+      ctx->err = std::string(#expr) + ": " + hipGetErrorString(e_);                                \
+      return BALM_ERR_HIP;                                                                         \
+    }                                                                                              \
+  } while (0)
+
+namespace {
+
+// ---- timing ------------------------------------------------------------------------------------
+struct Span {
+  balm_ctx *c; int slot; hipEvent_t a = nullptr, b = nullptr;
+  Span(balm_ctx *ctx, int s) : c(ctx), slot(s) {
+    if (!c->timer.on) return;
+    a = take(); b = take();
+    hipEventRecord(a, c->stream);
+  }
+  ~Span() {
+    if (!c->timer.on) return;
+    hipEventRecord(b, c->stream);
+    c->timer.pending.push_back({a, b, slot});
+  }
+  hipEvent_t take() {
+    if (!c->timer.pool.empty()) { hipEvent_t e = c->timer.pool.back(); c->timer.pool.pop_back(); return e; }
+    hipEvent_t e; hipEventCreate(&e); return e;
+  }
+};
+
+void collect_timing(balm_ctx *c) {   // call only after the stream is synchronised
+  for (auto &sp : c->timer.pending) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, sp.a, sp.b) == hipSuccess) { c->timer.ms[sp.slot] += ms; c->timer.cnt[sp.slot]++; }
+    c->timer.pool.push_back(sp.a); c->timer.pool.push_back(sp.b);
+  }
+  c->timer.pending.clear();
+}
+
+template <class T>
+int dalloc(balm_ctx *ctx, T **p, size_t count) {
+  if (*p) { hipFree(*p); *p = nullptr; }
+  if (count == 0) count = 1;
+  HIP_TRY(hipMalloc((void **)p, count * sizeof(T)));
+  return BALM_OK;
+}
+
+template <class T>
+int ensure(balm_ctx *ctx, T **p, size_t *cap, size_t count) {
+  if (*p && *cap >= count) return BALM_OK;
+  int rc = dalloc(ctx, p, count);
+  if (rc) return rc;
+  *cap = count;
+  return BALM_OK;
+}
+
+int sync_stream(balm_ctx *ctx) {
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  HIP_TRY(hipGetLastError());
+  collect_timing(ctx);
+  return BALM_OK;
+}
+
+long red_dacc_off(const balm_ctx *c) { return (long)c->ntiles * TILE_ELEMS; }
+long red_r_off(const balm_ctx *c) { return red_dacc_off(c) + (long)DACC_MAX * c->W; }
+
+int hook_allreduce(balm_ctx *ctx, double *buf, long n) {
+  if (!ctx->allreduce) return BALM_OK;
+  int rc = sync_stream(ctx);
+  if (rc) return rc;
+  if (ctx->allreduce((void *)buf, n, ctx->allreduce_user) != 0) {
+    ctx->err = "all-reduce hook failed";
+    return BALM_ERR_STATE;
+  }
+  return BALM_OK;
+}
+
+// residual-only evaluation of features [f0,f1) at device poses -> d_scal[slot] (summed over ranks)
+int residual_device(balm_ctx *ctx, const double *d_poses, int f0, int f1, int slot) {
+  {
+    Span sp(ctx, BALM_T_MOMENTS);
+    launch_world_moments(ctx->stream, ctx->d_cl, d_poses, ctx->W, f0, f1, ctx->d_C);
+    int nr = launch_feature_eigen(ctx->stream, ctx->d_C, ctx->d_fix, ctx->d_coe, f0, f1, ctx->d_feat, ctx->d_rpart);
+    launch_sum_scalar(ctx->stream, ctx->d_rpart, nr, ctx->d_scal + slot);
+  }
+  return hook_allreduce(ctx, ctx->d_scal + slot, 1);
+}
+
+// Hessian + gradient + residual of features [f0,f1) at device poses -> d_H, d_g, d_scal[slot]
+int evaluate_device(balm_ctx *ctx, int form, const double *d_poses, int f0, int f1, int slot) {
+  const int W = ctx->W, nf = f1 - f0;
+  const int dacc = form == 0 ? DACC_LEFT : DACC_RIGHT;
+  SyrkPlan plan = plan_syrk(ctx->ntiles, 3L * nf);
+  int rc;
+  if ((rc = ensure(ctx, &ctx->d_Gt, &ctx->cap_Gt, (size_t)(plan.Kpad + 8) * ctx->npad))) return rc;
+  if ((rc = ensure(ctx, &ctx->d_part, &ctx->cap_part, (size_t)plan.SG * ctx->ntiles * TILE_ELEMS))) return rc;
+  const int nblk = factors_grid(W, nf, form);
+  if ((rc = ensure(ctx, &ctx->d_dpart, &ctx->cap_dpart, (size_t)nblk * DACC_MAX * W))) return rc;
+  hipStream_t s = ctx->stream;
+  int nr;
+  {
+    Span sp(ctx, BALM_T_MOMENTS);
+    launch_world_moments(s, ctx->d_cl, d_poses, W, f0, f1, ctx->d_C);
+    nr = launch_feature_eigen(s, ctx->d_C, ctx->d_fix, ctx->d_coe, f0, f1, ctx->d_feat, ctx->d_rpart);
+  }
+  {
+    Span sp(ctx, BALM_T_FACTORS);
+    // zero the Gt columns the factor kernel does not write: [3 nf, Kpad + 8) and the row padding
+    const size_t k0 = (size_t)3 * nf, k1 = (size_t)plan.Kpad + 8;
+    HIP_TRY(hipMemsetAsync(ctx->d_Gt + k0 * ctx->npad, 0, (k1 - k0) * ctx->npad * sizeof(double), s));
+    if (ctx->npad > ctx->n)
+      HIP_TRY(hipMemset2DAsync(ctx->d_Gt + ctx->n, (size_t)ctx->npad * sizeof(double), 0,
+                               (size_t)(ctx->npad - ctx->n) * sizeof(double), k0 ? k0 : 1, s));
+    launch_factors(s, form, ctx->d_cl, d_poses, ctx->d_feat, W, ctx->npad, f0, f1, ctx->d_Gt, ctx->d_dpart, nblk);
+  }
+  {
+    Span sp(ctx, BALM_T_SYRK);
+    launch_syrk(s, ctx->d_Gt, ctx->npad, ctx->ntiles, ctx->d_tileIJ, plan, ctx->d_part);
+  }
+  {
+    Span sp(ctx, BALM_T_ASSEMBLE);
+    HIP_TRY(hipMemsetAsync(ctx->d_red + red_dacc_off(ctx), 0, (size_t)(DACC_MAX * W + 2) * sizeof(double), s));
+    launch_reduce(s, ctx->d_part, plan.SG, (long)ctx->ntiles * TILE_ELEMS, ctx->d_dpart, nblk, dacc * W,
+                  ctx->d_rpart, nr, ctx->d_red, red_dacc_off(ctx), red_r_off(ctx));
+  }
+  if ((rc = hook_allreduce(ctx, ctx->d_red, (long)ctx->red_len))) return rc;
+  {
+    Span sp(ctx, BALM_T_ASSEMBLE);
+    launch_assemble(s, form, ctx->d_red, red_dacc_off(ctx), ctx->d_tileIJ, ctx->ntiles, W, ctx->d_H, ctx->d_g);
+    HIP_TRY(hipMemcpyAsync(ctx->d_scal + slot, ctx->d_red + red_r_off(ctx), sizeof(double),
+                           hipMemcpyDeviceToDevice, s));
+  }
+  return BALM_OK;
+}
+
+int read_scalars(balm_ctx *ctx) {
+  HIP_TRY(hipMemcpyAsync(ctx->h_scal, ctx->d_scal, 16 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  return sync_stream(ctx);
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *balm_version(void) { return "balm_hip 0.1.0 (gfx950)"; }
+
+const char *balm_last_error(balm_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+balm_ctx *balm_create(int win_size, int device, int flags) {
+  if (win_size < 1 || win_size > MAX_W_LDS) return nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1 || device < 0 || device >= ndev) return nullptr;
+  if (hipSetDevice(device) != hipSuccess) return nullptr;
+  balm_ctx *ctx = new balm_ctx();
+  ctx->W = win_size;
+  ctx->n = 6 * win_size;
+  ctx->npad = (ctx->n + TILE - 1) / TILE * TILE;
+  ctx->T = ctx->npad / TILE;
+  ctx->ntiles = ctx->T * (ctx->T + 1) / 2;
+  ctx->nA = (ctx->n + NB - 1) / NB * NB;
+  ctx->device = device;
+  ctx->flags = flags;
+  ctx->timer.on = (flags & BALM_FLAG_TIMING) != 0;
+  auto fail = [&]() -> balm_ctx * { balm_destroy(ctx); return nullptr; };
+  if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) return fail();
+  const int W = ctx->W, n = ctx->n, nA = ctx->nA;
+  ctx->red_len = (size_t)ctx->ntiles * TILE_ELEMS + (size_t)DACC_MAX * W + 2;
+  if (dalloc(ctx, &ctx->d_poses, (size_t)12 * W) || dalloc(ctx, &ctx->d_poses_tmp, (size_t)12 * W) ||
+      dalloc(ctx, &ctx->d_red, ctx->red_len) || dalloc(ctx, &ctx->d_tileIJ, (size_t)2 * ctx->ntiles) ||
+      dalloc(ctx, &ctx->d_H, (size_t)n * n) || dalloc(ctx, &ctx->d_g, (size_t)n) ||
+      dalloc(ctx, &ctx->d_A, (size_t)nA * nA) || dalloc(ctx, &ctx->d_Wp, (size_t)NB * nA) ||
+      dalloc(ctx, &ctx->d_Minv, (size_t)(nA / NB) * NB * NB) || dalloc(ctx, &ctx->d_dvec, (size_t)nA) ||
+      dalloc(ctx, &ctx->d_perm, (size_t)nA) || dalloc(ctx, &ctx->d_dx, (size_t)n) ||
+      dalloc(ctx, &ctx->d_scal, (size_t)16))
+    return fail();
+  if (hipHostMalloc((void **)&ctx->h_scal, 16 * sizeof(double)) != hipSuccess) return fail();
+  std::vector<int> ij;
+  for (int I = 0; I < ctx->T; I++)      // off-diagonal tiles first (25 MFMA tiles), diagonal ones (15) last
+    for (int J = I + 1; J < ctx->T; J++) { ij.push_back(I); ij.push_back(J); }
+  for (int I = 0; I < ctx->T; I++) { ij.push_back(I); ij.push_back(I); }
+  if (hipMemcpy(ctx->d_tileIJ, ij.data(), ij.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) return fail();
+  if (hipMemset(ctx->d_scal, 0, 16 * sizeof(double)) != hipSuccess) return fail();
+  if (hipMemset(ctx->d_red, 0, ctx->red_len * sizeof(double)) != hipSuccess) return fail();
+  return ctx;
+}
+
+void balm_destroy(balm_ctx *ctx) {
+  if (!ctx) return;
+  hipSetDevice(ctx->device);
+  if (ctx->stream) hipStreamSynchronize(ctx->stream);
+  void *ptrs[] = {ctx->d_cl, ctx->d_fix, ctx->d_coe, ctx->d_poses, ctx->d_poses_tmp, ctx->d_C, ctx->d_feat,
+                  ctx->d_Gt, ctx->d_part, ctx->d_dpart, ctx->d_rpart, ctx->d_red, ctx->d_tileIJ, ctx->d_H,
+                  ctx->d_g, ctx->d_A, ctx->d_Wp, ctx->d_Minv, ctx->d_dvec, ctx->d_perm, ctx->d_dx, ctx->d_scal};
+  for (void *p : ptrs) if (p) hipFree(p);
+  if (ctx->h_scal) hipHostFree(ctx->h_scal);
+  for (auto &sp : ctx->timer.pending) { hipEventDestroy(sp.a); hipEventDestroy(sp.b); }
+  for (auto e : ctx->timer.pool) hipEventDestroy(e);
+  if (ctx->stream) hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+static int install_feature_buffers(balm_ctx *ctx, int F, const double *fix, const double *coeffs) {
+  int rc;
+  if (fix) {
+    if ((rc = dalloc(ctx, &ctx->d_fix, (size_t)F * 10))) return rc;
+    HIP_TRY(hipMemcpyAsync(ctx->d_fix, fix, (size_t)F * 10 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  } else if (ctx->d_fix) {
+    hipFree(ctx->d_fix); ctx->d_fix = nullptr;
+  }
+  if ((rc = dalloc(ctx, &ctx->d_coe, (size_t)F))) return rc;
+  HIP_TRY(hipMemcpyAsync(ctx->d_coe, coeffs, (size_t)F * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  if ((rc = dalloc(ctx, &ctx->d_C, (size_t)F * 10))) return rc;
+  if ((rc = dalloc(ctx, &ctx->d_feat, (size_t)F * FEAT_STRIDE))) return rc;
+  if ((rc = ensure(ctx, &ctx->d_rpart, &ctx->cap_rpart, (size_t)(F + 255) / 256 + 1))) return rc;
+  ctx->F = F;
+  return BALM_OK;
+}
+
+int balm_set_features(balm_ctx *ctx, int F, const double *clusters, const double *fix, const double *coeffs) {
+  if (!ctx) return BALM_ERR_ARG;
+  if (F < 1 || !clusters || !coeffs) { ctx->err = "balm_set_features: bad argument"; return BALM_ERR_ARG; }
+  HIP_TRY(hipSetDevice(ctx->device));
+  const int W = ctx->W;
+  const size_t count = (size_t)F * W * 10;
+  int rc;
+  ctx->F = 0;
+  if ((rc = dalloc(ctx, &ctx->d_cl, count))) return rc;
+  double *d_aos = nullptr;
+  HIP_TRY(hipMalloc((void **)&d_aos, count * sizeof(double)));
+  hipError_t e = hipMemcpyAsync(d_aos, clusters, count * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) {
+    launch_transpose_clusters(ctx->stream, d_aos, ctx->d_cl, F, W);
+    e = hipStreamSynchronize(ctx->stream);
+  }
+  hipFree(d_aos);
+  HIP_TRY(e);
+  // host bookkeeping: planes per pose (precheck at bavoxel.hpp:1071-1085) and the work model
+  ctx->planes_per_pose.assign(W, 0);
+  double S = 0, B = 0;
+  for (int a = 0; a < F; a++) {
+    int na = 0;
+    const double *ca = clusters + (size_t)a * W * 10;
+    for (int i = 0; i < W; i++)
+      if (ca[(size_t)i * 10 + 9] != 0) { ctx->planes_per_pose[i]++; na++; }
+    S += na; B += 0.5 * na * (na + 1.0);
+  }
+  ctx->work_S = S; ctx->work_B = B;
+  if ((rc = install_feature_buffers(ctx, F, fix, coeffs))) return rc;
+  return sync_stream(ctx);
+}
+
+int balm_build_clusters(balm_ctx *ctx, int F, const float *xyz, const int *feat_id, const int *pose_id, long n_pts,
+                        const double *fix, const double *coeffs, double *clusters_out) {
+  if (!ctx) return BALM_ERR_ARG;
+  if (F < 1 || n_pts < 0 || !xyz || !feat_id || !pose_id || !coeffs) {
+    ctx->err = "balm_build_clusters: bad argument"; return BALM_ERR_ARG;
+  }
+  HIP_TRY(hipSetDevice(ctx->device));
+  const int W = ctx->W;
+  const size_t count = (size_t)F * W * 10;
+  int rc;
+  ctx->F = 0;
+  if ((rc = dalloc(ctx, &ctx->d_cl, count))) return rc;
+  float *d_xyz = nullptr; int *d_f = nullptr, *d_p = nullptr;
+  HIP_TRY(hipMalloc((void **)&d_xyz, (size_t)(n_pts ? n_pts : 1) * 3 * sizeof(float)));
+  hipError_t e = hipMalloc((void **)&d_f, (size_t)(n_pts ? n_pts : 1) * sizeof(int));
+  if (e == hipSuccess) e = hipMalloc((void **)&d_p, (size_t)(n_pts ? n_pts : 1) * sizeof(int));
+  if (e == hipSuccess) e = hipMemcpyAsync(d_xyz, xyz, (size_t)n_pts * 3 * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_f, feat_id, (size_t)n_pts * sizeof(int), hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_p, pose_id, (size_t)n_pts * sizeof(int), hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) e = hipMemsetAsync(ctx->d_cl, 0, count * sizeof(double), ctx->stream);
+  if (e == hipSuccess) {
+    launch_build_clusters(ctx->stream, d_xyz, d_f, d_p, n_pts, F, W, ctx->d_cl);
+    e = hipStreamSynchronize(ctx->stream);
+  }
+  if (d_xyz) hipFree(d_xyz);
+  if (d_f) hipFree(d_f);
+  if (d_p) hipFree(d_p);
+  HIP_TRY(e);
+  // host copy of the cluster table (also feeds the planes-per-pose precheck)
+  std::vector<double> host(count);
+  double *d_aos = nullptr;
+  HIP_TRY(hipMalloc((void **)&d_aos, count * sizeof(double)));
+  launch_soa_to_aos(ctx->stream, ctx->d_cl, d_aos, F, W);
+  e = hipMemcpyAsync(host.data(), d_aos, count * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  hipFree(d_aos);
+  HIP_TRY(e);
+  if (clusters_out) std::memcpy(clusters_out, host.data(), count * sizeof(double));
+  ctx->planes_per_pose.assign(W, 0);
+  double S = 0, B = 0;
+  for (int a = 0; a < F; a++) {
+    int na = 0;
+    for (int i = 0; i < W; i++)
+      if (host[((size_t)a * W + i) * 10 + 9] != 0) { ctx->planes_per_pose[i]++; na++; }
+    S += na; B += 0.5 * na * (na + 1.0);
+  }
+  ctx->work_S = S; ctx->work_B = B;
+  if ((rc = install_feature_buffers(ctx, F, fix, coeffs))) return rc;
+  return sync_stream(ctx);
+}
+
+int balm_set_allreduce(balm_ctx *ctx, balm_allreduce_fn fn, void *user) {
+  if (!ctx) return BALM_ERR_ARG;
+  ctx->allreduce = fn;
+  ctx->allreduce_user = user;
+  return BALM_OK;
+}
+
+int balm_evaluate(balm_ctx *ctx, int form, const double *poses, int head, int end, double *Hess, double *JacT,
+                  double *residual) {
+  if (!ctx) return BALM_ERR_ARG;
+  if (ctx->F < 1) { ctx->err = "balm_evaluate: no features installed"; return BALM_ERR_STATE; }
+  if ((form != 0 && form != 1) || !poses || head < 0 || end > ctx->F || head >= end) {
+    ctx->err = "balm_evaluate: bad argument"; return BALM_ERR_ARG;
+  }
+  HIP_TRY(hipSetDevice(ctx->device));
+  const int n = ctx->n;
+  HIP_TRY(hipMemcpyAsync(ctx->d_poses, poses, (size_t)12 * ctx->W * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  int rc = evaluate_device(ctx, form, ctx->d_poses, head, end, 0);
+  if (rc) return rc;
+  if (Hess) HIP_TRY(hipMemcpyAsync(Hess, ctx->d_H, (size_t)n * n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  if (JacT) HIP_TRY(hipMemcpyAsync(JacT, ctx->d_g, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  if ((rc = read_scalars(ctx))) return rc;
+  if (residual) *residual = ctx->h_scal[0];
+  return BALM_OK;
+}
+
+int balm_only_residual(balm_ctx *ctx, const double *poses, double *residual) {
+  if (!ctx) return BALM_ERR_ARG;
+  if (ctx->F < 1) { ctx->err = "balm_only_residual: no features installed"; return BALM_ERR_STATE; }
+  if (!poses || !residual) { ctx->err = "balm_only_residual: bad argument"; return BALM_ERR_ARG; }
+  HIP_TRY(hipSetDevice(ctx->device));
+  HIP_TRY(hipMemcpyAsync(ctx->d_poses_tmp, poses, (size_t)12 * ctx->W * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  int rc = residual_device(ctx, ctx->d_poses_tmp, 0, ctx->F, 1);
+  if (rc) return rc;
+  if ((rc = read_scalars(ctx))) return rc;
+  *residual = ctx->h_scal[1];
+  return BALM_OK;
+}
+
+int balm_solve_damped(balm_ctx *ctx, const double *Hess, const double *JacT, double u, double *dxi, double *q1) {
+  if (!ctx) return BALM_ERR_ARG;
+  if (!Hess || !JacT || !dxi) { ctx->err = "balm_solve_damped: bad argument"; return BALM_ERR_ARG; }
+  HIP_TRY(hipSetDevice(ctx->device));
+  const int n = ctx->n;
+  HIP_TRY(hipMemcpyAsync(ctx->d_H, Hess, (size_t)n * n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(ctx->d_g, JacT, (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  {
+    Span sp(ctx, BALM_T_SOLVE);
+    launch_solve(ctx, u, true);
+  }
+  HIP_TRY(hipMemcpyAsync(dxi, ctx->d_dx, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  int rc = read_scalars(ctx);
+  if (rc) return rc;
+  if (q1) *q1 = ctx->h_scal[2];
+  return BALM_OK;
+}
+
+int balm_damping_iter(balm_ctx *ctx, const balm_lm_opts *o, double *poses, balm_iter_log *log, int *n_iters) {
+  if (!ctx) return BALM_ERR_ARG;
+  if (ctx->F < 1) { ctx->err = "balm_damping_iter: no features installed"; return BALM_ERR_STATE; }
+  if (!o || !poses || (o->form != 0 && o->form != 1) || o->max_iter < 1) {
+    ctx->err = "balm_damping_iter: bad argument"; return BALM_ERR_ARG;
+  }
+  if (n_iters) *n_iters = 0;
+  // bavoxel.hpp:1071-1085: every pose must see >= 20 planes (printf + exit(0) in the reference).
+  // With an all-reduce hook the counts are per-shard, so the caller prechecks the global counts.
+  if (o->min_planes_per_pose > 0 && !ctx->allreduce) {
+    int mn = ctx->planes_per_pose.empty() ? 0 : ctx->planes_per_pose[0];
+    for (int v : ctx->planes_per_pose) mn = v < mn ? v : mn;
+    if (mn < o->min_planes_per_pose) {
+      ctx->err = "Initial error too large. Please loose plane determination criteria for more planes. "
+                 "The optimization is terminated.";
+      return BALM_ERR_TOO_FEW_PLANES;
+    }
+  }
+  HIP_TRY(hipSetDevice(ctx->device));
+  const int W = ctx->W, F = ctx->F;
+  hipStream_t s = ctx->stream;
+  HIP_TRY(hipMemcpyAsync(ctx->d_poses, poses, (size_t)12 * W * sizeof(double), hipMemcpyHostToDevice, s));
+  double u = o->u0, v = 2, r1 = 0, r2 = 0;
+  bool calc = true;
+  int it = 0, rc;
+  while (it < o->max_iter) {
+    const bool evaluated = calc || o->force_hess;
+    if (evaluated && (rc = evaluate_device(ctx, o->form, ctx->d_poses, 0, F, 0))) return rc;
+    {
+      Span sp(ctx, BALM_T_SOLVE);
+      launch_solve(ctx, u, evaluated);
+    }
+    {
+      Span sp(ctx, BALM_T_UPDATE);
+      launch_update_poses(s, o->form, W, ctx->d_poses, ctx->d_dx, ctx->d_poses_tmp);
+    }
+    if ((rc = residual_device(ctx, ctx->d_poses_tmp, 0, F, 1))) return rc;
+    if ((rc = read_scalars(ctx))) return rc;
+    r1 = ctx->h_scal[0]; r2 = ctx->h_scal[1];
+    const double q1 = ctx->h_scal[2];
+    double q = r1 - r2;
+    if (!(std::isfinite(r1) && std::isfinite(r2))) {
+      ctx->err = "balm_damping_iter: non-finite residual";
+      return BALM_ERR_NUMERIC;
+    }
+    if (log) { log[it].r1 = r1; log[it].r2 = r2; log[it].u = u; log[it].v = v; log[it].q = q; log[it].q1 = q1;
+               log[it].accepted = q > 0; log[it].hess_evaluated = evaluated; }
+    if (o->verbose)   // the reference's progress line, bavoxel.hpp:1132
+      printf("iter%d: (%lf %lf) u: %lf v: %.1lf q: %.3lf %lf %lf\n", it, r1, r2, u, v, q / q1, q1, q);
+    if (q > 0) {      // bavoxel.hpp:1134-1143
+      double *t = ctx->d_poses; ctx->d_poses = ctx->d_poses_tmp; ctx->d_poses_tmp = t;
+      q = q / q1; v = 2; q = 1 - std::pow(2 * q - 1, 3);
+      u *= (q < 1.0 / 3.0 ? 1.0 / 3.0 : q);
+      calc = true;
+    } else {          // :1144-1149
+      u = u * v; v = 2 * v; calc = false;
+    }
+    it++;
+    if (!o->no_stop && std::fabs(r1 - r2) / r1 < o->rel_tol) break;   // :1155
+  }
+  if (o->reanchor) launch_reanchor(s, W, ctx->d_poses);
+  HIP_TRY(hipMemcpyAsync(poses, ctx->d_poses, (size_t)12 * W * sizeof(double), hipMemcpyDeviceToHost, s));
+  if ((rc = sync_stream(ctx))) return rc;
+  if (n_iters) *n_iters = it;
+  return BALM_OK;
+}
+
+int balm_get_timing(balm_ctx *ctx, double *ms, long *count) {
+  if (!ctx) return BALM_ERR_ARG;
+  for (int k = 0; k < BALM_T_COUNT; k++) {
+    if (ms) ms[k] = ctx->timer.ms[k];
+    if (count) count[k] = ctx->timer.cnt[k];
+  }
+  return BALM_OK;
+}
+
+int balm_reset_timing(balm_ctx *ctx) {
+  if (!ctx) return BALM_ERR_ARG;
+  for (int k = 0; k < BALM_T_COUNT; k++) { ctx->timer.ms[k] = 0; ctx->timer.cnt[k] = 0; }
+  return BALM_OK;
+}
+
+int balm_work_model(balm_ctx *ctx, double *out4) {
+  if (!ctx || !out4) return BALM_ERR_ARG;
+  const double W = ctx->W, F = ctx->F;
+  out4[0] = ctx->work_S;
+  out4[1] = ctx->work_B;
+  out4[2] = 108.0 * F * W * (W + 1.0);            // 108 FMA = 216 flop per unordered pair incl. diagonal -> x2/2
+  SyrkPlan p = plan_syrk(ctx->ntiles, 3L * ctx->F);
+  const double noff = ctx->ntiles - ctx->T, ndiag = ctx->T;
+  out4[3] = (noff * 25.0 + ndiag * 15.0) * 2048.0 * ((double)p.Kpad / 4.0);
+  return BALM_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,117 @@
+// Internal declarations shared by the HIP translation units of libbalm_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstddef>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/balm_hip.h"
+
+namespace balm {
+
+// ---- geometry constants ----------------------------------------------------------------------
+constexpr int TILE = 80;            // hessian_syrk macro tile (5x5 f64 MFMA 16x16 tiles per wave)
+constexpr int TM = 5;
+constexpr int TILE_ELEMS = TILE * TILE;   // 6400 doubles, stored [mfma_tile(25)][reg(4)][lane(64)]
+constexpr int FEAT_STRIDE = 24;     // per-feature eigen record (doubles)
+constexpr int DACC_LEFT = 27;       // per-pose accumulators: 6 gradient + 21 (symmetric 6x6)
+constexpr int DACC_RIGHT = 30;      // 6 gradient + 9 (TL) + 9 (TR) + 6 (BR symmetric)
+constexpr int DACC_MAX = 30;
+constexpr int NB = 48;              // LDL^T panel width
+constexpr int MAX_W_LDS = 480;      // feature_factors keeps (12 + DACC) * W doubles in LDS
+
+// feat record layout
+enum { FT_NN = 0, FT_VBAR = 1, FT_LAM = 4, FT_U0 = 7, FT_U1 = 10, FT_U2 = 13, FT_C0 = 16, FT_C1 = 17,
+       FT_C2 = 18, FT_COE = 19 };
+
+struct Timer {
+  bool on = false;
+  struct Span { hipEvent_t a, b; int slot; };
+  std::vector<Span> pending;
+  std::vector<hipEvent_t> pool;
+  double ms[BALM_T_COUNT] = {0};
+  long cnt[BALM_T_COUNT] = {0};
+};
+
+}  // namespace balm
+
+struct balm_ctx {
+  int W = 0, n = 0, npad = 0, T = 0, ntiles = 0, device = 0, flags = 0;
+  int nA = 0;                       // solver dimension (n rounded up to NB)
+  int F = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+
+  // features (HBM resident)
+  double *d_cl = nullptr;           // [F][10][W]  per-feature SoA
+  double *d_fix = nullptr;          // [F][10] or null
+  double *d_coe = nullptr;          // [F]
+  size_t cap_F = 0;
+  // poses
+  double *d_poses = nullptr;        // [W][12] current
+  double *d_poses_tmp = nullptr;    // [W][12] trial
+  // per-evaluation scratch
+  double *d_C = nullptr;            // [F][10] world moments
+  double *d_feat = nullptr;         // [F][FEAT_STRIDE]
+  double *d_Gt = nullptr;           // [Kcols][npad]  factored Hessian columns (k-major)
+  size_t cap_Gt = 0;                // doubles
+  double *d_part = nullptr;         // [SG][ntiles][6400] split-K partial tiles
+  size_t cap_part = 0;
+  double *d_dpart = nullptr;        // [nblk_factors][DACC][W]
+  size_t cap_dpart = 0;
+  double *d_rpart = nullptr;        // residual partials
+  size_t cap_rpart = 0;
+  double *d_red = nullptr;          // [ntiles*6400 | DACC_MAX*W | r | pad]   all-reduce payload
+  size_t red_len = 0;
+  int *d_tileIJ = nullptr;          // [ntiles][2]
+  double *d_H = nullptr;            // [n][n] column-major
+  double *d_g = nullptr;            // [n]
+  // solver
+  double *d_A = nullptr;            // [nA][nA] permuted damped matrix -> L (unit lower) in place
+  double *d_Wp = nullptr;           // [NB][nA]  W21 = L21 * D11 of the current panel
+  double *d_Minv = nullptr;         // [nA/NB][NB*NB] inverses of the unit-lower diagonal blocks
+  double *d_dvec = nullptr;         // [nA] pivots D
+  int *d_perm = nullptr;            // [nA] position -> original index
+  double *d_dx = nullptr;           // [n]
+  double *d_scal = nullptr;         // [16] device scalars: 0 r1, 1 r2, 2 q1, 3 flags
+  double *h_scal = nullptr;         // pinned mirror
+  // host bookkeeping
+  std::vector<int> planes_per_pose;
+  double work_S = 0, work_B = 0;
+  balm_allreduce_fn allreduce = nullptr;
+  void *allreduce_user = nullptr;
+  balm::Timer timer;
+};
+
+namespace balm {
+
+// launchers (kernels_accum.hip)
+void launch_transpose_clusters(hipStream_t s, const double *aos, double *soa, int F, int W);
+void launch_world_moments(hipStream_t s, const double *cl, const double *poses, int W, int f0, int f1, double *C);
+int launch_feature_eigen(hipStream_t s, const double *C, const double *fix, const double *coe, int f0, int f1,
+                         double *feat, double *rpart);   // returns #partials
+int factors_grid(int W, int nfeat, int form);
+void launch_factors(hipStream_t s, int form, const double *cl, const double *poses, const double *feat, int W,
+                    int npad, int f0, int f1, double *Gt, double *dpart, int nblk);
+struct SyrkPlan { int SG; int units_per_slice; int Kpad; long nblocks; };
+SyrkPlan plan_syrk(int ntiles, long K);
+void launch_syrk(hipStream_t s, const double *Gt, int npad, int ntiles, const int *tileIJ, const SyrkPlan &p,
+                 double *part);
+void launch_reduce(hipStream_t s, const double *part, int SG, long tile_elems_total, const double *dpart, int nblk,
+                   int dacc_len, const double *rpart, int nr, double *red, long red_dacc_off, long red_r_off);
+void launch_assemble(hipStream_t s, int form, const double *red, long red_dacc_off, const int *tileIJ, int ntiles,
+                     int W, double *H, double *g);
+void launch_sum_scalar(hipStream_t s, const double *rpart, int nr, double *out);
+
+// launchers (kernels_solve.hip)
+void launch_solve(balm_ctx *c, double u, bool new_hessian);      // (H + u diag H) dx = -g ; q1 -> d_scal[2]
+void launch_update_poses(hipStream_t s, int form, int W, const double *poses, const double *dx, double *out);
+void launch_reanchor(hipStream_t s, int W, double *poses);
+
+// launchers (kernels_build.hip)
+void launch_build_clusters(hipStream_t s, const float *xyz, const int *feat_id, const int *pose_id, long n_pts,
+                           int F, int W, double *soa);
+void launch_soa_to_aos(hipStream_t s, const double *soa, double *aos, int F, int W);
+
+}  // namespace balm

@@ -1,0 +1,768 @@
+// Hessian / gradient / residual accumulation kernels for gfx950 (MI355X).  FP64 throughout.
+//
+// The reference evaluators (src/benchmark/bavoxel.hpp:304-426 left form, :53-158 right form,
+// :428-470 residual) are restated through the exact identity
+//        Hess = blockdiag_i(B_i) - Gt * Gt^T ,   Gt in R^{6W x 3F}
+// (three scaled 6-vectors per (feature, pose)), so the O(F W^2)
+// pair loop (:404-418) becomes one FP64 SYRK on the matrix cores:
+//   K1  world_moments   one wavefront per feature, coalesced SoA reads, shuffle reduction
+//   K1b feature_eigen   one lane per feature: 3x3 Jacobi, residual partials
+//   K2  feature_factors one lane per (feature, pose): Gt columns + gradient + B_i partials
+//   K3  hessian_syrk    80x80 tiles per wavefront on v_mfma_f64_16x16x4_f64, split-K
+//   K4  reduce / assemble
+#include "balm_internal.h"
+
+namespace balm {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+typedef double d2 __attribute__((ext_vector_type(2)));
+
+// ------------------------------------------------------------------------------------------------
+// small device helpers
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+struct Obs {          // one observation (feature a, pose i) moved to the world frame
+  double N;
+  double Rv[3];       // R v
+  double b[3];        // R v + N p                 (world first moment; tools.hpp:336)
+  double Pw[6];       // world second moment P' (xx xy xz yy yz zz; tools.hpp:337-338)
+};
+
+// tools.hpp:333-339 (PointCluster::transform) == TCT_i of bavoxel.hpp:334-335
+__device__ __forceinline__ void to_world(const double P[6], const double v[3], double N, const double R[9],
+                                         const double p[3], Obs &o) {
+  // R is column-major: R(r,c) = R[3*c+r]
+  o.N = N;
+#pragma unroll
+  for (int r = 0; r < 3; r++) o.Rv[r] = R[r] * v[0] + R[3 + r] * v[1] + R[6 + r] * v[2];
+#pragma unroll
+  for (int r = 0; r < 3; r++) o.b[r] = o.Rv[r] + N * p[r];
+  const double Pf[3][3] = {{P[0], P[1], P[2]}, {P[1], P[3], P[4]}, {P[2], P[4], P[5]}};
+  double RP[3][3];
+#pragma unroll
+  for (int r = 0; r < 3; r++)
+#pragma unroll
+    for (int c = 0; c < 3; c++) RP[r][c] = R[r] * Pf[0][c] + R[3 + r] * Pf[1][c] + R[6 + r] * Pf[2][c];
+  int k = 0;
+#pragma unroll
+  for (int r = 0; r < 3; r++)
+#pragma unroll
+    for (int c = r; c < 3; c++) {
+      double rprt = RP[r][0] * R[c] + RP[r][1] * R[3 + c] + RP[r][2] * R[6 + c];
+      o.Pw[k++] = rprt + o.Rv[r] * p[c] + p[r] * o.b[c];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K0: caller layout [F][W][10] -> per-feature SoA [F][10][W] (one-off, at balm_set_features)
+// ------------------------------------------------------------------------------------------------
+__global__ void k_transpose_clusters(const double *__restrict__ aos, double *__restrict__ soa, int F, int W) {
+  const size_t total = (size_t)F * W;
+  for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+    const size_t a = t / W;
+    const int i = (int)(t - a * W);
+    const double *src = aos + t * 10;
+    double *dst = soa + a * 10 * W + i;
+#pragma unroll
+    for (int c = 0; c < 10; c++) dst[(size_t)c * W] = src[c];
+  }
+}
+
+void launch_transpose_clusters(hipStream_t s, const double *aos, double *soa, int F, int W) {
+  size_t total = (size_t)F * W;
+  int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  if (grid < 1) grid = 1;
+  hipLaunchKernelGGL(k_transpose_clusters, dim3(grid), dim3(256), 0, s, aos, soa, F, W);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1: per-feature world moments  C_a = sum_i T_i Co_i T_i^T   (bavoxel.hpp:331-339, :443-447)
+// One wavefront per feature; lanes stride the W poses; ten coalesced f64 streams per feature.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_world_moments(const double *__restrict__ cl,
+                                                       const double *__restrict__ poses, int W, int f0, int f1,
+                                                       double *__restrict__ Cout) {
+  extern __shared__ __attribute__((aligned(16))) double sp[];   // [12][W]
+  for (int t = threadIdx.x; t < 12 * W; t += blockDim.x) {
+    int i = t / 12, c = t - 12 * i;
+    sp[c * W + i] = poses[t];
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  for (int a = f0 + blockIdx.x * nw + wv; a < f1; a += gridDim.x * nw) {
+    const double *ca = cl + (size_t)a * 10 * W;
+    double acc[10];
+#pragma unroll
+    for (int c = 0; c < 10; c++) acc[c] = 0.0;
+    for (int i = lane; i < W; i += 64) {
+      const double N = ca[(size_t)9 * W + i];
+      if ((int)N > 0) {
+        double P[6], v[3], R[9], p[3];
+#pragma unroll
+        for (int c = 0; c < 6; c++) P[c] = ca[(size_t)c * W + i];
+#pragma unroll
+        for (int c = 0; c < 3; c++) v[c] = ca[(size_t)(6 + c) * W + i];
+#pragma unroll
+        for (int c = 0; c < 9; c++) R[c] = sp[c * W + i];
+#pragma unroll
+        for (int c = 0; c < 3; c++) p[c] = sp[(9 + c) * W + i];
+        Obs o;
+        to_world(P, v, N, R, p, o);
+#pragma unroll
+        for (int c = 0; c < 6; c++) acc[c] += o.Pw[c];
+#pragma unroll
+        for (int c = 0; c < 3; c++) acc[6 + c] += o.b[c];
+        acc[9] += N;
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < 10; c++) acc[c] = wave_sum(acc[c]);
+    if (lane == 0) {
+#pragma unroll
+      for (int c = 0; c < 10; c++) Cout[(size_t)a * 10 + c] = acc[c];
+    }
+  }
+}
+
+void launch_world_moments(hipStream_t s, const double *cl, const double *poses, int W, int f0, int f1, double *C) {
+  int nf = f1 - f0;
+  if (nf <= 0) return;
+  int grid = (nf + 3) / 4;
+  if (grid > 2048) grid = 2048;
+  size_t lds = (size_t)12 * W * sizeof(double);
+  hipLaunchKernelGGL(k_world_moments, dim3(grid), dim3(256), lds, s, cl, poses, W, f0, f1, C);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1b: per-feature 3x3 symmetric eigen-decomposition (stand-in for Eigen::SelfAdjointEigenSolver,
+// bavoxel.hpp:345-351), residual partials coe*lambda_0 (:349), and the per-feature scale factors
+// of the three Gt columns.  One lane per feature.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void jrot(double &app, double &aqq, double &apq, double &arp, double &arq, double &v0p,
+                                     double &v0q, double &v1p, double &v1q, double &v2p, double &v2q) {
+  if (apq == 0.0) return;
+  const double theta = (aqq - app) / (2.0 * apq);
+  const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+  const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+  app -= t * apq;
+  aqq += t * apq;
+  apq = 0.0;
+  const double rp = c * arp - s * arq, rq = s * arp + c * arq;
+  arp = rp; arq = rq;
+  double x, y;
+  x = c * v0p - s * v0q; y = s * v0p + c * v0q; v0p = x; v0q = y;
+  x = c * v1p - s * v1q; y = s * v1p + c * v1q; v1p = x; v1q = y;
+  x = c * v2p - s * v2q; y = s * v2p + c * v2q; v2p = x; v2q = y;
+}
+
+// eigenvalues ascending in lam[], eigenvector k = (U[0][k], U[1][k], U[2][k])
+__device__ __forceinline__ void eig3_jacobi(double a00, double a01, double a02, double a11, double a12, double a22,
+                                            double lam[3], double U[3][3]) {
+  double v00 = 1, v01 = 0, v02 = 0, v10 = 0, v11 = 1, v12 = 0, v20 = 0, v21 = 0, v22 = 1;
+  for (int sweep = 0; sweep < 30; sweep++) {
+    const double off = a01 * a01 + a02 * a02 + a12 * a12;
+    const double dia = a00 * a00 + a11 * a11 + a22 * a22;
+    if (off <= 1e-300 || off <= 1e-34 * dia) break;
+    jrot(a00, a11, a01, a02, a12, v00, v01, v10, v11, v20, v21);   // (p,q)=(0,1), r=2
+    jrot(a00, a22, a02, a01, a12, v00, v02, v10, v12, v20, v22);   // (0,2), r=1
+    jrot(a11, a22, a12, a01, a02, v01, v02, v11, v12, v21, v22);   // (1,2), r=0
+  }
+  double l0 = a00, l1 = a11, l2 = a22;
+  double c0[3] = {v00, v10, v20}, c1[3] = {v01, v11, v21}, c2[3] = {v02, v12, v22};
+#define BALM_CSWAP(la, lb, ca, cb)                                                         \
+  if (la > lb) {                                                                            \
+    double t_ = la; la = lb; lb = t_;                                                       \
+    for (int k_ = 0; k_ < 3; k_++) { double s_ = ca[k_]; ca[k_] = cb[k_]; cb[k_] = s_; }    \
+  }
+  BALM_CSWAP(l0, l1, c0, c1)
+  BALM_CSWAP(l1, l2, c1, c2)
+  BALM_CSWAP(l0, l1, c0, c1)
+#undef BALM_CSWAP
+  lam[0] = l0; lam[1] = l1; lam[2] = l2;
+  for (int k = 0; k < 3; k++) { U[k][0] = c0[k]; U[k][1] = c1[k]; U[k][2] = c2[k]; }
+}
+
+__global__ __launch_bounds__(256) void k_feature_eigen(const double *__restrict__ C, const double *__restrict__ fix,
+                                                       const double *__restrict__ coe, int f0, int f1,
+                                                       double *__restrict__ feat, double *__restrict__ rpart) {
+  __shared__ double sred[256];
+  const int a = f0 + blockIdx.x * blockDim.x + threadIdx.x;
+  double res = 0.0;
+  if (a < f1) {
+    double c[10];
+#pragma unroll
+    for (int k = 0; k < 10; k++) c[k] = C[(size_t)a * 10 + k];
+    if (fix) {
+#pragma unroll
+      for (int k = 0; k < 10; k++) c[k] += fix[(size_t)a * 10 + k];
+    }
+    const double NN = c[9];
+    const double inv = 1.0 / NN;
+    const double vb0 = c[6] * inv, vb1 = c[7] * inv, vb2 = c[8] * inv;
+    double lam[3], U[3][3];
+    eig3_jacobi(c[0] * inv - vb0 * vb0, c[1] * inv - vb0 * vb1, c[2] * inv - vb0 * vb2, c[3] * inv - vb1 * vb1,
+                c[4] * inv - vb1 * vb2, c[5] * inv - vb2 * vb2, lam, U);
+    const double w = coe[a];
+    res = w * lam[0];
+    double *f = feat + (size_t)a * FEAT_STRIDE;
+    f[FT_NN] = NN;
+    f[FT_VBAR] = vb0; f[FT_VBAR + 1] = vb1; f[FT_VBAR + 2] = vb2;
+    f[FT_LAM] = lam[0]; f[FT_LAM + 1] = lam[1]; f[FT_LAM + 2] = lam[2];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      f[FT_U0 + k] = U[k][0]; f[FT_U1 + k] = U[k][1]; f[FT_U2 + k] = U[k][2];
+    }
+    // column scales of Gt: sqrt(2 coe)/NN, sqrt(2 coe/(lam_k - lam_0))/NN
+    f[FT_C0] = sqrt(2.0 * w) * inv;
+    f[FT_C1] = sqrt(2.0 * w / (lam[1] - lam[0])) * inv;
+    f[FT_C2] = sqrt(2.0 * w / (lam[2] - lam[0])) * inv;
+    f[FT_COE] = w;
+  }
+  sred[threadIdx.x] = res;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) sred[threadIdx.x] += sred[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) rpart[blockIdx.x] = sred[0];
+}
+
+int launch_feature_eigen(hipStream_t s, const double *C, const double *fix, const double *coe, int f0, int f1,
+                         double *feat, double *rpart) {
+  int nf = f1 - f0;
+  if (nf <= 0) return 0;
+  int grid = (nf + 255) / 256;
+  hipLaunchKernelGGL(k_feature_eigen, dim3(grid), dim3(256), 0, s, C, fix, coe, f0, f1, feat, rpart);
+  return grid;
+}
+
+// deterministic single-block sum of `nr` partials -> out[0]
+__global__ __launch_bounds__(256) void k_sum_scalar(const double *__restrict__ part, int nr, double *__restrict__ out) {
+  __shared__ double sred[256];
+  double s = 0.0;
+  for (int t = threadIdx.x; t < nr; t += 256) s += part[t];
+  sred[threadIdx.x] = s;
+  __syncthreads();
+  for (int k = 128; k > 0; k >>= 1) {
+    if (threadIdx.x < k) sred[threadIdx.x] += sred[threadIdx.x + k];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = sred[0];
+}
+
+void launch_sum_scalar(hipStream_t s, const double *rpart, int nr, double *out) {
+  hipLaunchKernelGGL(k_sum_scalar, dim3(1), dim3(256), 0, s, rpart, nr, out);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2: per-(feature, pose) factors.  Block = 256 lanes = 256 poses of ONE feature at a time (the
+// feature record is wave-uniform -> scalar loads); a lane owns its pose's accumulators in LDS
+// ([DACC][W], conflict-free, no atomics).  Writes the three Gt columns of the feature (k-major:
+// Gt[(3a+k)*npad + 6i + r], 48 contiguous bytes per lane -> fully coalesced).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void cross3(const double a[3], const double b[3], double o[3]) {
+  o[0] = a[1] * b[2] - a[2] * b[1];
+  o[1] = a[2] * b[0] - a[0] * b[2];
+  o[2] = a[0] * b[1] - a[1] * b[0];
+}
+
+__device__ __forceinline__ void store6(double *dst, const double x[6]) {
+  d2 *q = reinterpret_cast<d2 *>(dst);     // 6i doubles -> 48-byte offsets: 16-byte aligned
+  d2 t0 = {x[0], x[1]}, t1 = {x[2], x[3]}, t2 = {x[4], x[5]};
+  q[0] = t0; q[1] = t1; q[2] = t2;
+}
+
+template <int FORM>
+__global__ __launch_bounds__(256) void k_feature_factors(const double *__restrict__ cl,
+                                                         const double *__restrict__ poses,
+                                                         const double *__restrict__ feat, int W, int npad, int f0,
+                                                         int f1, double *__restrict__ Gt,
+                                                         double *__restrict__ dpart) {
+  constexpr int DACC = FORM == 0 ? DACC_LEFT : DACC_RIGHT;
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  double *sp = sm;                 // [12][W] poses
+  double *sacc = sm + 12 * W;      // [DACC][W]
+  for (int t = threadIdx.x; t < 12 * W; t += blockDim.x) {
+    int i = t / 12, c = t - 12 * i;
+    sp[c * W + i] = poses[t];
+  }
+  for (int t = threadIdx.x; t < DACC * W; t += blockDim.x) sacc[t] = 0.0;
+  __syncthreads();
+
+  for (int a = f0 + blockIdx.x; a < f1; a += gridDim.x) {
+    const double *f = feat + (size_t)a * FEAT_STRIDE;
+    const double NN = f[FT_NN];
+    const double vbar[3] = {f[FT_VBAR], f[FT_VBAR + 1], f[FT_VBAR + 2]};
+    const double u0[3] = {f[FT_U0], f[FT_U0 + 1], f[FT_U0 + 2]};
+    const double u1[3] = {f[FT_U1], f[FT_U1 + 1], f[FT_U1 + 2]};
+    const double u2[3] = {f[FT_U2], f[FT_U2 + 1], f[FT_U2 + 2]};
+    const double c0 = f[FT_C0], c1 = f[FT_C1], c2 = f[FT_C2], coe = f[FT_COE];
+    const double iNN = 1.0 / NN;
+    const double *ca = cl + (size_t)a * 10 * W;
+    double *g0 = Gt + (size_t)(3 * (a - f0)) * npad;
+
+    for (int i = threadIdx.x; i < W; i += blockDim.x) {
+      double col0[6], col1[6], col2[6];
+      const double N = ca[(size_t)9 * W + i];
+      if ((int)N > 0) {
+        double P[6], v[3], R[9], p[3];
+#pragma unroll
+        for (int c = 0; c < 6; c++) P[c] = ca[(size_t)c * W + i];
+#pragma unroll
+        for (int c = 0; c < 3; c++) v[c] = ca[(size_t)(6 + c) * W + i];
+#pragma unroll
+        for (int c = 0; c < 9; c++) R[c] = sp[c * W + i];
+#pragma unroll
+        for (int c = 0; c < 3; c++) p[c] = sp[(9 + c) * W + i];
+
+        if (FORM == 0) {
+          // ---- LEFT form, bavoxel.hpp:365-402 -------------------------------------------------
+          Obs o;
+          to_world(P, v, N, R, p, o);
+          // M = TC_i [R_i, p_i - vbar]^T (:368-370):  M_top = P' - b vbar^T ,  M_bot = (b - N vbar)^T
+          const double Pw[3][3] = {{o.Pw[0], o.Pw[1], o.Pw[2]}, {o.Pw[1], o.Pw[3], o.Pw[4]}, {o.Pw[2], o.Pw[4], o.Pw[5]}};
+          double cvec[3];
+#pragma unroll
+          for (int r = 0; r < 3; r++) cvec[r] = o.b[r] - N * vbar[r];
+          double m0[3], m1[3], m2[3];
+          const double vu0 = vbar[0] * u0[0] + vbar[1] * u0[1] + vbar[2] * u0[2];
+          const double vu1 = vbar[0] * u1[0] + vbar[1] * u1[1] + vbar[2] * u1[2];
+          const double vu2 = vbar[0] * u2[0] + vbar[1] * u2[1] + vbar[2] * u2[2];
+#pragma unroll
+          for (int r = 0; r < 3; r++) {
+            m0[r] = Pw[r][0] * u0[0] + Pw[r][1] * u0[1] + Pw[r][2] * u0[2] - o.b[r] * vu0;
+            m1[r] = Pw[r][0] * u1[0] + Pw[r][1] * u1[1] + Pw[r][2] * u1[2] - o.b[r] * vu1;
+            m2[r] = Pw[r][0] * u2[0] + Pw[r][1] * u2[1] + Pw[r][2] * u2[2] - o.b[r] * vu2;
+          }
+          const double s0 = cvec[0] * u0[0] + cvec[1] * u0[1] + cvec[2] * u0[2];
+          const double s1 = cvec[0] * u1[0] + cvec[1] * u1[1] + cvec[2] * u1[2];
+          const double s2 = cvec[0] * u2[0] + cvec[1] * u2[1] + cvec[2] * u2[2];
+          // g_k = (U_k M u_0 + U_0 M u_k)/NN (:371-378) with U_k [x;s] = [x cross u_k ; s u_k]
+          double x00[3], x01[3], x10[3], x02[3], x20[3], bxu[3];
+          cross3(m0, u0, x00);
+          cross3(m0, u1, x01); cross3(m1, u0, x10);
+          cross3(m0, u2, x02); cross3(m2, u0, x20);
+          cross3(o.b, u0, bxu);                       // w = (U_0 TC_i)[:,3] = [b x u0 ; N u0] (:380)
+          double grad[6];
+#pragma unroll
+          for (int r = 0; r < 3; r++) {
+            grad[r] = 2.0 * coe * iNN * x00[r];       // coe * g_0 (:381)
+            grad[3 + r] = 2.0 * coe * iNN * s0 * u0[r];
+            col0[r] = c0 * bxu[r];
+            col0[3 + r] = c0 * N * u0[r];
+            col1[r] = c1 * (x01[r] + x10[r]);
+            col1[3 + r] = c1 * (s0 * u1[r] + s1 * u0[r]);
+            col2[r] = c2 * (x02[r] + x20[r]);
+            col2[3 + r] = c2 * (s0 * u2[r] + s2 * u0[r]);
+          }
+          // B_i = coe (Ell + Ell^T in the top-left 3x3) + (2 coe/NN) U_0 TCT_i U_0^T   (:387-388,:397-402)
+          //   Ell + Ell^T = (u0 m0^T + m0 u0^T - 2 (m0.u0) I)/NN
+          //   U_0 TCT U_0^T = [[K P' K^T, (b x u0) u0^T],[u0 (b x u0)^T, N u0 u0^T]],  K = hat(u0)
+          const double K[3][3] = {{0, -u0[2], u0[1]}, {u0[2], 0, -u0[0]}, {-u0[1], u0[0], 0}};
+          double KP[3][3];
+#pragma unroll
+          for (int r = 0; r < 3; r++)
+#pragma unroll
+            for (int c = 0; c < 3; c++) KP[r][c] = K[r][0] * Pw[0][c] + K[r][1] * Pw[1][c] + K[r][2] * Pw[2][c];
+          const double m0u0 = m0[0] * u0[0] + m0[1] * u0[1] + m0[2] * u0[2];
+          const double k1 = coe * iNN, k2 = 2.0 * coe * iNN;
+          double bd[21];
+          int q = 0;
+#pragma unroll
+          for (int r = 0; r < 3; r++)
+#pragma unroll
+            for (int c = r; c < 3; c++) {          // TL, symmetric
+              double kpk = KP[r][0] * K[c][0] + KP[r][1] * K[c][1] + KP[r][2] * K[c][2];
+              double ell = u0[r] * m0[c] + m0[r] * u0[c] - (r == c ? 2.0 * m0u0 : 0.0);
+              bd[q++] = k1 * ell + k2 * kpk;
+            }
+#pragma unroll
+          for (int r = 0; r < 3; r++)
+#pragma unroll
+            for (int c = 0; c < 3; c++) bd[q++] = k2 * bxu[r] * u0[c];   // TR (rows 0..2, cols 3..5)
+#pragma unroll
+          for (int r = 0; r < 3; r++)
+#pragma unroll
+            for (int c = r; c < 3; c++) bd[q++] = k2 * N * u0[r] * u0[c];   // BR, symmetric
+#pragma unroll
+          for (int k = 0; k < 6; k++) sacc[k * W + i] += grad[k];
+#pragma unroll
+          for (int k = 0; k < 21; k++) sacc[(6 + k) * W + i] += bd[k];
+        } else {
+          // ---- RIGHT form, bavoxel.hpp:93-130 ("Right update.pdf") ----------------------------
+          const double Pf[3][3] = {{P[0], P[1], P[2]}, {P[1], P[3], P[4]}, {P[2], P[4], P[5]}};
+          const double NNi = (double)(int)NN;            // int NN in the reference (:82)
+          const double jNN = 1.0 / NNi;
+          double r3[3];                                   // R^T u0
+#pragma unroll
+          for (int c = 0; c < 3; c++) r3[c] = R[3 * c] * u0[0] + R[3 * c + 1] * u0[1] + R[3 * c + 2] * u0[2];
+          double ai[3];
+          cross3(v, r3, ai);                              // hat(v) r
+          double ti[3];
+#pragma unroll
+          for (int r = 0; r < 3; r++) ti[r] = p[r] - vbar[r];
+          const double s = u0[0] * ti[0] + u0[1] * ti[1] + u0[2] * ti[2];
+          double Pr[3];
+#pragma unroll
+          for (int r = 0; r < 3; r++) Pr[r] = Pf[r][0] * r3[0] + Pf[r][1] * r3[1] + Pf[r][2] * r3[2];
+          // combo1 = hat(P r) + hat(v) s ; combo2 = R v + n t
+          const double h1[3] = {Pr[0] + v[0] * s, Pr[1] + v[1] * s, Pr[2] + v[2] * s};   // combo1 = hat(h1)
+          const double C1[3][3] = {{0, -h1[2], h1[1]}, {h1[2], 0, -h1[0]}, {-h1[1], h1[0], 0}};
+          const double rh[3][3] = {{0, -r3[2], r3[1]}, {r3[2], 0, -r3[0]}, {-r3[1], r3[0], 0}};
+          double Rv[3], combo2[3];
+#pragma unroll
+          for (int r = 0; r < 3; r++) {
+            Rv[r] = R[r] * v[0] + R[3 + r] * v[1] + R[6 + r] * v[2];
+            combo2[r] = Rv[r] + N * ti[r];
+          }
+          // Auk = [ ((R P + t v^T) rh - R combo1) , (combo2 u0^T + (combo2.u0) I) ] / NN     (3x6)
+          double E[3][3];      // R P + t v^T
+#pragma unroll
+          for (int r = 0; r < 3; r++)
+#pragma unroll
+            for (int c = 0; c < 3; c++)
+              E[r][c] = R[r] * Pf[0][c] + R[3 + r] * Pf[1][c] + R[6 + r] * Pf[2][c] + ti[r] * v[c];
+          double Auk[3][6];
+          const double c2u = combo2[0] * u0[0] + combo2[1] * u0[1] + combo2[2] * u0[2];
+#pragma unroll
+          for (int r = 0; r < 3; r++)
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+              double erh = E[r][0] * rh[0][c] + E[r][1] * rh[1][c] + E[r][2] * rh[2][c];
+              double rc1 = R[r] * C1[0][c] + R[3 + r] * C1[1][c] + R[6 + r] * C1[2][c];
+              Auk[r][c] = (erh - rc1) * jNN;
+              Auk[r][3 + c] = (combo2[r] * u0[c] + (r == c ? c2u : 0.0)) * jNN;
+            }
+          double jjt[6], a1[6], a2[6];
+#pragma unroll
+          for (int c = 0; c < 6; c++) {
+            jjt[c] = Auk[0][c] * u0[0] + Auk[1][c] * u0[1] + Auk[2][c] * u0[2];
+            a1[c] = Auk[0][c] * u1[0] + Auk[1][c] * u1[1] + Auk[2][c] * u1[2];
+            a2[c] = Auk[0][c] * u2[0] + Auk[1][c] * u2[1] + Auk[2][c] * u2[2];
+          }
+          // Gt columns: c0' [a_i ; n u0], c1' Auk^T u1, c2' Auk^T u2 with the 1/NN already in Auk.
+          // FT_C* carry 1/NN (double NN); the right form divides by the int NN -> rescale.
+          const double r0 = c0 * NN * jNN, r1 = c1 * NN, r2 = c2 * NN;
+#pragma unroll
+          for (int r = 0; r < 3; r++) {
+            col0[r] = r0 * ai[r];
+            col0[3 + r] = r0 * N * u0[r];
+          }
+#pragma unroll
+          for (int c = 0; c < 6; c++) { col1[c] = r1 * a1[c]; col2[c] = r2 * a2[c]; }
+          // B_i (right) = Hess_ii + (Gt Gt^T)_ii:
+          //   TL = coe (2/NN (combo1 - rh P) rh - 0.5 hat(jjt[0:3]))   (general 3x3)
+          //   TR = coe 2/NN a_i u0^T ; BR = coe 2 n/NN u0 u0^T
+          double D1[3][3];
+#pragma unroll
+          for (int r = 0; r < 3; r++)
+#pragma unroll
+            for (int c = 0; c < 3; c++)
+              D1[r][c] = C1[r][c] - (rh[r][0] * Pf[0][c] + rh[r][1] * Pf[1][c] + rh[r][2] * Pf[2][c]);
+          const double hj[3][3] = {{0, -jjt[2], jjt[1]}, {jjt[2], 0, -jjt[0]}, {-jjt[1], jjt[0], 0}};
+          const double k2 = 2.0 * coe * jNN;
+          double bd[24];
+          int q = 0;
+#pragma unroll
+          for (int r = 0; r < 3; r++)
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+              double d1rh = D1[r][0] * rh[0][c] + D1[r][1] * rh[1][c] + D1[r][2] * rh[2][c];
+              bd[q++] = k2 * d1rh - 0.5 * coe * hj[r][c];
+            }
+#pragma unroll
+          for (int r = 0; r < 3; r++)
+#pragma unroll
+            for (int c = 0; c < 3; c++) bd[q++] = k2 * ai[r] * u0[c];
+#pragma unroll
+          for (int r = 0; r < 3; r++)
+#pragma unroll
+            for (int c = r; c < 3; c++) bd[q++] = k2 * N * u0[r] * u0[c];
+#pragma unroll
+          for (int k = 0; k < 6; k++) sacc[k * W + i] += coe * jjt[k];
+#pragma unroll
+          for (int k = 0; k < 24; k++) sacc[(6 + k) * W + i] += bd[k];
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < 6; k++) col0[k] = col1[k] = col2[k] = 0.0;
+      }
+      store6(g0 + 6 * i, col0);
+      store6(g0 + (size_t)npad + 6 * i, col1);
+      store6(g0 + (size_t)2 * npad + 6 * i, col2);
+    }
+  }
+  __syncthreads();
+  double *dp = dpart + (size_t)blockIdx.x * DACC * W;
+  for (int t = threadIdx.x; t < DACC * W; t += blockDim.x) dp[t] = sacc[t];
+}
+
+int factors_grid(int W, int nfeat, int form) {
+  int dacc = form == 0 ? DACC_LEFT : DACC_RIGHT;
+  size_t lds = (size_t)(12 + dacc) * W * sizeof(double);
+  int per_cu = (int)(160 * 1024 / lds);
+  if (per_cu < 1) per_cu = 1;
+  if (per_cu > 4) per_cu = 4;
+  int grid = 256 * per_cu;
+  if (grid > nfeat) grid = nfeat;
+  if (grid < 1) grid = 1;
+  return grid;
+}
+
+void launch_factors(hipStream_t s, int form, const double *cl, const double *poses, const double *feat, int W,
+                    int npad, int f0, int f1, double *Gt, double *dpart, int nblk) {
+  int dacc = form == 0 ? DACC_LEFT : DACC_RIGHT;
+  size_t lds = (size_t)(12 + dacc) * W * sizeof(double);
+  int bs = W <= 64 ? 64 : (W <= 128 ? 128 : 256);
+  if (form == 0)
+    hipLaunchKernelGGL(k_feature_factors<0>, dim3(nblk), dim3(bs), lds, s, cl, poses, feat, W, npad, f0, f1, Gt, dpart);
+  else
+    hipLaunchKernelGGL(k_feature_factors<1>, dim3(nblk), dim3(bs), lds, s, cl, poses, feat, W, npad, f0, f1, Gt, dpart);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K3: hessian_syrk.  part[sg][tile] = Gt[I-rows, kslice] * Gt[J-rows, kslice]^T for the upper
+// triangle of 80x80 tiles.  One wavefront owns a full 80x80 accumulator (25 v_mfma_f64_16x16x4_f64
+// tiles = 200 accumulator VGPRs, one wave per SIMD); the four waves of a block take four
+// consecutive k sub-slices of the same tile and are summed through LDS, so split-K partial traffic
+// stays at SG (not 4 SG) tiles.  Operands come straight from HBM/L2: lane l of an MFMA operand is
+// Gt[k0 + (l>>4)][row0 + (l&15)] -- four 128-byte row segments per instruction.
+// ------------------------------------------------------------------------------------------------
+#include "syrk_mfma_asm.inc"
+
+__device__ __forceinline__ void load5(const double *__restrict__ p, double (&x)[TM]) {
+#pragma unroll
+  for (int r = 0; r < TM; r++) x[r] = p[16 * r];
+}
+
+// The 200 accumulator registers are pinned to AGPRs a0..a199 by generated inline asm
+// (gen/gen_syrk_asm.py explains why); the compiler only sees the operand loads.
+template <bool DIAG>
+__device__ __forceinline__ void syrk_sweep(const double *__restrict__ pa, const double *__restrict__ pb, size_t step,
+                                           int units) {
+  double a0[TM], b0[TM], a1[TM], b1[TM];
+  load5(pa, a0);
+  if (!DIAG) load5(pb, b0);
+  for (int u = 0; u < units; u++) {        // one unit = 8 columns of Gt = two MFMA k-steps
+    pa += step; pb += step;
+    load5(pa, a1);
+    if (!DIAG) load5(pb, b1);
+    if (DIAG) { BALM_SYRK_MFMA_DIAG(a0, a0) } else { BALM_SYRK_MFMA_FULL(a0, b0) }
+    pa += step; pb += step;
+    load5(pa, a0);                          // last unit: prefetches 4 columns past the slice (allocated)
+    if (!DIAG) load5(pb, b0);
+    if (DIAG) { BALM_SYRK_MFMA_DIAG(a1, a1) } else { BALM_SYRK_MFMA_FULL(a1, b1) }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_hessian_syrk(const double *__restrict__ Gt, int npad, int ntiles,
+                                                      const int *__restrict__ tileIJ, int units_per_slice,
+                                                      long nblocks, double *__restrict__ part) {
+  extern __shared__ __attribute__((aligned(16))) double sred[];   // [3][100][64]
+  // XCD-aware remap: hardware places block b on XCD b % 8; give every XCD a contiguous run of
+  // logical blocks (same k-slice group, neighbouring tiles) so shared Gt panels hit its L2.
+  long bid = blockIdx.x;
+  if ((nblocks & 7) == 0) bid = (bid & 7) * (nblocks >> 3) + (bid >> 3);
+  const int tile = (int)(bid % ntiles);
+  const int sg = (int)(bid / ntiles);
+  const int I = tileIJ[2 * tile], J = tileIJ[2 * tile + 1];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const long slice = (long)sg * 4 + wv;
+  const size_t k_begin = (size_t)slice * units_per_slice * 8;
+  const double *base = Gt + (k_begin + (lane >> 4)) * (size_t)npad + (lane & 15);
+  const double *pa = base + I * TILE;
+  const double *pb = base + J * TILE;
+  const size_t step = (size_t)4 * npad;
+
+  BALM_SYRK_ZERO_ACC();
+  if (I == J) syrk_sweep<true>(pa, pb, step, units_per_slice);
+  else syrk_sweep<false>(pa, pb, step, units_per_slice);
+  // MFMA (16 passes) -> v_accvgpr_read needs wait states the assembler will not insert for asm
+  asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+
+  // sum the four k sub-slices of this block through LDS (register-major layout, conflict-free)
+  if (wv > 0) {
+    double *dst = sred + (size_t)(wv - 1) * TILE_ELEMS + lane;
+#define BALM_X(T)                                                                             \
+  {                                                                                           \
+    unsigned U[8];                                                                            \
+    BALM_SYRK_READ_##T(U);                                                                    \
+    _Pragma("unroll") for (int e = 0; e < 4; e++) dst[(T * 4 + e) * 64] = __hiloint2double(U[2 * e + 1], U[2 * e]); \
+  }
+    BALM_SYRK_FOR_TILES(BALM_X)
+#undef BALM_X
+  }
+  __syncthreads();
+  if (wv == 0) {
+    double *out = part + ((size_t)sg * ntiles + tile) * TILE_ELEMS + lane;
+#define BALM_X(T)                                                                             \
+  {                                                                                           \
+    unsigned U[8];                                                                            \
+    BALM_SYRK_READ_##T(U);                                                                    \
+    _Pragma("unroll") for (int e = 0; e < 4; e++) {                                           \
+      const int o = (T * 4 + e) * 64;                                                         \
+      out[o] = __hiloint2double(U[2 * e + 1], U[2 * e]) + sred[o + lane] + sred[TILE_ELEMS + o + lane] + \
+               sred[2 * TILE_ELEMS + o + lane];                                               \
+    }                                                                                         \
+  }
+    BALM_SYRK_FOR_TILES(BALM_X)
+#undef BALM_X
+  }
+}
+
+SyrkPlan plan_syrk(int ntiles, long K) {
+  SyrkPlan p;
+  long units = (K + 7) / 8;
+  if (units < 1) units = 1;
+  long sg = (3840 + ntiles - 1) / ntiles;           // ~15 rounds of 256 CUs at W=200
+  long max_sg = units / (4 * 8);                    // keep >= 64 columns per wave
+  if (max_sg < 1) max_sg = 1;
+  if (sg > max_sg) sg = max_sg;
+  if (sg < 1) sg = 1;
+  long slices = sg * 4;
+  long ups = (units + slices - 1) / slices;
+  p.SG = (int)sg;
+  p.units_per_slice = (int)ups;
+  p.Kpad = (int)(slices * ups * 8);
+  p.nblocks = sg * ntiles;
+  return p;
+}
+
+void launch_syrk(hipStream_t s, const double *Gt, int npad, int ntiles, const int *tileIJ, const SyrkPlan &p,
+                 double *part) {
+  size_t lds = (size_t)3 * TILE_ELEMS * sizeof(double);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute((const void *)k_hessian_syrk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(k_hessian_syrk, dim3((unsigned)p.nblocks), dim3(256), lds, s, Gt, npad, ntiles, tileIJ,
+                     p.units_per_slice, p.nblocks, part);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K4a: deterministic reductions into the all-reduce payload  red = [tiles | dacc | r]
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_reduce(const double *__restrict__ part, int SG, long tile_total,
+                                                const double *__restrict__ dpart, int nblk, int dacc_len,
+                                                const double *__restrict__ rpart, int nr, double *__restrict__ red,
+                                                long dacc_off, long r_off) {
+  const long total = tile_total + dacc_len;
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+    if (t < tile_total) {
+      double s = 0.0;
+      for (int g = 0; g < SG; g++) s += part[(size_t)g * tile_total + t];
+      red[t] = s;
+    } else {
+      const long j = t - tile_total;
+      double s = 0.0;
+      for (int b = 0; b < nblk; b++) s += dpart[(size_t)b * dacc_len + j];
+      red[dacc_off + j] = s;
+    }
+  }
+  if (blockIdx.x == 0) {
+    __shared__ double sred[256];
+    double s = 0.0;
+    for (int t = threadIdx.x; t < nr; t += 256) s += rpart[t];
+    sred[threadIdx.x] = s;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) {
+      if (threadIdx.x < k) sred[threadIdx.x] += sred[threadIdx.x + k];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) red[r_off] = sred[0];
+  }
+}
+
+void launch_reduce(hipStream_t s, const double *part, int SG, long tile_total, const double *dpart, int nblk,
+                   int dacc_len, const double *rpart, int nr, double *red, long dacc_off, long r_off) {
+  long total = tile_total + dacc_len;
+  int grid = (int)((total + 255) / 256);
+  if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(k_reduce, dim3(grid), dim3(256), 0, s, part, SG, tile_total, dpart, nblk, dacc_len, rpart, nr,
+                     red, dacc_off, r_off);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K4b: H = blockdiag(B_i) - (Gt Gt^T), mirrored to the lower triangle (bavoxel.hpp:422-424);
+// g = per-pose gradient sums.  One lane per tile element.
+// MFMA f64 16x16x4 C/D layout: col = lane & 15, row = (lane >> 4) + 4 * reg.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int sym3(int r, int c) {   // index into xx xy xz yy yz zz
+  if (r > c) { int t = r; r = c; c = t; }
+  return r == 0 ? c : (r == 1 ? 2 + c : 5);
+}
+
+template <int FORM>
+__device__ __forceinline__ double blockdiag_at(const double *__restrict__ dacc, int W, int i, int r, int c) {
+  // left : 6 grad | TL sym(6) | TR (9, rows 0..2 x cols 3..5) | BR sym(6)
+  // right: 6 grad | TL full(9) | TR (9) | BR sym(6)
+  const double *d = dacc + i;
+  if (FORM == 0) {
+    if (r < 3 && c < 3) return d[(size_t)(6 + sym3(r, c)) * W];
+    if (r < 3 && c >= 3) return d[(size_t)(12 + 3 * r + (c - 3)) * W];
+    if (r >= 3 && c < 3) return d[(size_t)(12 + 3 * c + (r - 3)) * W];
+    return d[(size_t)(21 + sym3(r - 3, c - 3)) * W];
+  } else {
+    if (r < 3 && c < 3) return d[(size_t)(6 + 3 * r + c) * W];
+    if (r < 3 && c >= 3) return d[(size_t)(15 + 3 * r + (c - 3)) * W];
+    if (r >= 3 && c < 3) return d[(size_t)(15 + 3 * c + (r - 3)) * W];
+    return d[(size_t)(24 + sym3(r - 3, c - 3)) * W];
+  }
+}
+
+template <int FORM>
+__global__ __launch_bounds__(256) void k_assemble(const double *__restrict__ red, long dacc_off,
+                                                  const int *__restrict__ tileIJ, int ntiles, int W,
+                                                  double *__restrict__ H, double *__restrict__ g) {
+  const int n = 6 * W;
+  const long total = (long)ntiles * TILE_ELEMS;
+  const double *dacc = red + dacc_off;
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+    const int tile = (int)(t / TILE_ELEMS);
+    const int e = (int)(t - (long)tile * TILE_ELEMS);
+    const int lane = e & 63, slot = e >> 6;
+    const int reg = slot & 3, mt = slot >> 2;
+    const int mr = mt / TM, mc = mt - mr * TM;
+    const int I = tileIJ[2 * tile], J = tileIJ[2 * tile + 1];
+    const int row = I * TILE + mr * 16 + (lane >> 4) + 4 * reg;
+    const int col = J * TILE + mc * 16 + (lane & 15);
+    if (row >= n || col >= n || row > col) continue;   // diagonal tiles: only r <= c was computed
+    double val = -red[t];
+    const int pi = row / 6, pj = col / 6;
+    if (pi == pj) {
+      const int r = row - 6 * pi, c = col - 6 * pi;
+      val += blockdiag_at<FORM>(dacc, W, pi, r, c);
+      if (FORM == 1 && r != c) {
+        // the right form's diagonal block is not forced symmetric in the reference (:129)
+        H[(size_t)row * n + col] = -red[t] + blockdiag_at<FORM>(dacc, W, pi, c, r);
+        H[(size_t)col * n + row] = val;
+        continue;
+      }
+    }
+    H[(size_t)col * n + row] = val;
+    H[(size_t)row * n + col] = val;
+  }
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long)gridDim.x * blockDim.x) {
+    const int i = (int)(t / 6), k = (int)(t - 6 * (t / 6));
+    g[t] = dacc[(size_t)k * W + i];
+  }
+}
+
+void launch_assemble(hipStream_t s, int form, const double *red, long dacc_off, const int *tileIJ, int ntiles, int W,
+                     double *H, double *g) {
+  long total = (long)ntiles * TILE_ELEMS;
+  int grid = (int)((total + 255) / 256);
+  if (grid > 4096) grid = 4096;
+  if (form == 0)
+    hipLaunchKernelGGL(k_assemble<0>, dim3(grid), dim3(256), 0, s, red, dacc_off, tileIJ, ntiles, W, H, g);
+  else
+    hipLaunchKernelGGL(k_assemble<1>, dim3(grid), dim3(256), 0, s, red, dacc_off, tileIJ, ntiles, W, H, g);
+}
+
+}  // namespace balm

@@ -99,7 +99,10 @@ void gen_feature(Engine &e, Dists &d, int a, int W, int pts, const std::vector<M
       for (int r = 0; r < 3; r++) q.v[r] += centre.v[r];
       V3 dq{{q.v[0] - ps[j].v[0], q.v[1] - ps[j].v[1], q.v[2] - ps[j].v[2]}};
       V3 b = mtv(Rs[j], dq);
-      float fx = (float)b.v[0], fy = (float)b.v[1], fz = (float)b.v[2];
+      // pcl::PointXYZINormal stores float32; volatile pins the rounding (g++ 11 -O3 otherwise
+      // folds the double->float->double round trip of x and y away inside the SLP-vectorised body)
+      volatile float vfx = (float)b.v[0], vfy = (float)b.v[1], vfz = (float)b.v[2];
+      const float fx = vfx, fy = vfy, fz = vfz;
       if (points_a) {
         float *o = points_a + 3 * ((size_t)j * pts + k);
         o[0] = fx; o[1] = fy; o[2] = fz;
@@ -119,10 +122,12 @@ extern "C" {
 // mode 1: trajectory and pose noise from engine(seed); feature a from its own engine(seed+1+a),
 //         generated on `threads` host threads (large scenes; not the reference's stream).
 // points (optional, may be NULL): F*W*pts*3 floats, body-frame points in (feature, pose, k) order.
+// feature_offset (mode 1 only): global index of this call's first feature, so that ranks of a
+//         sharded run draw disjoint features against the same trajectory and pose noise.
 // coeffs[a] = W*pts (benchmark_virtual.cpp:391).  Returns 0.
 int balm_scene_generate(unsigned seed, int W, int F, int pts, double point_noise, double surf_range,
-                        int mode, int threads, double *poses_gt, double *poses_init,
-                        double *clusters, double *coeffs, float *points) {
+                        int mode, int threads, int feature_offset, double *poses_gt,
+                        double *poses_init, double *clusters, double *coeffs, float *points) {
   std::default_random_engine e(seed);
   Dists d(surf_range, point_noise);
   std::normal_distribution<double> rand_traj(-1, 1);   // sic, :559
@@ -154,8 +159,9 @@ int balm_scene_generate(unsigned seed, int W, int F, int pts, double point_noise
       th.emplace_back([&, t]() {
         Dists dl(surf_range, point_noise);
         for (int a = t; a < F; a += T) {
-          std::mt19937_64 ef((uint64_t)seed * 1000003ull + 1 + a);
-          gen_feature(ef, dl, a, W, pts, Rs, ps, clusters + cstride * a,
+          const int ga = a + feature_offset;
+          std::mt19937_64 ef((uint64_t)seed * 1000003ull + 1 + ga);
+          gen_feature(ef, dl, ga, W, pts, Rs, ps, clusters + cstride * a,
                       points ? points + pstride * a : nullptr);
         }
       });

@@ -48,9 +48,10 @@ def _p(a):
 
 
 def generate(seed, W, F, pts, point_noise=0.01, surf_range=2.0, mode=0, threads=None,
-             keep_points=False):
+             keep_points=False, feature_offset=0):
     """mode 0 = one RNG stream in the reference's draw order; mode 1 = per-feature streams,
-    generated on `threads` host threads (large scenes)."""
+    generated on `threads` host threads (large scenes); `feature_offset` = global index of the
+    first feature (ranks of a sharded run share trajectory and pose noise, not features)."""
     if threads is None:
         threads = min(os.cpu_count() or 1, 32)
     gt = np.zeros((W, 12))
@@ -59,7 +60,7 @@ def generate(seed, W, F, pts, point_noise=0.01, surf_range=2.0, mode=0, threads=
     co = np.zeros(F)
     points = np.zeros((F, W, pts, 3), dtype=np.float32) if keep_points else None
     rc = _lib().balm_scene_generate(C.c_uint(seed), W, F, pts, C.c_double(point_noise),
-                                    C.c_double(surf_range), mode, threads, _p(gt), _p(init), _p(cl),
+                                    C.c_double(surf_range), mode, threads, int(feature_offset), _p(gt), _p(init), _p(cl),
                                     _p(co), _p(points))
     assert rc == 0
     return Scene(W, F, pts, gt, init, cl, co, points)

@@ -1,0 +1,146 @@
+/* balm_hip.h -- C ABI of libbalm_hip.so: the MI355X (gfx950, HIP) implementation of BALM 2.0's
+ * second-order bundle-adjustment hot path.  Plain C types, caller-owned host buffers, int status
+ * returns, no exceptions, no exit().  One context per caller thread; every call is synchronous
+ * (device work for the call has finished when it returns).
+ *
+ * The reference has no FFI for this path; its "API" is the method surface of two header classes
+ * (VOX_HESS, BALM2) plus the mutable global `int win_size` (src/benchmark/bavoxel.hpp:17).  Each
+ * entry point below names the reference interface it replaces (paths relative to the reference
+ * root).  include/balm_shim.hpp re-declares VOX_HESS / BALM2 with the reference's signatures on
+ * top of this ABI; INTEGRATION.md shows the binding.
+ *
+ * Layouts (all FP64):
+ *   pose     12 doubles: R column-major (R(r,c) = q[3*c+r]) then p          include/tools.hpp:144-145
+ *   cluster  10 doubles: Pxx Pxy Pxz Pyy Pyz Pzz vx vy vz N                 include/tools.hpp:290-295
+ *   clusters F*W*10, feature-major: clusters[(a*W + i)*10 + c]; an all-zero cluster (N == 0)
+ *            means "pose i does not observe feature a"
+ *   Hess     (6W)x(6W) column-major, fully symmetric-filled; pose block i = rows 6i..6i+5 =
+ *            [dtheta(3); dt(3)]  (DVEL = 6, include/tools.hpp:20)
+ */
+#ifndef BALM_HIP_H
+#define BALM_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct balm_ctx balm_ctx;
+
+enum { BALM_FORM_LEFT = 0, BALM_FORM_RIGHT = 1 };
+
+enum {
+  BALM_OK = 0,
+  BALM_ERR_ARG = 1,            /* bad argument                                              */
+  BALM_ERR_HIP = 2,            /* HIP runtime error; see balm_last_error()                  */
+  BALM_ERR_STATE = 3,          /* call order (e.g. evaluate before set_features)            */
+  BALM_ERR_TOO_FEW_PLANES = 4, /* replaces printf+exit(0) at bavoxel.hpp:1079-1085          */
+  BALM_ERR_NUMERIC = 5         /* non-finite residual / zero point count                    */
+};
+
+/* balm_create flags */
+enum {
+  BALM_FLAG_TIMING = 1   /* record HIP events around every kernel class (balm_get_timing) */
+};
+
+/* One row per LM iteration; the quantities the reference prints at bavoxel.hpp:1132. */
+typedef struct balm_iter_log {
+  double r1, r2, u, v, q, q1;   /* q = r1 - r2 (before the gain-ratio rescale)              */
+  int accepted;                 /* q > 0                                                     */
+  int hess_evaluated;           /* Hessian/gradient were recomputed at this iteration        */
+} balm_iter_log;
+
+/* LM loop constants.  bavoxel.hpp:1087,1104,1155 use u0=0.01, max_iter=10, rel_tol=1e-6,
+ * min_planes_per_pose=20; benchmark_virtual.cpp:380,408,453 use u0=0.1, max_iter=20, no plane
+ * precheck. */
+typedef struct balm_lm_opts {
+  int form;                 /* BALM_FORM_LEFT (active in the reference) or BALM_FORM_RIGHT   */
+  double u0;
+  int max_iter;
+  double rel_tol;
+  int min_planes_per_pose;  /* 0 disables the precheck                                       */
+  int force_hess;           /* benchmarking: re-evaluate the Hessian on every iteration      */
+  int no_stop;              /* benchmarking: ignore the rel_tol stop, run max_iter           */
+  int verbose;              /* print the reference's per-iteration line                      */
+  int reanchor;             /* express poses relative to pose 0 at the end (:1159-1164)      */
+} balm_lm_opts;
+
+/* Replaces the global `int win_size` (bavoxel.hpp:17) + object construction.  `device` is the
+ * HIP device ordinal this context owns (one process per GPU sets it to LOCAL_RANK). */
+balm_ctx *balm_create(int win_size, int device, int flags);
+void balm_destroy(balm_ctx *ctx);
+
+/* Replaces F calls of VOX_HESS::push_voxel (bavoxel.hpp:30-51): the shim flattens the borrowed
+ * `const vector<PointCluster>*` / `const PointCluster* fix` pointers into these arrays.  Copies to
+ * HBM.  `fix` (F*10) may be NULL (= all-empty fix clusters); `coeffs` are the per-feature weights
+ * (bavoxel.hpp:42-44; benchmark_virtual.cpp:391).  Features seen by fewer than 2 poses are the
+ * caller's to drop (push_voxel :32-37); they are legal here and contribute like any other. */
+int balm_set_features(balm_ctx *ctx, int F, const double *clusters, const double *fix,
+                      const double *coeffs);
+
+/* Replaces VOX_HESS::left_evaluate_acc2 (bavoxel.hpp:304-426; form 0) and
+ * VOX_HESS::acc_evaluate2 (bavoxel.hpp:53-158; form 1) over features [head,end), and -- with
+ * head=0,end=F -- BALM2::divide_thread_left/right (bavoxel.hpp:1025-1059,989-1023).  Outputs are
+ * overwritten; Hess (may be NULL) is returned fully symmetric.  With an all-reduce hook installed
+ * the outputs are the sums over all ranks. */
+int balm_evaluate(balm_ctx *ctx, int form, const double *poses, int head, int end, double *Hess,
+                  double *JacT, double *residual);
+
+/* Replaces VOX_HESS::evaluate_only_residual / BALM2::only_residual (bavoxel.hpp:428-470,
+ * 1061-1067). */
+int balm_only_residual(balm_ctx *ctx, const double *poses, double *residual);
+
+/* Replaces `D.diagonal() = Hess.diagonal(); dxi = (Hess + u*D).ldlt().solve(-JacT);`
+ * (bavoxel.hpp:1113-1114) and `q1 = 0.5*dxi.dot(u*D*dxi-JacT)` (:1127).  Same elimination order
+ * as Eigen's LDLT (diagonal pivots by decreasing |diag|), D may be indefinite.  n = 6*win_size.
+ * q1 may be NULL. */
+int balm_solve_damped(balm_ctx *ctx, const double *Hess, const double *JacT, double u, double *dxi,
+                      double *q1);
+
+/* Replaces BALM2::damping_iter (bavoxel.hpp:1069-1166) and the LM loop of BALM2::dampingIter
+ * (benchmark_virtual.cpp:380-479): device-resident loop, poses updated in place.  `log` (may be
+ * NULL) must hold opts->max_iter rows; *n_iters receives the iterations executed. */
+int balm_damping_iter(balm_ctx *ctx, const balm_lm_opts *opts, double *poses_inout,
+                      balm_iter_log *log, int *n_iters);
+
+/* Replaces the per-point PointCluster::push loops (tools.hpp:311-316; benchmark_virtual.cpp:
+ * 392-403; bavoxel.hpp:1194-1198): builds the F*W clusters on the device from body-frame points
+ * keyed by (feature, pose) and installs them like balm_set_features.  xyz: n_pts*3 floats;
+ * feat_id / pose_id: n_pts ints.  clusters_out (F*W*10, may be NULL) receives a host copy. */
+int balm_build_clusters(balm_ctx *ctx, int F, const float *xyz, const int *feat_id,
+                        const int *pose_id, long n_pts, const double *fix, const double *coeffs,
+                        double *clusters_out);
+
+/* Multi-GPU: features are sharded across one-process-per-GPU ranks; each rank installs its shard
+ * with balm_set_features and a hook that sums a device buffer of n doubles across ranks in place
+ * (RCCL allreduce over xGMI; replaces the serial `Hess += hessians[i]` at bavoxel.hpp:1049-1056).
+ * The hook is called with the library's stream already synchronised and must return after the
+ * reduced data is visible on the device.  Return 0 on success. */
+typedef int (*balm_allreduce_fn)(void *dev_buf, long n_doubles, void *user);
+int balm_set_allreduce(balm_ctx *ctx, balm_allreduce_fn fn, void *user);
+
+/* Timing (BALM_FLAG_TIMING): accumulated HIP-event milliseconds and launch counts per kernel
+ * class since the last reset.  Slots: see BALM_T_* below.  ms/count arrays of BALM_T_COUNT. */
+enum {
+  BALM_T_MOMENTS = 0,   /* world_moments + feature_eigen + residual reduce (= only_residual)  */
+  BALM_T_FACTORS = 1,   /* feature_factors (G-tilde, gradient, block-diagonal partials)       */
+  BALM_T_SYRK = 2,      /* hessian_syrk (f64 MFMA) -- the dominant kernel                     */
+  BALM_T_ASSEMBLE = 3,  /* split-K reduce + assemble H, g                                      */
+  BALM_T_SOLVE = 4,     /* permute + blocked LDL^T + triangular solves                        */
+  BALM_T_UPDATE = 5,    /* pose update + gain-ratio scalars                                   */
+  BALM_T_COUNT = 6
+};
+int balm_get_timing(balm_ctx *ctx, double *ms, long *count);
+int balm_reset_timing(balm_ctx *ctx);
+
+/* Work model of the last balm_set_features: out[0] = S = sum_a n_a, out[1] = sum_a n_a(n_a+1)/2,
+ * out[2] = algorithmic FLOPs of one hessian_syrk launch (dense, upper triangle incl. diagonal
+ * blocks: 108*F*W*(W+1) flops), out[3] = FLOPs the launch actually issues (tile padding incl.). */
+int balm_work_model(balm_ctx *ctx, double *out4);
+
+const char *balm_last_error(balm_ctx *ctx);
+const char *balm_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BALM_HIP_H */

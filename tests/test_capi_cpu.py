@@ -1,0 +1,48 @@
+"""CPU-side checks of the drop-in boundary: libbalm_hip.so loads and exports every symbol that
+include/balm_hip.h declares; without a GPU the product path fails loudly (no CPU fallback)."""
+import os
+import re
+
+import pytest
+
+from balm_amd import capi
+from conftest import HAS_GPU, ROOT
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "balm_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(balm_[a-z_]+)\s*\(", text)) - {"balm_allreduce_fn"})
+
+
+def test_library_exports_every_declared_symbol():
+    L = capi.lib()
+    syms = _declared_symbols()
+    assert len(syms) >= 14
+    for s in syms:
+        assert hasattr(L, s), "libbalm_hip.so does not export %s" % s
+    assert set(syms) == set(capi.EXPORTS)
+    assert b"gfx950" in L.balm_version()
+
+
+def test_product_package_never_touches_the_oracle():
+    """only tests/, smoke() and bench.py's cpu_baseline leg may use oracle/."""
+    pkg = os.path.join(ROOT, "balm_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".h", ".hpp", ".inc")):
+                src = open(os.path.join(dp, f)).read()
+                assert "oracle" not in src.lower(), "%s mentions the oracle" % os.path.join(dp, f)
+
+
+@pytest.mark.skipif(HAS_GPU, reason="GPU present")
+def test_fails_loudly_without_gpu():
+    with pytest.raises(capi.BalmError):
+        capi.Context(20)
+
+
+def test_bad_window_is_rejected():
+    with pytest.raises(capi.BalmError):
+        capi.Context(0)
+    with pytest.raises(capi.BalmError):
+        capi.Context(100000)

@@ -1,0 +1,118 @@
+// FP64 peak microbenchmarks for gfx950: v_mfma_f64_16x16x4_f64, v_fma_f64, and both together.
+// Confirms the roofline peak that bench.py prices hessian_syrk against (MI355X_MICROARCH.md gives
+// 157.3 TF fp32 vector/matrix; FP64 = half that = 78.6 TF is the working assumption).
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+template <int NACC>
+__global__ __launch_bounds__(256) void k_mfma(double *out, int iters, double seed) {
+  d4 acc[NACC];
+  for (int i = 0; i < NACC; i++) acc[i] = (d4){0, 0, 0, 0};
+  double a = seed + threadIdx.x * 1e-3, b = seed - threadIdx.x * 1e-3;
+  for (int it = 0; it < iters; it++) {
+#pragma unroll
+    for (int i = 0; i < NACC; i++) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+  }
+  double s = 0;
+  for (int i = 0; i < NACC; i++) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+template <int NCH>
+__global__ __launch_bounds__(256) void k_fma(double *out, int iters, double seed) {
+  double x[NCH];
+  for (int i = 0; i < NCH; i++) x[i] = seed + i + threadIdx.x * 1e-6;
+  const double m = 1.0000001, c = 1e-9;
+  for (int it = 0; it < iters; it++) {
+#pragma unroll
+    for (int i = 0; i < NCH; i++) x[i] = __builtin_fma(x[i], m, c);
+  }
+  double s = 0;
+  for (int i = 0; i < NCH; i++) s += x[i];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+// waves 0..(nm-1) of each block run MFMA, the rest VALU fma: do the two pipes overlap for f64?
+template <int NACC, int NCH>
+__global__ __launch_bounds__(512) void k_mixed(double *out, int iters, int iters_fma, int n_mfma_waves, double seed) {
+  const int wv = threadIdx.x >> 6;
+  double s = 0;
+  if (wv < n_mfma_waves) {
+    d4 acc[NACC];
+    for (int i = 0; i < NACC; i++) acc[i] = (d4){0, 0, 0, 0};
+    double a = seed + threadIdx.x * 1e-3, b = seed - threadIdx.x * 1e-3;
+    for (int it = 0; it < iters; it++) {
+#pragma unroll
+      for (int i = 0; i < NACC; i++) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+    }
+    for (int i = 0; i < NACC; i++) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+  } else {
+    double x[NCH];
+    for (int i = 0; i < NCH; i++) x[i] = seed + i + threadIdx.x * 1e-6;
+    const double m = 1.0000001, c = 1e-9;
+    for (int it = 0; it < iters_fma; it++) {
+#pragma unroll
+      for (int i = 0; i < NCH; i++) x[i] = __builtin_fma(x[i], m, c);
+    }
+    for (int i = 0; i < NCH; i++) s += x[i];
+  }
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+__global__ void k_copy(const double4 *__restrict__ in, double4 *__restrict__ out, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = in[i];
+}
+
+template <class F>
+float time_ms(F f, int reps = 5) {
+  hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+  f();  hipDeviceSynchronize();
+  float best = 1e30f;
+  for (int r = 0; r < reps; r++) {
+    hipEventRecord(a); f(); hipEventRecord(b); hipEventSynchronize(b);
+    float ms; hipEventElapsedTime(&ms, a, b); if (ms < best) best = ms;
+  }
+  return best;
+}
+
+int main() {
+  hipDeviceProp_t p; hipGetDeviceProperties(&p, 0);
+  printf("device: %s  CUs=%d  clock=%d MHz\n", p.name, p.multiProcessorCount, p.clockRate / 1000);
+  const int CU = p.multiProcessorCount;
+  double *out; hipMalloc(&out, sizeof(double) * 512 * CU * 8);
+  const int iters = 20000;
+  for (int wpb : {4, 8}) {       // waves per block = waves per CU (1 block/CU)
+    {
+      float ms = time_ms([&] { hipLaunchKernelGGL(k_mfma<8>, dim3(CU), dim3(64 * wpb), 0, 0, out, iters, 1.0); });
+      double fl = (double)CU * wpb * iters * 8 * 2048.0;
+      printf("mfma_f64_16x16x4  %d waves/CU: %8.3f ms  %7.2f TFLOP/s  (%.1f cycles/MFMA/SIMD @2.4GHz)\n", wpb, ms, fl / ms / 1e9,
+             ms * 1e-3 * 2.4e9 / ((double)iters * 8 * wpb / 4));
+    }
+    {
+      float ms = time_ms([&] { hipLaunchKernelGGL(k_fma<16>, dim3(CU), dim3(64 * wpb), 0, 0, out, iters, 1.0); });
+      double fl = (double)CU * wpb * 64 * iters * 16 * 2.0;
+      printf("v_fma_f64         %d waves/CU: %8.3f ms  %7.2f TFLOP/s\n", wpb, ms, fl / ms / 1e9);
+    }
+  }
+  {  // 8 waves/CU: 4 MFMA + 4 VALU, sized to take about equally long alone
+    const int im = iters, ifma = iters * 4;     // 8 MFMA*2048 flop vs 16 fma*128 flop per iteration
+    float ms = time_ms([&] { hipLaunchKernelGGL((k_mixed<8, 16>), dim3(CU), dim3(512), 0, 0, out, im, ifma, 4, 1.0); });
+    double fm = (double)CU * 4 * im * 8 * 2048.0, fv = (double)CU * 4 * 64 * (double)ifma * 16 * 2.0;
+    printf("mixed 4 MFMA + 4 VALU waves/CU: %8.3f ms  mfma %.2f + valu %.2f = %.2f TFLOP/s\n", ms, fm / ms / 1e9, fv / ms / 1e9,
+           (fm + fv) / ms / 1e9);
+    float ms_m = time_ms([&] { hipLaunchKernelGGL((k_mixed<8, 16>), dim3(CU), dim3(512), 0, 0, out, im, 0, 4, 1.0); });
+    float ms_v = time_ms([&] { hipLaunchKernelGGL((k_mixed<8, 16>), dim3(CU), dim3(512), 0, 0, out, 0, ifma, 4, 1.0); });
+    printf("   alone: mfma part %.3f ms, valu part %.3f ms  (overlap if mixed ~ max, serial if ~ sum)\n", ms_m, ms_v);
+  }
+  {
+    size_t n = (size_t)1 << 26;   // 64M double4 = 2 GiB
+    double4 *a, *b; hipMalloc(&a, n * 32); hipMalloc(&b, n * 32); hipMemset(a, 1, n * 32);
+    float ms = time_ms([&] { hipLaunchKernelGGL(k_copy, dim3(CU * 8), dim3(256), 0, 0, a, b, n); });
+    printf("copy 2 GiB: %.3f ms  %.2f TB/s (read+write)\n", ms, 2.0 * n * 32 / ms / 1e9);
+    hipFree(a); hipFree(b);
+  }
+  hipFree(out);
+  return 0;
+}
