@@ -68,9 +68,8 @@ struct balm_ctx {
   double *d_H = nullptr;            // [n][n] column-major
   double *d_g = nullptr;            // [n]
   // solver
-  double *d_A = nullptr;            // [nA][nA] permuted damped matrix -> L (unit lower) in place
-  double *d_Wp = nullptr;           // [NB][nA]  W21 = L21 * D11 of the current panel
-  double *d_Minv = nullptr;         // [nA/NB][NB*NB] inverses of the unit-lower diagonal blocks
+  double *d_A = nullptr;            // [nA cols][nA+NB rows] permuted damped matrix + RHS row tile -> L in place
+  double *d_Wp = nullptr;           // [NB][nA+NB]  W21 = L21 * D11 of the current panel
   double *d_dvec = nullptr;         // [nA] pivots D
   int *d_perm = nullptr;            // [nA] position -> original index
   double *d_dx = nullptr;           // [n]

@@ -648,44 +648,71 @@ void launch_syrk(hipStream_t s, const double *Gt, int npad, int ntiles, const in
 // ------------------------------------------------------------------------------------------------
 // K4a: deterministic reductions into the all-reduce payload  red = [tiles | dacc | r]
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_reduce(const double *__restrict__ part, int SG, long tile_total,
-                                                const double *__restrict__ dpart, int nblk, int dacc_len,
-                                                const double *__restrict__ rpart, int nr, double *__restrict__ red,
-                                                long dacc_off, long r_off) {
-  const long total = tile_total + dacc_len;
-  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
-    if (t < tile_total) {
-      double s = 0.0;
-      for (int g = 0; g < SG; g++) s += part[(size_t)g * tile_total + t];
-      red[t] = s;
-    } else {
-      const long j = t - tile_total;
-      double s = 0.0;
-      for (int b = 0; b < nblk; b++) s += dpart[(size_t)b * dacc_len + j];
-      red[dacc_off + j] = s;
+__global__ __launch_bounds__(256) void k_reduce_tiles(const double *__restrict__ part, int SG, long tile_total,
+                                                      double *__restrict__ red) {
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < tile_total; t += (long)gridDim.x * blockDim.x) {
+    // fixed summation order (deterministic), four independent chains to keep loads in flight
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    const double *pp = part + t;
+    int g = 0;
+    for (; g + 3 < SG; g += 4) {
+      s0 += pp[(size_t)g * tile_total];
+      s1 += pp[(size_t)(g + 1) * tile_total];
+      s2 += pp[(size_t)(g + 2) * tile_total];
+      s3 += pp[(size_t)(g + 3) * tile_total];
     }
+    for (; g < SG; g++) s0 += pp[(size_t)g * tile_total];
+    red[t] = (s0 + s1) + (s2 + s3);
   }
+}
+
+// per-pose accumulators: sum over the feature_factors workgroups.  64 outputs per workgroup, the
+// workgroup index range split over the four waves, eight loads in flight per lane.
+__global__ __launch_bounds__(256) void k_reduce_dacc(const double *__restrict__ dpart, int nblk, int dacc_len,
+                                                     const double *__restrict__ rpart, int nr,
+                                                     double *__restrict__ red_dacc, double *__restrict__ red_r) {
+  __shared__ double sq[256];
+  const int jl = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int j = blockIdx.x * 64 + jl;
+  double s = 0.0;
+  if (j < dacc_len) {
+    const int chunk = (nblk + 3) / 4;
+    const int b0 = q * chunk, b1 = min(nblk, b0 + chunk);
+    double a[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) a[k] = 0.0;
+    int b = b0;
+    for (; b + 7 < b1; b += 8) {
+#pragma unroll
+      for (int k = 0; k < 8; k++) a[k] += dpart[(size_t)(b + k) * dacc_len + j];
+    }
+    for (; b < b1; b++) a[0] += dpart[(size_t)b * dacc_len + j];
+    s = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+  }
+  sq[threadIdx.x] = s;
+  __syncthreads();
+  if (q == 0 && j < dacc_len) red_dacc[j] = (sq[jl] + sq[64 + jl]) + (sq[128 + jl] + sq[192 + jl]);
   if (blockIdx.x == 0) {
-    __shared__ double sred[256];
-    double s = 0.0;
-    for (int t = threadIdx.x; t < nr; t += 256) s += rpart[t];
-    sred[threadIdx.x] = s;
+    __syncthreads();
+    double r = 0.0;
+    for (int t = threadIdx.x; t < nr; t += 256) r += rpart[t];
+    sq[threadIdx.x] = r;
     __syncthreads();
     for (int k = 128; k > 0; k >>= 1) {
-      if (threadIdx.x < k) sred[threadIdx.x] += sred[threadIdx.x + k];
+      if (threadIdx.x < k) sq[threadIdx.x] += sq[threadIdx.x + k];
       __syncthreads();
     }
-    if (threadIdx.x == 0) red[r_off] = sred[0];
+    if (threadIdx.x == 0) red_r[0] = sq[0];
   }
 }
 
 void launch_reduce(hipStream_t s, const double *part, int SG, long tile_total, const double *dpart, int nblk,
                    int dacc_len, const double *rpart, int nr, double *red, long dacc_off, long r_off) {
-  long total = tile_total + dacc_len;
-  int grid = (int)((total + 255) / 256);
-  if (grid > 4096) grid = 4096;
-  hipLaunchKernelGGL(k_reduce, dim3(grid), dim3(256), 0, s, part, SG, tile_total, dpart, nblk, dacc_len, rpart, nr,
-                     red, dacc_off, r_off);
+  int grid = (int)((tile_total + 255) / 256);
+  if (grid > 8192) grid = 8192;
+  hipLaunchKernelGGL(k_reduce_tiles, dim3(grid), dim3(256), 0, s, part, SG, tile_total, red);
+  hipLaunchKernelGGL(k_reduce_dacc, dim3((dacc_len + 63) / 64), dim3(256), 0, s, dpart, nblk, dacc_len, rpart, nr,
+                     red + dacc_off, red + r_off);
 }
 
 // ------------------------------------------------------------------------------------------------

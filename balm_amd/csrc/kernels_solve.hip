@@ -6,10 +6,12 @@
 // |diagonal| of the input matrix".  We therefore apply that static symmetric permutation once and
 // run an un-pivoted *blocked* LDL^T (D diagonal, possibly negative: the exact second-order Hessian
 // is indefinite away from the optimum, SURVEY.md finding 4):
-//   per panel of NB=48 columns:  ldl_diag  (one workgroup, LDS)       L11, D11, M = L11^-1
-//                                ldl_panel (row blocks)               W21 = A21 M^T, L21 = W21 D11^-1
-//                                ldl_trail (f64 MFMA, 48x48 tiles)    A22 -= L21 W21^T
-//   then one workgroup does  P b -> L^-1 -> D^+ -> L^-T -> P^T  using the stored M blocks.
+//   per panel of NB=48 columns:  ldl_panel (single-wave workgroups)   L11, D11 in registers (redundantly per
+//                                                                     workgroup), W21 = L21 D11, L21
+//                                ldl_trail (f64 MFMA, 48x16 tiles)    A22 -= L21 W21^T
+//   The right-hand side rides along as one extra row below the matrix (row nA of the ldA = nA+NB
+//   row storage): the panel / trail kernels then produce z = D^+ L^-1 P b for free, and only the
+//   backward solve  L^T x = z  (+ un-permute, q1) is left for one workgroup in 16-column sub-panels.
 // Pose update kernels (bavoxel.hpp:1116-1126, 1159-1164) live here too.
 #include <cfloat>
 
@@ -20,245 +22,255 @@ namespace balm {
 typedef double d4 __attribute__((ext_vector_type(4)));
 
 // ------------------------------------------------------------------------------------------------
-// permutation by decreasing |diag H| (ties by index); padded positions (>= n) go last
+// permutation by decreasing |diag H| (ties by index); padded positions (>= n) go last.
+// 64 ranks per workgroup, the j-range split over the four waves.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_rank_diag(const double *__restrict__ H, int n, int nA,
-                                                    int *__restrict__ perm) {
-  extern __shared__ __attribute__((aligned(16))) double dabs[];
+__global__ __launch_bounds__(256) void k_rank_diag(const double *__restrict__ H, int n, int nA,
+                                                   int *__restrict__ perm) {
+  extern __shared__ __attribute__((aligned(16))) double dabs[];   // [nA] then int part[256]
+  int *part = reinterpret_cast<int *>(dabs + nA);
   for (int i = threadIdx.x; i < nA; i += blockDim.x) dabs[i] = i < n ? fabs(H[(size_t)i * n + i]) : -1.0;
   __syncthreads();
-  for (int i = threadIdx.x; i < nA; i += blockDim.x) {
+  const int il = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + il;
+  int rank = 0;
+  if (i < nA) {
     const double di = dabs[i];
-    int rank = 0;
-    for (int j = 0; j < nA; j++) {
+    const int chunk = (nA + 3) / 4;
+    const int j0 = q * chunk, j1 = min(nA, j0 + chunk);
+    for (int j = j0; j < j1; j++) {
       const double dj = dabs[j];
       rank += (dj > di) || (dj == di && j < i);
     }
-    if (di != di) rank = i;   // NaN: keep it somewhere valid; the solve is garbage anyway
+  }
+  part[threadIdx.x] = rank;
+  __syncthreads();
+  if (q == 0 && i < nA) {
+    rank = part[il] + part[64 + il] + part[128 + il] + part[192 + il];
+    if (dabs[i] != dabs[i]) rank = i;   // NaN: keep it somewhere valid; the solve is garbage anyway
     perm[rank] = i;
   }
 }
 
-__global__ __launch_bounds__(256) void k_build_A(const double *__restrict__ H, int n, int nA,
-                                                 const int *__restrict__ perm, double u, double *__restrict__ A) {
-  const long total = (long)nA * nA;
+__global__ __launch_bounds__(256) void k_build_A(const double *__restrict__ H, const double *__restrict__ g, int n,
+                                                 int nA, const int *__restrict__ perm, double u,
+                                                 double *__restrict__ A) {
+  const int ldA = nA + NB;
+  const long total = (long)ldA * nA;
   for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
-    const int c = (int)(t / nA), r = (int)(t - (long)c * nA);
-    const int pr = perm[r], pc = perm[c];
+    const int c = (int)(t / ldA), r = (int)(t - (long)c * ldA);
+    const int pc = perm[c];
     double v;
-    if (pr < n && pc < n) {
-      v = H[(size_t)pc * n + pr];
-      if (r == c) v += u * v;      // D = diag(H)  (bavoxel.hpp:1113)
+    if (r < nA) {
+      const int pr = perm[r];
+      if (pr < n && pc < n) {
+        v = H[(size_t)pc * n + pr];
+        if (r == c) v += u * v;      // D = diag(H)  (bavoxel.hpp:1113)
+      } else {
+        v = (r == c) ? 1.0 : 0.0;
+      }
     } else {
-      v = (r == c) ? 1.0 : 0.0;
+      v = (r == nA && pc < n) ? -g[pc] : 0.0;     // right-hand side row: P (-JacT)
     }
     A[t] = v;
   }
 }
 
+// wave-uniform broadcast of lane `src`'s value (src is a compile-time constant after unrolling)
+__device__ __forceinline__ double bcast(double v, int src) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+  return __hiloint2double(hi, lo);
+}
+
 // ------------------------------------------------------------------------------------------------
-// ldl_diag: unblocked LDL^T of the NB x NB diagonal block in LDS + inverse of its unit-lower factor
+// ldl_panel: one single-wavefront workgroup per 64 rows below the diagonal block.  Every
+// workgroup first factors the NB x NB diagonal block redundantly *in registers* (lane j owns the
+// full symmetric column j; pivots and multipliers travel by v_readlane, no LDS, no barriers), then
+// each lane forward-substitutes its own row:  w L11^T = a  ->  W21 = L21 D11, L21 = W21 D11^-1.
+// Workgroup 0 also stores L11 and D11.  (The diagonal block is fully symmetric-valid: build_A
+// fills both triangles and ldl_trail updates whole tiles.)
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_ldl_diag(double *__restrict__ A, int nA, int c0, double *__restrict__ dvec,
-                                                  double *__restrict__ Minv) {
-  __shared__ double S[NB][NB + 1];
-  __shared__ double Mi[NB][NB + 1];
-  __shared__ double lcol[NB];
-  const int tid = threadIdx.x;
-  for (int t = tid; t < NB * NB; t += 256) {
-    const int c = t / NB, r = t - c * NB;
-    S[r][c] = (r >= c) ? A[(size_t)(c0 + c) * nA + c0 + r] : 0.0;
-  }
-  __syncthreads();
+__global__ __launch_bounds__(64) void k_ldl_panel(double *__restrict__ A, int nA, int c0,
+                                                  double *__restrict__ dvec, double *__restrict__ Wp) {
+  __shared__ double Lt[NB * NB];      // L11[j][k] at k*NB + j (j > k): column k contiguous
+  const int ldA = nA + NB, nR = nA + NB;          // rows nA..nA+NB-1: right-hand side tile
+  const int lane = threadIdx.x;
+  const int r = c0 + NB + blockIdx.x * 64 + lane;
+  const bool has_row = r < nR;
+  const int rr = has_row ? r : nR - 1;
+  // this lane's row of A21 (issued first so the loads fly under the factorization)
+  double a[NB];
+#pragma unroll
+  for (int k = 0; k < NB; k++) a[k] = A[(size_t)(c0 + k) * ldA + rr];
+
+  double c[NB];
+  const int jc = lane < NB ? lane : 0;          // lanes 48..63 shadow column 0 and never contribute
+  const double *colp = A + (size_t)(c0 + jc) * ldA + c0;
+#pragma unroll
+  for (int i = 0; i < NB; i++) c[i] = colp[i];
+
+#pragma unroll
   for (int k = 0; k < NB; k++) {
-    const double d = S[k][k];
-    const double inv = (fabs(d) > DBL_MIN) ? 1.0 / d : 0.0;
-    if (tid > k && tid < NB) lcol[tid] = S[tid][k] * inv;
-    __syncthreads();
-    // trailing update of the lower triangle: S[i][j] -= l_i * a_jk  (k < j <= i)
-    const int m = NB - 1 - k;
-    for (int t = tid; t < m * m; t += 256) {
-      const int ii = t / m, jj = t - ii * m;
-      if (jj <= ii) {
-        const int i = k + 1 + ii, j = k + 1 + jj;
-        S[i][j] -= lcol[i] * S[j][k];
-      }
+    const double dk = bcast(c[k], k);
+    const double inv = (fabs(dk) > DBL_MIN) ? 1.0 / dk : 0.0;
+    const double f = (lane > k && lane < NB) ? c[k] * inv : 0.0;     // l_jk for the columns still active
+#pragma unroll
+    for (int i = k + 1; i < NB; i++) {
+      const double aik = bcast(c[i], k);                             // a_ik (column k is final up to scale)
+      c[i] = __builtin_fma(-aik, f, c[i]);
     }
-    __syncthreads();
-    if (tid > k && tid < NB) S[tid][k] = lcol[tid];
-    // (next iteration reads S[k+1][k+1] and column k+1 only; column k is final -> no hazard
-    //  with the write above because the sync at the top of the next update phase orders it)
+    __builtin_amdgcn_sched_barrier(0);     // keep hipcc from hoisting hundreds of readlanes
+  }
+  // lane j: c[j] = d_j, c[i>j] = l_ij d_j
+  double dj = 1.0;
+#pragma unroll
+  for (int i = 0; i < NB; i++) dj = (i == lane) ? c[i] : dj;
+  const double invd = (fabs(dj) > DBL_MIN) ? 1.0 / dj : 0.0;
+  if (lane < NB) {
+#pragma unroll
+    for (int i = 1; i < NB; i++) Lt[lane * NB + i] = c[i] * invd;    // rows i <= lane are never read
+  }
+  if (blockIdx.x == 0 && lane < NB) {
+    dvec[c0 + lane] = dj;
+    double *colw = A + (size_t)(c0 + lane) * ldA + c0;
+#pragma unroll
+    for (int i = 1; i < NB; i++)
+      if (i > lane) colw[i] = c[i] * invd;
   }
   __syncthreads();
-  // M = L11^-1 (unit lower), column j by lane j
-  if (tid < NB) {
-    const int j = tid;
-    for (int r = 0; r < NB; r++) Mi[r][j] = (r == j) ? 1.0 : 0.0;
-    for (int r = j + 1; r < NB; r++) {
-      double s = 0.0;
-      for (int k = j; k < r; k++) s += S[r][k] * Mi[k][j];
-      Mi[r][j] = -s;
-    }
-    dvec[c0 + j] = S[j][j];
+  // forward substitution along the row (right-looking): a_j -= a_k L11[j][k]; L11[j][k] is a
+  // wave-uniform LDS broadcast.  hipcc would otherwise hoist ALL 1128 LDS reads above the loop and
+  // spill them; the opaque zero tied to an already-final pivot bounds the read lookahead to 2 steps.
+#pragma unroll
+  for (int k = 0; k < NB - 1; k++) {
+    int z = 0;
+    asm volatile("" : "+v"(z) : "v"(a[k > 1 ? k - 2 : 0]));
+    const double *Lk = Lt + k * NB + z;
+#pragma unroll
+    for (int j = k + 1; j < NB; j++) a[j] = __builtin_fma(-a[k], Lk[j], a[j]);
   }
-  __syncthreads();
-  double *Mo = Minv + (size_t)(c0 / NB) * NB * NB;
-  for (int t = tid; t < NB * NB; t += 256) {
-    const int c = t / NB, r = t - c * NB;
-    if (r > c) A[(size_t)(c0 + c) * nA + c0 + r] = S[r][c];
-    Mo[r * NB + c] = Mi[r][c];     // row-major M
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
-// ldl_panel: W21 = A21 M^T (= L21 D11), L21 = W21 D11^-1 for 64 rows per workgroup
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_ldl_panel(double *__restrict__ A, int nA, int c0,
-                                                   const double *__restrict__ dvec, const double *__restrict__ Minv,
-                                                   double *__restrict__ Wp) {
-  __shared__ double Ab[64][NB + 1];
-  __shared__ double M[NB][NB + 1];
-  __shared__ double dinv[NB];
-  const int tid = threadIdx.x;
-  const int r0 = c0 + NB + blockIdx.x * 64;
-  const double *Mo = Minv + (size_t)(c0 / NB) * NB * NB;
-  for (int t = tid; t < NB * NB; t += 256) M[t / NB][t % NB] = Mo[t];
-  if (tid < NB) {
-    const double d = dvec[c0 + tid];
-    dinv[tid] = (fabs(d) > DBL_MIN) ? 1.0 / d : 0.0;
-  }
-  for (int t = tid; t < 64 * NB; t += 256) {
-    const int k = t / 64, r = t - k * 64;
-    Ab[r][k] = (r0 + r < nA) ? A[(size_t)(c0 + k) * nA + r0 + r] : 0.0;
-  }
-  __syncthreads();
-  const int r = tid & 63, jg = tid >> 6;
-  if (r0 + r < nA) {
-    for (int j = jg; j < NB; j += 4) {
-      double s = 0.0;
-      for (int k = 0; k <= j; k++) s += Ab[r][k] * M[j][k];
-      Wp[(size_t)j * nA + r0 + r] = s;
-      A[(size_t)(c0 + j) * nA + r0 + r] = s * dinv[j];
+#pragma unroll
+  for (int j = 0; j < NB; j++) {
+    const double dd = bcast(invd, j);       // every lane still active: readlane needs lane j live
+    if (has_row) {
+      Wp[(size_t)j * ldA + r] = a[j];
+      A[(size_t)(c0 + j) * ldA + r] = a[j] * dd;
     }
   }
 }
 
 // ------------------------------------------------------------------------------------------------
-// ldl_trail: A22 -= W21 L21^T on the lower triangle, 48x48 tile per wavefront, f64 MFMA.
-//   D[m][nn] = sum_k L21[j0+m][k] * W21[i0+nn][k]  -> element (i0+nn, j0+m), stored column-major so
-//   the 16 lanes of a row group touch 128 contiguous bytes.
+// ldl_trail: A22 -= W21 L21^T on the lower triangle; one wavefront per 48 (rows i) x 16 (cols j)
+// tile, f64 MFMA, every operand prefetched before the first MFMA (the kernel is latency-bound).
+//   D[m][nn] = sum_k L21[j0+m][k] * W21[i0+nn][k]  -> element (i0+nn, j0+m); lanes of a row group
+//   touch 128 contiguous bytes of a column.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_ldl_trail(double *__restrict__ A, int nA, int c0,
-                                                   const double *__restrict__ Wp, int mt, int ntile) {
+                                                   const double *__restrict__ Wp, int mt) {
+  const int ldA = nA + NB;
   const int lane = threadIdx.x & 63;
-  const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (t >= ntile) return;
-  // t -> (ti >= tj) in the lower triangle of an mt x mt tile grid
-  int ti = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
-  while ((ti + 1) * (ti + 2) / 2 <= t) ti++;
-  while (ti * (ti + 1) / 2 > t) ti--;
-  const int tj = t - ti * (ti + 1) / 2;
+  const int ti = blockIdx.y;                                  // 48-row tile; ti == mt: right-hand side tile
+  const int tj = blockIdx.x * 4 + (threadIdx.x >> 6);         // 16-col tile
+  if (ti < mt ? (tj > 3 * ti + 2) : (tj >= 3 * mt)) return;
   const int base = c0 + NB;
-  const int i0 = base + ti * NB, j0 = base + tj * NB;
-  d4 acc[3][3];
-#pragma unroll
-  for (int a = 0; a < 3; a++)
-#pragma unroll
-    for (int b = 0; b < 3; b++) acc[a][b] = (d4){0.0, 0.0, 0.0, 0.0};
-  const double *pl = A + (size_t)(c0 + (lane >> 4)) * nA + j0 + (lane & 15);    // L21 rows j
-  const double *pw = Wp + (size_t)(lane >> 4) * nA + i0 + (lane & 15);          // W21 rows i
+  const int i0 = base + ti * NB, j0 = base + tj * 16;
+  const double *pl = A + (size_t)(c0 + (lane >> 4)) * ldA + j0 + (lane & 15);    // L21 rows j
+  const double *pw = Wp + (size_t)(lane >> 4) * ldA + i0 + (lane & 15);          // W21 rows i
+  double a[NB / 4], b[NB / 4][3];
 #pragma unroll
   for (int ks = 0; ks < NB / 4; ks++) {
-    double a[3], b[3];
+    a[ks] = pl[(size_t)ks * 4 * ldA];
 #pragma unroll
-    for (int q = 0; q < 3; q++) {
-      a[q] = pl[(size_t)ks * 4 * nA + 16 * q];
-      b[q] = pw[(size_t)ks * 4 * nA + 16 * q];
-    }
-#pragma unroll
-    for (int x = 0; x < 3; x++)
-#pragma unroll
-      for (int y = 0; y < 3; y++) acc[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[x], b[y], acc[x][y], 0, 0, 0);
+    for (int q = 0; q < 3; q++) b[ks][q] = pw[(size_t)ks * 4 * ldA + 16 * q];
   }
+  // the tile itself (read-modify-write), also in flight before the MFMAs
+  double old[3][4];
 #pragma unroll
-  for (int x = 0; x < 3; x++)
+  for (int y = 0; y < 3; y++)
 #pragma unroll
-    for (int y = 0; y < 3; y++)
+    for (int e = 0; e < 4; e++)
+      old[y][e] = A[(size_t)(j0 + (lane >> 4) + 4 * e) * ldA + i0 + 16 * y + (lane & 15)];
+  d4 acc[3];
 #pragma unroll
-      for (int e = 0; e < 4; e++) {
-        const int j = j0 + 16 * x + (lane >> 4) + 4 * e;
-        const int i = i0 + 16 * y + (lane & 15);
-        A[(size_t)j * nA + i] -= acc[x][y][e];
-      }
+  for (int y = 0; y < 3; y++) acc[y] = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int ks = 0; ks < NB / 4; ks++)
+#pragma unroll
+    for (int y = 0; y < 3; y++) acc[y] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks], b[ks][y], acc[y], 0, 0, 0);
+#pragma unroll
+  for (int y = 0; y < 3; y++)
+#pragma unroll
+    for (int e = 0; e < 4; e++)
+      A[(size_t)(j0 + (lane >> 4) + 4 * e) * ldA + i0 + 16 * y + (lane & 15)] = old[y][e] - acc[y][e];
 }
 
 // ------------------------------------------------------------------------------------------------
-// triangular solves + un-permute + q1, one workgroup
+// backward solve  L^T x = z  (z = row nA of the factored storage) + un-permute + q1; one workgroup
+// of 8 waves.  Left-looking over panels of NB columns, descending:
+//   t_k = sum_{r below} L[r][c0+k] x[r]   six columns per wave, lanes stride the rows (every load is
+//                                        512 contiguous bytes of a column), shuffle reduction;
+//   wave 0 then solves the NB x NB unit-triangular block by v_readlane substitution (lane = column).
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_ldl_solve(const double *__restrict__ A, int nA, int n,
-                                                    const double *__restrict__ dvec,
-                                                    const double *__restrict__ Minv, const int *__restrict__ perm,
-                                                    const double *__restrict__ H, const double *__restrict__ g,
-                                                    double u, double *__restrict__ dx, double *__restrict__ scal) {
+constexpr int TPB = 512;
+static_assert(NB == 6 * (TPB / 64), "six panel columns per wave");
+
+__global__ __launch_bounds__(TPB) void k_ldl_backsolve(const double *__restrict__ A, int nA, int n,
+                                                       const int *__restrict__ perm, const double *__restrict__ H,
+                                                       const double *__restrict__ g, double u,
+                                                       double *__restrict__ dx, double *__restrict__ scal) {
   extern __shared__ __attribute__((aligned(16))) double sh[];
-  double *y = sh;            // [nA]
-  double *tb = sh + nA;      // [NB]
-  double *red = tb + NB;     // [1024]
+  double *y = sh;            // [nA]  z on entry, x on exit
+  double *t = sh + nA;       // [NB]
+  double *red = t + NB;      // [TPB]
+  const int ldA = nA + NB;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int P = nA / NB;
-  for (int r = tid; r < nA; r += 1024) {
-    const int p = perm[r];
-    y[r] = p < n ? -g[p] : 0.0;
-  }
+  for (int r = tid; r < nA; r += TPB) y[r] = A[(size_t)r * ldA + nA];
   __syncthreads();
-  // forward: L y' = y
-  for (int p = 0; p < P; p++) {
-    const int c0 = p * NB;
-    const double *M = Minv + (size_t)p * NB * NB;
-    if (tid < NB) {
-      double s = 0.0;
-      for (int k = 0; k <= tid; k++) s += M[tid * NB + k] * y[c0 + k];
-      tb[tid] = s;
-    }
-    __syncthreads();
-    if (tid < NB) y[c0 + tid] = tb[tid];
-    for (int r = c0 + NB + tid; r < nA; r += 1024) {
-      double s = 0.0;
-#pragma unroll 8
-      for (int k = 0; k < NB; k++) s += A[(size_t)(c0 + k) * nA + r] * tb[k];
-      y[r] -= s;
-    }
-    __syncthreads();
-  }
-  // D^+   (Eigen LDLT::_solve_impl: zero where |d| <= min())
-  for (int r = tid; r < nA; r += 1024) {
-    const double d = dvec[r];
-    y[r] = (fabs(d) > DBL_MIN) ? y[r] / d : 0.0;
-  }
-  __syncthreads();
-  // backward: L^T x = z
   for (int p = P - 1; p >= 0; p--) {
     const int c0 = p * NB;
-    const double *M = Minv + (size_t)p * NB * NB;
-    for (int k = wv; k < NB; k += 16) {
-      double s = 0.0;
-      const double *col = A + (size_t)(c0 + k) * nA;
-      for (int r = c0 + NB + lane; r < nA; r += 64) s += col[r] * y[r];
+    // wave 0: column `lane` of the diagonal block, rows below its diagonal (in flight under the dots)
+    double Lb[NB];
+    if (wv == 0) {
+      const double *col = A + (size_t)(c0 + (lane < NB ? lane : 0)) * ldA + c0;
 #pragma unroll
-      for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
-      if (lane == 0) tb[k] = y[c0 + k] - s;
+      for (int k = 0; k < NB; k++) Lb[k] = col[k];
+    }
+    double acc[6];
+#pragma unroll
+    for (int q = 0; q < 6; q++) acc[q] = 0.0;
+    const double *cb = A + (size_t)(c0 + 6 * wv) * ldA;
+#pragma unroll 4
+    for (int r = c0 + NB + lane; r < nA; r += 64) {
+      const double xr = y[r];
+#pragma unroll
+      for (int q = 0; q < 6; q++) acc[q] = __builtin_fma(cb[(size_t)q * ldA + r], xr, acc[q]);
+    }
+#pragma unroll
+    for (int q = 0; q < 6; q++) {
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) acc[q] += __shfl_xor(acc[q], off, 64);
+    }
+    if (lane == 0) {
+#pragma unroll
+      for (int q = 0; q < 6; q++) t[6 * wv + q] = acc[q];
     }
     __syncthreads();
-    if (tid < NB) {
-      double s = 0.0;
-      for (int k = tid; k < NB; k++) s += M[k * NB + tid] * tb[k];
-      y[c0 + tid] = s;
+    if (wv == 0) {
+      double v = lane < NB ? y[c0 + lane] - t[lane] : 0.0;
+#pragma unroll
+      for (int k = NB - 1; k >= 1; k--) {
+        const double xk = bcast(v, k);
+        if (lane < k) v = __builtin_fma(-Lb[k], xk, v);
+      }
+      if (lane < NB) y[c0 + lane] = v;
     }
     __syncthreads();
   }
   // un-permute, q1 = 0.5 dx.(u D dx - g)    (bavoxel.hpp:1127)
   double q = 0.0;
-  for (int r = tid; r < nA; r += 1024) {
+  for (int r = tid; r < nA; r += TPB) {
     const int p = perm[r];
     if (p < n) {
       const double x = y[r];
@@ -268,7 +280,7 @@ __global__ __launch_bounds__(1024) void k_ldl_solve(const double *__restrict__ A
   }
   red[tid] = q;
   __syncthreads();
-  for (int s = 512; s > 0; s >>= 1) {
+  for (int s = TPB / 2; s > 0; s >>= 1) {
     if (tid < s) red[tid] += red[tid + s];
     __syncthreads();
   }
@@ -279,28 +291,28 @@ void launch_solve(balm_ctx *c, double u, bool new_hessian) {
   hipStream_t s = c->stream;
   const int n = c->n, nA = c->nA;
   if (new_hessian)
-    hipLaunchKernelGGL(k_rank_diag, dim3(1), dim3(1024), (size_t)nA * sizeof(double), s, c->d_H, n, nA, c->d_perm);
+    hipLaunchKernelGGL(k_rank_diag, dim3((nA + 63) / 64), dim3(256), (size_t)nA * sizeof(double) + 256 * sizeof(int),
+                       s, c->d_H, n, nA, c->d_perm);
   {
-    long total = (long)nA * nA;
+    long total = (long)(nA + NB) * nA;
     int grid = (int)((total + 255) / 256);
     if (grid > 4096) grid = 4096;
-    hipLaunchKernelGGL(k_build_A, dim3(grid), dim3(256), 0, s, c->d_H, n, nA, c->d_perm, u, c->d_A);
+    hipLaunchKernelGGL(k_build_A, dim3(grid), dim3(256), 0, s, c->d_H, c->d_g, n, nA, c->d_perm, u, c->d_A);
   }
   const int P = nA / NB;
   for (int p = 0; p < P; p++) {
     const int c0 = p * NB;
-    hipLaunchKernelGGL(k_ldl_diag, dim3(1), dim3(256), 0, s, c->d_A, nA, c0, c->d_dvec, c->d_Minv);
-    const int m = nA - c0 - NB;
+    const int m = nA - c0 - NB;                 // square part still to factor
+    const int rows = m + NB;                    // + right-hand side tile
+    hipLaunchKernelGGL(k_ldl_panel, dim3((rows + 63) / 64), dim3(64), 0, s, c->d_A, nA, c0, c->d_dvec, c->d_Wp);
     if (m > 0) {
-      hipLaunchKernelGGL(k_ldl_panel, dim3((m + 63) / 64), dim3(256), 0, s, c->d_A, nA, c0, c->d_dvec, c->d_Minv,
-                         c->d_Wp);
-      const int mt = m / NB, ntile = mt * (mt + 1) / 2;
-      hipLaunchKernelGGL(k_ldl_trail, dim3((ntile + 3) / 4), dim3(256), 0, s, c->d_A, nA, c0, c->d_Wp, mt, ntile);
+      const int mt = m / NB;
+      hipLaunchKernelGGL(k_ldl_trail, dim3((3 * mt + 3) / 4, mt + 1), dim3(256), 0, s, c->d_A, nA, c0, c->d_Wp, mt);
     }
   }
-  size_t lds = (size_t)(nA + NB + 1024) * sizeof(double);
-  hipLaunchKernelGGL(k_ldl_solve, dim3(1), dim3(1024), lds, s, c->d_A, nA, n, c->d_dvec, c->d_Minv, c->d_perm,
-                     c->d_H, c->d_g, u, c->d_dx, c->d_scal);
+  size_t lds = (size_t)(nA + NB + TPB) * sizeof(double);
+  hipLaunchKernelGGL(k_ldl_backsolve, dim3(1), dim3(TPB), lds, s, c->d_A, nA, n, c->d_perm, c->d_H, c->d_g, u, c->d_dx,
+                     c->d_scal);
 }
 
 // ------------------------------------------------------------------------------------------------
