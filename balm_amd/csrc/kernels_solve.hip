@@ -332,8 +332,9 @@ __device__ __forceinline__ void exp_so3(const double w[3], double E[3][3]) {
     for (int r = 0; r < 3; r++)
 #pragma unroll
       for (int c = 0; c < 3; c++) {
-        const double kk = K[r][0] * K[0][c] + K[r][1] * K[1][c] + K[r][2] * K[2][c];
-        E[r][c] += s * K[r][c] + c1 * kk;
+        // evaluation order of the reference's `I33 + sin*K + (1-cos)*K*K`: ((1-cos)*K)*K
+        const double kk = (c1 * K[r][0]) * K[0][c] + (c1 * K[r][1]) * K[1][c] + (c1 * K[r][2]) * K[2][c];
+        E[r][c] = (E[r][c] + s * K[r][c]) + kk;
       }
   }
 }

@@ -34,9 +34,9 @@ M3 rodrigues(const V3 &w) {
   M3 o = ident();
   for (int r = 0; r < 3; r++)
     for (int c = 0; c < 3; c++) {
-      double kk = 0;
-      for (int k = 0; k < 3; k++) kk += K[r][k] * K[k][c];
-      o.m[r][c] += s * K[r][c] + c1 * kk;
+      double kk = 0;   // ((1-cos)*K)*K, the reference's evaluation order
+      for (int k = 0; k < 3; k++) kk += (c1 * K[r][k]) * K[k][c];
+      o.m[r][c] = (o.m[r][c] + s * K[r][c]) + kk;
     }
   return o;
 }

@@ -42,7 +42,21 @@ def cpu_baseline(sc, ctx, target_seconds=18.0, threads=4):
     H, g, _ = ctx.evaluate(0, sc.poses_init)
     ts = orc.time_solve(H, g, 0.1)
     t_iter = (te + tr) * (F / fs) + ts
+    extra = {}
+    try:    # the reference's own source (oracle/_ref: bavoxel.hpp against the stand-in Eigen), same sample
+        from oracle import ref
+        if ref.available():
+            fr = max(64, fs // 8)
+            re_, rr_ = ref.time_sample(sc.clusters, sc.coeffs, sc.poses_init, fr)
+            rs_ = ref.time_solve(H, g, 0.1)
+            extra["reference_source_iter_per_s"] = 1.0 / ((re_ + rr_) * (F / fr) + rs_)
+            extra["reference_source_note"] = ("BALM2::divide_thread_left + evaluate_only_residual of the reference's "
+                                              "bavoxel.hpp compiled against oracle/compat (stand-in Eigen, slower than "
+                                              "real Eigen), first %d features, 4 threads" % fr)
+    except Exception as e:
+        extra["reference_source_error"] = repr(e)
     return {
+        **extra,
         "value": 1.0 / t_iter, "unit": "iter/s", "cores": threads, "kind": "port",
         "sample": "oracle left_evaluate_acc2 + evaluate_only_residual on the first %d of %d features "
                   "(W=%d), scaled by F/F_sample, + one full %dx%d LDLT solve; %d std::threads as "

@@ -107,9 +107,9 @@ inline M3 hat(const V3 &v) {
 inline M3 Exp(const V3 &w) {
   double n = norm3(w);
   if (n >= 1e-11) {
-    M3 K = hat(scl(w, 1.0 / n));
-    M3 KK = mul(K, K);
-    return add(add(eye3(), scl(K, std::sin(n))), scl(KK, 1.0 - std::cos(n)));
+    M3 K = hat(vec3(w.a[0] / n, w.a[1] / n, w.a[2] / n));     // `ang / ang_norm`: a division
+    // evaluation order of `I33 + sin*K + (1-cos)*K*K`: ((1-cos)*K)*K
+    return add(add(eye3(), scl(K, std::sin(n))), mul(scl(K, 1.0 - std::cos(n)), K));
   }
   return eye3();
 }

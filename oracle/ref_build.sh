@@ -1,0 +1,18 @@
+#!/bin/bash
+# Builds oracle/_ref/libbalm_ref.so from the reference's own sources where they lie under
+# /root/reference (read-only; nothing is copied), against the stand-in headers in oracle/compat/.
+# Flags follow the reference's CMakeLists.txt:8-9 (-std=c++14 -O3).  No-op when /root/reference is
+# absent (the GPU box uses the prebuilt .so that travels with the repo snapshot).
+set -e
+HERE="$(cd "$(dirname "$0")" && pwd)"
+REF=${BALM_REFERENCE_ROOT:-/root/reference}
+if [ ! -f "$REF/src/benchmark/bavoxel.hpp" ]; then
+  echo "ref_build: $REF not present; keeping any prebuilt oracle/_ref"; exit 0
+fi
+mkdir -p "$HERE/_ref"
+OUT="$HERE/_ref/libbalm_ref.so"
+if [ "$OUT" -nt "$HERE/ref_driver.cpp" ] && [ "$OUT" -nt "$HERE/compat/Eigen/Core" ] && [ -z "$BALM_FORCE_BUILD" ]; then exit 0; fi
+g++ -std=c++14 -O3 -fPIC -pthread -shared -w \
+    -I"$HERE/compat" -I"$REF/include" -I"$REF/src/benchmark" \
+    -o "$OUT" "$HERE/ref_driver.cpp"
+echo "ref_build: built $OUT"

@@ -224,3 +224,36 @@ def test_full_width_window_properties(W, F):
     gt = g.reshape(W, 6)[:, 3:].sum(0)
     assert np.abs(gt).max() < 1e-9 * np.abs(g).max()
     c.close()
+
+
+# ---- golden fixtures: outputs of the reference's own source (tests/golden/make_golden.py) ------------
+import glob as _glob
+import os as _os
+
+_GOLD = sorted(_glob.glob(_os.path.join(_os.path.dirname(__file__), "golden", "*.npz")))
+
+
+@pytest.mark.parametrize("path", _GOLD, ids=[_os.path.basename(p)[:-4] for p in _GOLD])
+def test_hip_matches_reference_fixtures(path):
+    g = dict(np.load(path))
+    cl, co, P = g["clusters"], g["coeffs"], g["poses"]
+    c = capi.Context(cl.shape[1])
+    c.set_features(cl, None, co)
+    for form in (0, 1):
+        H, J, r = c.evaluate(form, P)
+        assert abs(r - g["r%d" % form]) / g["r%d" % form] < 1e-12
+        assert rel_err(J, g["g%d" % form]) < HTOL
+        if "H%d" % form in g:
+            assert rel_err(H, g["H%d" % form]) < HTOL
+    assert abs(c.only_residual(P) - g["r_only"]) / g["r_only"] < 1e-12
+    for u in (0.01, 0.1):
+        dx, q1 = c.solve_damped(g["H0"], g["g0"], u)
+        assert rel_err(dx, g["dx_u%g" % u]) < 1e-7
+        assert abs(q1 - g["q1_u%g" % u]) / abs(g["q1_u%g" % u]) < 1e-8
+    if "lm_poses" in g:      # BALM2::damping_iter of the reference: left form, u0 = 0.01, <= 10 iterations
+        out, lg = c.damping_iter(P, form=0, u0=0.01, max_iter=10, min_planes=20)
+        assert len(lg) == len(g["lm_log"])
+        assert np.allclose(lg[:, :2], g["lm_log"][:, :2], atol=2e-6)      # the reference prints 6 decimals
+        rot, tr = pose_errors(out, g["lm_poses"])
+        assert rot.max() <= ROT_TOL_RAD and tr.max() <= TRANS_TOL_M
+    c.close()
