@@ -1,0 +1,12 @@
+#!/bin/bash
+# Builds tests/cpp/shim_driver.cpp against the reference's own headers (where they lie) + the stand-in
+# Eigen/PCL/ROS headers, linking libbalm_hip.so.  Output: oracle/_ref/shim_driver (git-ignored; travels).
+set -e
+ROOT="$(cd "$(dirname "$0")/../.." && pwd)"
+REF=${BALM_REFERENCE_ROOT:-/root/reference}
+[ -f "$REF/src/benchmark/bavoxel.hpp" ] || { echo "build_shim_driver: $REF not present"; exit 0; }
+mkdir -p "$ROOT/oracle/_ref"
+g++ -std=c++14 -O2 -w -pthread -I"$ROOT/oracle/compat" -I"$REF/include" -I"$REF/src/benchmark" -I"$ROOT/include" \
+    -o "$ROOT/oracle/_ref/shim_driver" "$ROOT/tests/cpp/shim_driver.cpp" \
+    -L"$ROOT/balm_amd/lib" -lbalm_hip -ldl -Wl,-rpath,'$ORIGIN/../../balm_amd/lib'
+echo "built $ROOT/oracle/_ref/shim_driver"

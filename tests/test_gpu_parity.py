@@ -257,3 +257,20 @@ def test_hip_matches_reference_fixtures(path):
         rot, tr = pose_errors(out, g["lm_poses"])
         assert rot.max() <= ROT_TOL_RAD and tr.max() <= TRANS_TOL_M
     c.close()
+
+
+def test_cpp_shim_dropin_with_reference_association():
+    """include/balm_shim.hpp end to end: the reference's own cut_voxel/recut/tras_opt (compiled from
+    /root/reference) fill VOX_HESS; the same container then runs through the reference BALM2 (CPU)
+    and BALM2_HIP (GPU) -- tests/cpp/shim_driver.cpp.  Needs the binary built in the build container."""
+    import subprocess
+    from conftest import ROOT
+    exe = _os.path.join(ROOT, "oracle", "_ref", "shim_driver")
+    if not _os.path.exists(exe):
+        pytest.skip("oracle/_ref/shim_driver not built (needs /root/reference at build time)")
+    scene_so = _os.path.join(ROOT, "balm_amd", "lib", "libbalm_scene.so")
+    p = subprocess.run([exe, "1", "20", "150", "40", scene_so], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    line = [l for l in p.stdout.splitlines() if l.startswith("SHIM_DRIVER")]
+    assert line, p.stdout[-2000:] + p.stderr[-2000:]
+    print(line[-1])
+    assert p.returncode == 0, line[-1]
