@@ -274,3 +274,30 @@ def test_cpp_shim_dropin_with_reference_association():
     assert line, p.stdout[-2000:] + p.stderr[-2000:]
     print(line[-1])
     assert p.returncode == 0, line[-1]
+
+
+def test_allreduce_hook_over_rccl_single_rank():
+    """the multi-GPU plumbing with world_size 1: torch.distributed 'nccl' (= RCCL) all-reduce of the
+    library's device payload through balm_set_allreduce must leave every result unchanged."""
+    import socket
+    import torch.distributed as dist
+    from balm_amd import dist as bdist
+    sc, _ = make_scene(80, 24, 90, 6, drop=0.2)
+    c = ctx_for(sc)
+    H0, g0, r0 = c.evaluate(0, sc.poses_init)
+    out0, lg0 = c.damping_iter(sc.poses_init, u0=0.01, max_iter=10)
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    _os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    bdist.init_process_group("nccl")
+    try:
+        hook = bdist.install_allreduce(c)
+        H1, g1, r1 = c.evaluate(0, sc.poses_init)
+        assert np.array_equal(H0, H1) and np.array_equal(g0, g1) and r0 == r1
+        assert abs(c.only_residual(sc.poses_init) - r0) / r0 < 1e-14
+        out1, lg1 = c.damping_iter(sc.poses_init, u0=0.01, max_iter=10)
+        assert np.array_equal(out0, out1) and np.array_equal(lg0, lg1)
+        print("zero-copy device view:", hook.zero_copy)
+    finally:
+        c.set_allreduce(None)
+        dist.destroy_process_group()
+    c.close()
