@@ -87,13 +87,17 @@ int hook_allreduce(balm_ctx *ctx, double *buf, long n) {
   return BALM_OK;
 }
 
-// residual-only evaluation of features [f0,f1) at device poses -> d_scal[slot] (summed over ranks)
+// residual-only evaluation of features [f0,f1) at the TRIAL poses -> d_scal[slot] (summed over
+// ranks).  The per-feature eigen records it produces are kept (d_feat_tmp): if the step is accepted
+// they are exactly what the next Hessian evaluation needs at the same poses (the reference recomputes
+// them, bavoxel.hpp:331-351 after :443-457).
 int residual_device(balm_ctx *ctx, const double *d_poses, int f0, int f1, int slot) {
   {
     Span sp(ctx, BALM_T_MOMENTS);
     launch_world_moments(ctx->stream, ctx->d_cl, d_poses, ctx->W, f0, f1, ctx->d_C);
-    int nr = launch_feature_eigen(ctx->stream, ctx->d_C, ctx->d_fix, ctx->d_coe, f0, f1, ctx->d_feat, ctx->d_rpart);
-    launch_sum_scalar(ctx->stream, ctx->d_rpart, nr, ctx->d_scal + slot);
+    ctx->nr_tmp = launch_feature_eigen(ctx->stream, ctx->d_C, ctx->d_fix, ctx->d_coe, f0, f1, ctx->d_feat_tmp,
+                                       ctx->d_rpart_tmp);
+    launch_sum_scalar(ctx->stream, ctx->d_rpart_tmp, ctx->nr_tmp, ctx->d_scal + slot);
   }
   return hook_allreduce(ctx, ctx->d_scal + slot, 1);
 }
@@ -104,21 +108,22 @@ int evaluate_device(balm_ctx *ctx, int form, const double *d_poses, int f0, int 
   const int dacc = form == 0 ? DACC_LEFT : DACC_RIGHT;
   SyrkPlan plan = plan_syrk(ctx->ntiles, 3L * nf);
   int rc;
-  if ((rc = ensure(ctx, &ctx->d_Gt, &ctx->cap_Gt, (size_t)(plan.Kpad + 8) * ctx->npad))) return rc;
+  if ((rc = ensure(ctx, &ctx->d_Gt, &ctx->cap_Gt, (size_t)(plan.Kpad + 64) * ctx->npad))) return rc;
   if ((rc = ensure(ctx, &ctx->d_part, &ctx->cap_part, (size_t)plan.SG * ctx->ntiles * TILE_ELEMS))) return rc;
   const int nblk = factors_grid(W, nf, form);
   if ((rc = ensure(ctx, &ctx->d_dpart, &ctx->cap_dpart, (size_t)nblk * DACC_MAX * W))) return rc;
   hipStream_t s = ctx->stream;
-  int nr;
-  {
+  if (!(ctx->feat_cur_valid && f0 == 0 && f1 == ctx->F)) {
     Span sp(ctx, BALM_T_MOMENTS);
     launch_world_moments(s, ctx->d_cl, d_poses, W, f0, f1, ctx->d_C);
-    nr = launch_feature_eigen(s, ctx->d_C, ctx->d_fix, ctx->d_coe, f0, f1, ctx->d_feat, ctx->d_rpart);
+    ctx->nr_cur = launch_feature_eigen(s, ctx->d_C, ctx->d_fix, ctx->d_coe, f0, f1, ctx->d_feat, ctx->d_rpart);
+    ctx->feat_cur_valid = (f0 == 0 && f1 == ctx->F);
   }
+  const int nr = ctx->nr_cur;
   {
     Span sp(ctx, BALM_T_FACTORS);
     // zero the Gt columns the factor kernel does not write: [3 nf, Kpad + 8) and the row padding
-    const size_t k0 = (size_t)3 * nf, k1 = (size_t)plan.Kpad + 8;
+    const size_t k0 = (size_t)3 * nf, k1 = (size_t)plan.Kpad + 64;   // + prefetch overrun of the k-ring
     HIP_TRY(hipMemsetAsync(ctx->d_Gt + k0 * ctx->npad, 0, (k1 - k0) * ctx->npad * sizeof(double), s));
     if (ctx->npad > ctx->n)
       HIP_TRY(hipMemset2DAsync(ctx->d_Gt + ctx->n, (size_t)ctx->npad * sizeof(double), 0,
@@ -201,7 +206,7 @@ void balm_destroy(balm_ctx *ctx) {
   hipSetDevice(ctx->device);
   if (ctx->stream) hipStreamSynchronize(ctx->stream);
   void *ptrs[] = {ctx->d_cl, ctx->d_fix, ctx->d_coe, ctx->d_poses, ctx->d_poses_tmp, ctx->d_C, ctx->d_feat,
-                  ctx->d_Gt, ctx->d_part, ctx->d_dpart, ctx->d_rpart, ctx->d_red, ctx->d_tileIJ, ctx->d_H,
+                  ctx->d_Gt, ctx->d_part, ctx->d_dpart, ctx->d_rpart, ctx->d_feat_tmp, ctx->d_rpart_tmp, ctx->d_red, ctx->d_tileIJ, ctx->d_H,
                   ctx->d_g, ctx->d_A, ctx->d_Wp, ctx->d_dvec, ctx->d_perm, ctx->d_dx, ctx->d_scal};
   for (void *p : ptrs) if (p) hipFree(p);
   if (ctx->h_scal) hipHostFree(ctx->h_scal);
@@ -223,7 +228,10 @@ static int install_feature_buffers(balm_ctx *ctx, int F, const double *fix, cons
   HIP_TRY(hipMemcpyAsync(ctx->d_coe, coeffs, (size_t)F * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
   if ((rc = dalloc(ctx, &ctx->d_C, (size_t)F * 10))) return rc;
   if ((rc = dalloc(ctx, &ctx->d_feat, (size_t)F * FEAT_STRIDE))) return rc;
-  if ((rc = ensure(ctx, &ctx->d_rpart, &ctx->cap_rpart, (size_t)(F + 255) / 256 + 1))) return rc;
+  if ((rc = dalloc(ctx, &ctx->d_feat_tmp, (size_t)F * FEAT_STRIDE))) return rc;
+  if ((rc = dalloc(ctx, &ctx->d_rpart, (size_t)(F + 255) / 256 + 1))) return rc;
+  if ((rc = dalloc(ctx, &ctx->d_rpart_tmp, (size_t)(F + 255) / 256 + 1))) return rc;
+  ctx->feat_cur_valid = false;
   ctx->F = F;
   return BALM_OK;
 }
@@ -329,7 +337,9 @@ int balm_evaluate(balm_ctx *ctx, int form, const double *poses, int head, int en
   HIP_TRY(hipSetDevice(ctx->device));
   const int n = ctx->n;
   HIP_TRY(hipMemcpyAsync(ctx->d_poses, poses, (size_t)12 * ctx->W * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  ctx->feat_cur_valid = false;
   int rc = evaluate_device(ctx, form, ctx->d_poses, head, end, 0);
+  ctx->feat_cur_valid = false;
   if (rc) return rc;
   if (Hess) HIP_TRY(hipMemcpyAsync(Hess, ctx->d_H, (size_t)n * n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   if (JacT) HIP_TRY(hipMemcpyAsync(JacT, ctx->d_g, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
@@ -391,6 +401,7 @@ int balm_damping_iter(balm_ctx *ctx, const balm_lm_opts *o, double *poses, balm_
   const int W = ctx->W, F = ctx->F;
   hipStream_t s = ctx->stream;
   HIP_TRY(hipMemcpyAsync(ctx->d_poses, poses, (size_t)12 * W * sizeof(double), hipMemcpyHostToDevice, s));
+  ctx->feat_cur_valid = false;
   double u = o->u0, v = 2, r1 = 0, r2 = 0;
   bool calc = true;
   int it = 0, rc;
@@ -420,6 +431,11 @@ int balm_damping_iter(balm_ctx *ctx, const balm_lm_opts *o, double *poses, balm_
       printf("iter%d: (%lf %lf) u: %lf v: %.1lf q: %.3lf %lf %lf\n", it, r1, r2, u, v, q / q1, q1, q);
     if (q > 0) {      // bavoxel.hpp:1134-1143
       double *t = ctx->d_poses; ctx->d_poses = ctx->d_poses_tmp; ctx->d_poses_tmp = t;
+      // the trial poses become current: so do their eigen records and residual partials
+      t = ctx->d_feat; ctx->d_feat = ctx->d_feat_tmp; ctx->d_feat_tmp = t;
+      t = ctx->d_rpart; ctx->d_rpart = ctx->d_rpart_tmp; ctx->d_rpart_tmp = t;
+      ctx->nr_cur = ctx->nr_tmp;
+      ctx->feat_cur_valid = true;
       q = q / q1; v = 2; q = 1 - std::pow(2 * q - 1, 3);
       u *= (q < 1.0 / 3.0 ? 1.0 / 3.0 : q);
       calc = true;
@@ -429,6 +445,7 @@ int balm_damping_iter(balm_ctx *ctx, const balm_lm_opts *o, double *poses, balm_
     it++;
     if (!o->no_stop && std::fabs(r1 - r2) / r1 < o->rel_tol) break;   // :1155
   }
+  ctx->feat_cur_valid = false;
   if (o->reanchor) launch_reanchor(s, W, ctx->d_poses);
   HIP_TRY(hipMemcpyAsync(poses, ctx->d_poses, (size_t)12 * W * sizeof(double), hipMemcpyDeviceToHost, s));
   if ((rc = sync_stream(ctx))) return rc;

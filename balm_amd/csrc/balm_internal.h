@@ -53,7 +53,11 @@ struct balm_ctx {
   double *d_poses_tmp = nullptr;    // [W][12] trial
   // per-evaluation scratch
   double *d_C = nullptr;            // [F][10] world moments
-  double *d_feat = nullptr;         // [F][FEAT_STRIDE]
+  double *d_feat = nullptr;         // [F][FEAT_STRIDE]  per-feature eigen records at the CURRENT poses
+  double *d_feat_tmp = nullptr;     // ... at the TRIAL poses (swapped in when a step is accepted)
+  double *d_rpart_tmp = nullptr;    // residual partials at the trial poses
+  int nr_cur = 0, nr_tmp = 0;       // number of valid residual partials in d_rpart / d_rpart_tmp
+  bool feat_cur_valid = false;      // d_feat / d_rpart describe d_poses
   double *d_Gt = nullptr;           // [Kcols][npad]  factored Hessian columns (k-major)
   size_t cap_Gt = 0;                // doubles
   double *d_part = nullptr;         // [SG][ntiles][6400] split-K partial tiles

@@ -541,22 +541,31 @@ __device__ __forceinline__ void load5(const double *__restrict__ p, double (&x)[
 }
 
 // The 200 accumulator registers are pinned to AGPRs a0..a199 by generated inline asm
-// (gen/gen_syrk_asm.py explains why); the compiler only sees the operand loads.
+// (gen/gen_syrk_asm.py explains why); the compiler only sees the operand loads.  Operands are
+// prefetched NBUF-1 k-steps ahead (a k-step = 25 MFMAs = 1600 issue cycles) through a register ring.
+constexpr int SYRK_NBUF = 4;
+
 template <bool DIAG>
 __device__ __forceinline__ void syrk_sweep(const double *__restrict__ pa, const double *__restrict__ pb, size_t step,
-                                           int units) {
-  double a0[TM], b0[TM], a1[TM], b1[TM];
-  load5(pa, a0);
-  if (!DIAG) load5(pb, b0);
-  for (int u = 0; u < units; u++) {        // one unit = 8 columns of Gt = two MFMA k-steps
-    pa += step; pb += step;
-    load5(pa, a1);
-    if (!DIAG) load5(pb, b1);
-    if (DIAG) { BALM_SYRK_MFMA_DIAG(a0, a0) } else { BALM_SYRK_MFMA_FULL(a0, b0) }
-    pa += step; pb += step;
-    load5(pa, a0);                          // last unit: prefetches 4 columns past the slice (allocated)
-    if (!DIAG) load5(pb, b0);
-    if (DIAG) { BALM_SYRK_MFMA_DIAG(a1, a1) } else { BALM_SYRK_MFMA_FULL(a1, b1) }
+                                           int nsteps) {
+  double a[SYRK_NBUF][TM], b[SYRK_NBUF][TM];
+#pragma unroll
+  for (int i = 0; i < SYRK_NBUF - 1; i++) {
+    load5(pa + i * step, a[i]);
+    if (!DIAG) load5(pb + i * step, b[i]);
+  }
+  pa += (SYRK_NBUF - 1) * step;
+  pb += (SYRK_NBUF - 1) * step;
+  for (int s = 0; s < nsteps; s += SYRK_NBUF) {       // nsteps is a multiple of SYRK_NBUF
+#pragma unroll
+    for (int j = 0; j < SYRK_NBUF; j++) {
+      constexpr int dummy = 0; (void)dummy;
+      const int nb = (j + SYRK_NBUF - 1) % SYRK_NBUF;
+      load5(pa, a[nb]);                               // the last steps prefetch past the slice (allocated)
+      if (!DIAG) load5(pb, b[nb]);
+      pa += step; pb += step;
+      if (DIAG) { BALM_SYRK_MFMA_DIAG(a[j], a[j]) } else { BALM_SYRK_MFMA_FULL(a[j], b[j]) }
+    }
   }
 }
 
@@ -572,16 +581,18 @@ __global__ __launch_bounds__(256) void k_hessian_syrk(const double *__restrict__
   const int sg = (int)(bid / ntiles);
   const int I = tileIJ[2 * tile], J = tileIJ[2 * tile + 1];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const long slice = (long)sg * 4 + wv;
-  const size_t k_begin = (size_t)slice * units_per_slice * 8;
+  // the block owns 4 * units_per_slice * 8 consecutive columns of Gt; its four waves interleave the
+  // k-steps (wave w takes steps w, w+4, ...), so that all waves of the block -- and of the blocks of
+  // the same slice group running beside it on this XCD -- sweep one narrow window of Gt together
+  const size_t k_begin = (size_t)sg * 4 * units_per_slice * 8 + 4 * wv;
   const double *base = Gt + (k_begin + (lane >> 4)) * (size_t)npad + (lane & 15);
   const double *pa = base + I * TILE;
   const double *pb = base + J * TILE;
-  const size_t step = (size_t)4 * npad;
+  const size_t step = (size_t)16 * npad;
 
   BALM_SYRK_ZERO_ACC();
-  if (I == J) syrk_sweep<true>(pa, pb, step, units_per_slice);
-  else syrk_sweep<false>(pa, pb, step, units_per_slice);
+  if (I == J) syrk_sweep<true>(pa, pb, step, 2 * units_per_slice);
+  else syrk_sweep<false>(pa, pb, step, 2 * units_per_slice);
   // MFMA (16 passes) -> v_accvgpr_read needs wait states the assembler will not insert for asm
   asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
 
@@ -626,6 +637,7 @@ SyrkPlan plan_syrk(int ntiles, long K) {
   if (sg < 1) sg = 1;
   long slices = sg * 4;
   long ups = (units + slices - 1) / slices;
+  ups = (ups + 1) / 2 * 2;                           // 2*ups k-steps per wave, a multiple of the prefetch ring
   p.SG = (int)sg;
   p.units_per_slice = (int)ups;
   p.Kpad = (int)(slices * ups * 8);

@@ -203,7 +203,9 @@ def test_timing_slots_fill_when_enabled():
     c.damping_iter(sc.poses_init, u0=0.1, max_iter=3, no_stop=True, force_hess=True)
     t = c.timing()
     assert t["syrk"][1] == 3 and t["syrk"][0] > 0
-    assert t["solve"][1] == 3 and t["moments"][1] == 6
+    # one residual evaluation per iteration + one moments pass per Hessian evaluation whose poses were
+    # not just evaluated (after an accepted step the trial-pose records are reused)
+    assert t["solve"][1] == 3 and 4 <= t["moments"][1] <= 6
     c.close()
 
 
