@@ -6,8 +6,8 @@
 // |diagonal| of the input matrix".  We therefore apply that static symmetric permutation once and
 // run an un-pivoted *blocked* LDL^T (D diagonal, possibly negative: the exact second-order Hessian
 // is indefinite away from the optimum, SURVEY.md finding 4):
-//   per panel of NB=48 columns:  ldl_panel (single-wave workgroups)   L11, D11 in registers (redundantly per
-//                                                                     workgroup), W21 = L21 D11, L21
+//   per panel of NB=48 columns:  ldl_panel (rank-4 steps on f64 MFMA) L11, D11 (redundantly per workgroup),
+//                                                                     W21 = L21 D11, L21
 //                                ldl_trail (f64 MFMA, 48x16 tiles)    A22 -= L21 W21^T
 //   The right-hand side rides along as one extra row below the matrix (row nA of the ldA = nA+NB
 //   row storage): the panel / trail kernels then produce z = D^+ L^-1 P b for free, and only the
@@ -84,78 +84,133 @@ __device__ __forceinline__ double bcast(double v, int src) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// ldl_panel: one single-wavefront workgroup per 64 rows below the diagonal block.  Every
-// workgroup first factors the NB x NB diagonal block redundantly *in registers* (lane j owns the
-// full symmetric column j; pivots and multipliers travel by v_readlane, no LDS, no barriers), then
-// each lane forward-substitutes its own row:  w L11^T = a  ->  W21 = L21 D11, L21 = W21 D11^-1.
-// Workgroup 0 also stores L11 and D11.  (The diagonal block is fully symmetric-valid: build_A
-// fills both triangles and ldl_trail updates whole tiles.)
+// ldl_panel: LDL^T of the NB x NB diagonal block AND of this workgroup's 64 rows below it, by twelve
+// rank-4 steps whose trailing updates are single v_mfma_f64_16x16x4_f64 instructions (K = 4 is the
+// MFMA's k extent).  A workgroup (4 waves) keeps 7 row tiles of 16 rows -- tiles 0..2 = the diagonal
+// block (factored redundantly by every workgroup), tiles 3..6 = its own rows -- times 3 column tiles
+// in MFMA accumulators, transposed: accumulator element (lane, reg) of tile (rt, ct) is matrix
+// element (row 16 rt + (lane & 15), column 16 ct + (lane >> 4) + 4 reg), so that global loads and
+// stores touch 128 contiguous bytes per 16 lanes.  Per step q (columns 4q..4q+3):
+//   A  every lane publishes its one element of the four current columns to LDS;
+//   B  every lane factors the 4x4 pivot block redundantly in registers (no cross-lane traffic),
+//      lanes 0..111 turn their own row into W = row M4^T (= L D) and L = W D^-1, write the MFMA
+//      operands to LDS and stream L21 / W21 / L11 / D to global memory;
+//   C  acc(rt, ct) += L_op(ct) x (-W_op(rt))  -- one MFMA per live tile.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_ldl_panel(double *__restrict__ A, int nA, int c0,
-                                                  double *__restrict__ dvec, double *__restrict__ Wp) {
-  __shared__ double Lt[NB * NB];      // L11[j][k] at k*NB + j (j > k): column k contiguous
-  const int ldA = nA + NB, nR = nA + NB;          // rows nA..nA+NB-1: right-hand side tile
-  const int lane = threadIdx.x;
-  const int r = c0 + NB + blockIdx.x * 64 + lane;
-  const bool has_row = r < nR;
-  const int rr = has_row ? r : nR - 1;
-  // this lane's row of A21 (issued first so the loads fly under the factorization)
-  double a[NB];
-#pragma unroll
-  for (int k = 0; k < NB; k++) a[k] = A[(size_t)(c0 + k) * ldA + rr];
+constexpr int PANEL_ROWS = 64;                     // rows below the diagonal block per workgroup
+constexpr int PANEL_LR = NB + PANEL_ROWS;          // local rows: 48 diagonal + 64 own = 7 tiles of 16
+static_assert(PANEL_LR == 112 && NB == 48, "k_ldl_panel is written for 3 + 4 row tiles of 16");
 
-  double c[NB];
-  const int jc = lane < NB ? lane : 0;          // lanes 48..63 shadow column 0 and never contribute
-  const double *colp = A + (size_t)(c0 + jc) * ldA + c0;
+__device__ __forceinline__ double rcp_nr(double d) {        // 1/d: v_rcp_f64 + one Newton step
+  double x = __builtin_amdgcn_rcp(d);
+  x = __builtin_fma(__builtin_fma(-d, x, 1.0), x, x);
+  return (fabs(d) > DBL_MIN) ? x : 0.0;                      // Eigen's D^+ rule for a vanished pivot
+}
+
+__global__ __launch_bounds__(256) void k_ldl_panel(double *__restrict__ A, int nA, int c0,
+                                                   double *__restrict__ dvec, double *__restrict__ Wp) {
+  __shared__ double cur[4][PANEL_LR];     // the four current columns, all local rows
+  __shared__ double Wop[4][PANEL_LR];     // -W (B operand), k-major
+  __shared__ double Lop[4][PANEL_LR];     //  L (A operand; only local rows < NB are read)
+  const int ldA = nA + NB, nR = nA + NB;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int l15 = lane & 15, l4 = lane >> 4;
+  const int rbase = c0 + NB + blockIdx.x * PANEL_ROWS;        // first own row
+  auto grow = [&](int lr) { return lr < NB ? c0 + lr : rbase + (lr - NB); };   // local -> global row
+
+  // ---- load the 7 x 3 tiles into accumulators (wave w owns row tiles w and w + 4) ----
+  d4 acc[2][3];
 #pragma unroll
-  for (int i = 0; i < NB; i++) c[i] = colp[i];
+  for (int s = 0; s < 2; s++) {
+    const int rt = wv + 4 * s;
+    const int gr = grow(rt * 16 + l15);
+    const bool ok = rt < 7 && gr < nR;
+#pragma unroll
+    for (int ct = 0; ct < 3; ct++)
+#pragma unroll
+      for (int e = 0; e < 4; e++)
+        acc[s][ct][e] = ok ? A[(size_t)(c0 + ct * 16 + l4 + 4 * e) * ldA + (ok ? gr : 0)] : 0.0;
+  }
 
 #pragma unroll
-  for (int k = 0; k < NB; k++) {
-    const double dk = bcast(c[k], k);
-    const double inv = (fabs(dk) > DBL_MIN) ? 1.0 / dk : 0.0;
-    const double f = (lane > k && lane < NB) ? c[k] * inv : 0.0;     // l_jk for the columns still active
+  for (int q = 0; q < NB / 4; q++) {
+    const int jt = q >> 2, qq = q & 3;
+    // ---- A: publish columns 4q..4q+3 (lane holds row rt*16 + l15, column 4q + l4) ----
 #pragma unroll
-    for (int i = k + 1; i < NB; i++) {
-      const double aik = bcast(c[i], k);                             // a_ik (column k is final up to scale)
-      c[i] = __builtin_fma(-aik, f, c[i]);
+    for (int s = 0; s < 2; s++) {
+      const int rt = wv + 4 * s;
+      if (rt < 7) cur[l4][rt * 16 + l15] = acc[s][jt][qq];
     }
-    __builtin_amdgcn_sched_barrier(0);     // keep hipcc from hoisting hundreds of readlanes
-  }
-  // lane j: c[j] = d_j, c[i>j] = l_ij d_j
-  double dj = 1.0;
+    __syncthreads();
+    // ---- B: 4x4 pivot block (rows 4q..4q+3 of the diagonal block), redundantly per lane ----
+    const int p0 = 4 * q;
+    const double a00 = cur[0][p0], a10 = cur[0][p0 + 1], a20 = cur[0][p0 + 2], a30 = cur[0][p0 + 3];
+    const double a11 = cur[1][p0 + 1], a21 = cur[1][p0 + 2], a31 = cur[1][p0 + 3];
+    const double a22 = cur[2][p0 + 2], a32 = cur[2][p0 + 3], a33 = cur[3][p0 + 3];
+    const double d0 = a00, i0 = rcp_nr(d0);
+    const double l10 = a10 * i0, l20 = a20 * i0, l30 = a30 * i0;
+    const double d1 = __builtin_fma(-l10, a10, a11), i1 = rcp_nr(d1);
+    const double w21 = __builtin_fma(-l20, a10, a21), w31 = __builtin_fma(-l30, a10, a31);
+    const double l21 = w21 * i1, l31 = w31 * i1;
+    const double d2 = __builtin_fma(-l21, w21, __builtin_fma(-l20, a20, a22)), i2 = rcp_nr(d2);
+    const double w32 = __builtin_fma(-l31, w21, __builtin_fma(-l30, a20, a32));
+    const double l32 = w32 * i2;
+    const double d3 = __builtin_fma(-l32, w32, __builtin_fma(-l31, w31, __builtin_fma(-l30, a30, a33)));
+    const double i3 = rcp_nr(d3);
+    // M4 = L4^-1 (unit lower)
+    const double m10 = -l10, m21 = -l21, m32 = -l32;
+    const double m20 = __builtin_fma(l21, l10, -l20);
+    const double m31 = __builtin_fma(l32, l21, -l31);
+    const double m30 = -l30 - l31 * m10 - l32 * m20;
+    if (tid < PANEL_LR) {
+      const int lr = tid;
+      const double r0 = cur[0][lr], r1 = cur[1][lr], r2 = cur[2][lr], r3 = cur[3][lr];
+      double w0 = 0, w1 = 0, w2 = 0, w3 = 0, e0 = 0, e1 = 0, e2 = 0, e3 = 0;
+      const bool below = lr > p0 + 3;                      // rows still to be eliminated
+      if (below) {
+        w0 = r0;
+        w1 = __builtin_fma(m10, r0, r1);
+        w2 = __builtin_fma(m21, r1, __builtin_fma(m20, r0, r2));
+        w3 = __builtin_fma(m32, r2, __builtin_fma(m31, r1, __builtin_fma(m30, r0, r3)));
+        e0 = w0 * i0; e1 = w1 * i1; e2 = w2 * i2; e3 = w3 * i3;
+      }
+      Wop[0][lr] = -w0; Wop[1][lr] = -w1; Wop[2][lr] = -w2; Wop[3][lr] = -w3;
+      Lop[0][lr] = e0; Lop[1][lr] = e1; Lop[2][lr] = e2; Lop[3][lr] = e3;
+      // ---- stream the results out ----
+      const int gr = grow(lr);
+      const size_t cA = (size_t)(c0 + p0) * ldA + gr;
+      if (lr >= NB) {                                       // own rows: L21 in place, W21 for ldl_trail
+        if (gr < nR) {
+          A[cA] = e0; A[cA + ldA] = e1; A[cA + 2 * (size_t)ldA] = e2; A[cA + 3 * (size_t)ldA] = e3;
+          const size_t cW = (size_t)p0 * ldA + gr;
+          Wp[cW] = w0; Wp[cW + ldA] = w1; Wp[cW + 2 * (size_t)ldA] = w2; Wp[cW + 3 * (size_t)ldA] = w3;
+        }
+      } else if (blockIdx.x == 0) {                         // diagonal block: L11 and D, once
+        if (below) {
+          A[cA] = e0; A[cA + ldA] = e1; A[cA + 2 * (size_t)ldA] = e2; A[cA + 3 * (size_t)ldA] = e3;
+        } else if (lr >= p0) {                              // the pivot rows themselves: unit lower L4, D
+          const int e = lr - p0;
+          if (e >= 1) A[cA] = e == 1 ? l10 : (e == 2 ? l20 : l30);
+          if (e >= 2) A[cA + ldA] = e == 2 ? l21 : l31;
+          if (e >= 3) A[cA + 2 * (size_t)ldA] = l32;
+          dvec[c0 + lr] = e == 0 ? d0 : (e == 1 ? d1 : (e == 2 ? d2 : d3));
+        }
+      }
+    }
+    __syncthreads();
+    // ---- C: rank-4 update of every live tile: one MFMA each ----
 #pragma unroll
-  for (int i = 0; i < NB; i++) dj = (i == lane) ? c[i] : dj;
-  const double invd = (fabs(dj) > DBL_MIN) ? 1.0 / dj : 0.0;
-  if (lane < NB) {
+    for (int s = 0; s < 2; s++) {
+      const int rt = wv + 4 * s;
+      if (rt < 7) {
+        const double bop = Wop[l4][rt * 16 + l15];
 #pragma unroll
-    for (int i = 1; i < NB; i++) Lt[lane * NB + i] = c[i] * invd;    // rows i <= lane are never read
-  }
-  if (blockIdx.x == 0 && lane < NB) {
-    dvec[c0 + lane] = dj;
-    double *colw = A + (size_t)(c0 + lane) * ldA + c0;
-#pragma unroll
-    for (int i = 1; i < NB; i++)
-      if (i > lane) colw[i] = c[i] * invd;
-  }
-  __syncthreads();
-  // forward substitution along the row (right-looking): a_j -= a_k L11[j][k]; L11[j][k] is a
-  // wave-uniform LDS broadcast.  hipcc would otherwise hoist ALL 1128 LDS reads above the loop and
-  // spill them; the opaque zero tied to an already-final pivot bounds the read lookahead to 2 steps.
-#pragma unroll
-  for (int k = 0; k < NB - 1; k++) {
-    int z = 0;
-    asm volatile("" : "+v"(z) : "v"(a[k > 1 ? k - 2 : 0]));
-    const double *Lk = Lt + k * NB + z;
-#pragma unroll
-    for (int j = k + 1; j < NB; j++) a[j] = __builtin_fma(-a[k], Lk[j], a[j]);
-  }
-#pragma unroll
-  for (int j = 0; j < NB; j++) {
-    const double dd = bcast(invd, j);       // every lane still active: readlane needs lane j live
-    if (has_row) {
-      Wp[(size_t)j * ldA + r] = a[j];
-      A[(size_t)(c0 + j) * ldA + r] = a[j] * dd;
+        for (int ct = 0; ct < 3; ct++)
+          if (ct >= jt) {
+            const double aop = Lop[l4][ct * 16 + l15];
+            acc[s][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop, acc[s][ct], 0, 0, 0);
+          }
+      }
     }
   }
 }
@@ -304,7 +359,8 @@ void launch_solve(balm_ctx *c, double u, bool new_hessian) {
     const int c0 = p * NB;
     const int m = nA - c0 - NB;                 // square part still to factor
     const int rows = m + NB;                    // + right-hand side tile
-    hipLaunchKernelGGL(k_ldl_panel, dim3((rows + 63) / 64), dim3(64), 0, s, c->d_A, nA, c0, c->d_dvec, c->d_Wp);
+    hipLaunchKernelGGL(k_ldl_panel, dim3((rows + PANEL_ROWS - 1) / PANEL_ROWS), dim3(256), 0, s, c->d_A, nA, c0,
+                       c->d_dvec, c->d_Wp);
     if (m > 0) {
       const int mt = m / NB;
       hipLaunchKernelGGL(k_ldl_trail, dim3((3 * mt + 3) / 4, mt + 1), dim3(256), 0, s, c->d_A, nA, c0, c->d_Wp, mt);
