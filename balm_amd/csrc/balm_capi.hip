@@ -186,7 +186,7 @@ balm_ctx *balm_create(int win_size, int device, int flags) {
       dalloc(ctx, &ctx->d_red, ctx->red_len) || dalloc(ctx, &ctx->d_tileIJ, (size_t)2 * ctx->ntiles) ||
       dalloc(ctx, &ctx->d_H, (size_t)n * n) || dalloc(ctx, &ctx->d_g, (size_t)n) ||
       dalloc(ctx, &ctx->d_A, (size_t)(nA + NB) * nA) || dalloc(ctx, &ctx->d_Wp, (size_t)NB * (nA + NB)) ||
-      dalloc(ctx, &ctx->d_dvec, (size_t)nA) ||
+      dalloc(ctx, &ctx->d_dvec, (size_t)nA) || dalloc(ctx, &ctx->d_z, (size_t)nA) || dalloc(ctx, &ctx->d_x, (size_t)nA) ||
       dalloc(ctx, &ctx->d_perm, (size_t)nA) || dalloc(ctx, &ctx->d_dx, (size_t)n) ||
       dalloc(ctx, &ctx->d_scal, (size_t)16))
     return fail();
@@ -207,7 +207,7 @@ void balm_destroy(balm_ctx *ctx) {
   if (ctx->stream) hipStreamSynchronize(ctx->stream);
   void *ptrs[] = {ctx->d_cl, ctx->d_fix, ctx->d_coe, ctx->d_poses, ctx->d_poses_tmp, ctx->d_C, ctx->d_feat,
                   ctx->d_Gt, ctx->d_part, ctx->d_dpart, ctx->d_rpart, ctx->d_feat_tmp, ctx->d_rpart_tmp, ctx->d_red, ctx->d_tileIJ, ctx->d_H,
-                  ctx->d_g, ctx->d_A, ctx->d_Wp, ctx->d_dvec, ctx->d_perm, ctx->d_dx, ctx->d_scal};
+                  ctx->d_g, ctx->d_A, ctx->d_Wp, ctx->d_dvec, ctx->d_z, ctx->d_x, ctx->d_perm, ctx->d_dx, ctx->d_scal};
   for (void *p : ptrs) if (p) hipFree(p);
   if (ctx->h_scal) hipHostFree(ctx->h_scal);
   for (auto &sp : ctx->timer.pending) { hipEventDestroy(sp.a); hipEventDestroy(sp.b); }

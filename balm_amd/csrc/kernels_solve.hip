@@ -108,7 +108,8 @@ __device__ __forceinline__ double rcp_nr(double d) {        // 1/d: v_rcp_f64 + 
 }
 
 __global__ __launch_bounds__(256) void k_ldl_panel(double *__restrict__ A, int nA, int c0,
-                                                   double *__restrict__ dvec, double *__restrict__ Wp) {
+                                                   double *__restrict__ dvec, double *__restrict__ Wp,
+                                                   double *__restrict__ zvec) {
   __shared__ double cur[4][PANEL_LR];     // the four current columns, all local rows
   __shared__ double Wop[4][PANEL_LR];     // -W (B operand), k-major
   __shared__ double Lop[4][PANEL_LR];     //  L (A operand; only local rows < NB are read)
@@ -184,6 +185,9 @@ __global__ __launch_bounds__(256) void k_ldl_panel(double *__restrict__ A, int n
           A[cA] = e0; A[cA + ldA] = e1; A[cA + 2 * (size_t)ldA] = e2; A[cA + 3 * (size_t)ldA] = e3;
           const size_t cW = (size_t)p0 * ldA + gr;
           Wp[cW] = w0; Wp[cW + ldA] = w1; Wp[cW + 2 * (size_t)ldA] = w2; Wp[cW + 3 * (size_t)ldA] = w3;
+          if (gr == nA) {                                   // right-hand side row: z = D^+ L^-1 P b
+            zvec[c0 + p0] = e0; zvec[c0 + p0 + 1] = e1; zvec[c0 + p0 + 2] = e2; zvec[c0 + p0 + 3] = e3;
+          }
         }
       } else if (blockIdx.x == 0) {                         // diagonal block: L11 and D, once
         if (below) {
@@ -261,81 +265,73 @@ __global__ __launch_bounds__(256) void k_ldl_trail(double *__restrict__ A, int n
 }
 
 // ------------------------------------------------------------------------------------------------
-// backward solve  L^T x = z  (z = row nA of the factored storage) + un-permute + q1; one workgroup
-// of 8 waves.  Left-looking over panels of NB columns, descending:
-//   t_k = sum_{r below} L[r][c0+k] x[r]   six columns per wave, lanes stride the rows (every load is
-//                                        512 contiguous bytes of a column), shuffle reduction;
-//   wave 0 then solves the NB x NB unit-triangular block by v_readlane substitution (lane = column).
+// backward solve  L^T x = z, right-looking, one launch per panel (descending).  Every workgroup
+// solves the NB x NB unit-triangular block redundantly (wave 0: lane = column, v_readlane
+// substitution) while all its lanes already hold -- prefetched -- the NB multipliers
+// L[c0..c0+NB)[r] of their own row r < c0 (384 contiguous bytes), then applies the rank-NB update
+// z_r -= L[.,r] . x_p.  Workgroup 0 publishes x_p.
 // ------------------------------------------------------------------------------------------------
-constexpr int TPB = 512;
-static_assert(NB == 6 * (TPB / 64), "six panel columns per wave");
-
-__global__ __launch_bounds__(TPB) void k_ldl_backsolve(const double *__restrict__ A, int nA, int n,
-                                                       const int *__restrict__ perm, const double *__restrict__ H,
-                                                       const double *__restrict__ g, double u,
-                                                       double *__restrict__ dx, double *__restrict__ scal) {
-  extern __shared__ __attribute__((aligned(16))) double sh[];
-  double *y = sh;            // [nA]  z on entry, x on exit
-  double *t = sh + nA;       // [NB]
-  double *red = t + NB;      // [TPB]
+__global__ __launch_bounds__(256) void k_ldl_back_panel(const double *__restrict__ A, int nA, int c0,
+                                                        double *__restrict__ z, double *__restrict__ xout) {
+  __shared__ double xs[NB];
   const int ldA = nA + NB;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int P = nA / NB;
-  for (int r = tid; r < nA; r += TPB) y[r] = A[(size_t)r * ldA + nA];
-  __syncthreads();
-  for (int p = P - 1; p >= 0; p--) {
-    const int c0 = p * NB;
-    // wave 0: column `lane` of the diagonal block, rows below its diagonal (in flight under the dots)
-    double Lb[NB];
-    if (wv == 0) {
-      const double *col = A + (size_t)(c0 + (lane < NB ? lane : 0)) * ldA + c0;
+  const int r = blockIdx.x * 256 + tid;
+  const bool has_row = r < c0;
+  double l[NB];
+  {
+    const double *src = A + (size_t)(has_row ? r : 0) * ldA + c0;
 #pragma unroll
-      for (int k = 0; k < NB; k++) Lb[k] = col[k];
-    }
-    double acc[6];
-#pragma unroll
-    for (int q = 0; q < 6; q++) acc[q] = 0.0;
-    const double *cb = A + (size_t)(c0 + 6 * wv) * ldA;
-#pragma unroll 4
-    for (int r = c0 + NB + lane; r < nA; r += 64) {
-      const double xr = y[r];
-#pragma unroll
-      for (int q = 0; q < 6; q++) acc[q] = __builtin_fma(cb[(size_t)q * ldA + r], xr, acc[q]);
-    }
-#pragma unroll
-    for (int q = 0; q < 6; q++) {
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) acc[q] += __shfl_xor(acc[q], off, 64);
-    }
-    if (lane == 0) {
-#pragma unroll
-      for (int q = 0; q < 6; q++) t[6 * wv + q] = acc[q];
-    }
-    __syncthreads();
-    if (wv == 0) {
-      double v = lane < NB ? y[c0 + lane] - t[lane] : 0.0;
-#pragma unroll
-      for (int k = NB - 1; k >= 1; k--) {
-        const double xk = bcast(v, k);
-        if (lane < k) v = __builtin_fma(-Lb[k], xk, v);
-      }
-      if (lane < NB) y[c0 + lane] = v;
-    }
-    __syncthreads();
+    for (int k = 0; k < NB; k++) l[k] = src[k];
   }
-  // un-permute, q1 = 0.5 dx.(u D dx - g)    (bavoxel.hpp:1127)
+  if (wv == 0) {
+    const int j = lane < NB ? lane : 0;
+    const double *col = A + (size_t)(c0 + j) * ldA + c0;       // column j of the block: rows k > j
+    double Lb[NB];
+#pragma unroll
+    for (int k = 0; k < NB; k++) Lb[k] = col[k];
+    double v = z[c0 + j];
+#pragma unroll
+    for (int k = NB - 1; k >= 1; k--) {
+      const double xk = bcast(v, k);
+      if (lane < k) v = __builtin_fma(-Lb[k], xk, v);
+    }
+    if (lane < NB) {
+      xs[lane] = v;
+      if (blockIdx.x == 0) xout[c0 + lane] = v;
+    }
+  }
+  __syncthreads();
+  if (has_row) {
+    double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+    for (int k = 0; k < NB; k += 2) {
+      s0 = __builtin_fma(l[k], xs[k], s0);
+      s1 = __builtin_fma(l[k + 1], xs[k + 1], s1);
+    }
+    z[r] -= s0 + s1;
+  }
+}
+
+// un-permute, q1 = 0.5 dx.(u D dx - g)    (bavoxel.hpp:1127)
+__global__ __launch_bounds__(1024) void k_ldl_finish(const double *__restrict__ x, int nA, int n,
+                                                     const int *__restrict__ perm, const double *__restrict__ H,
+                                                     const double *__restrict__ g, double u,
+                                                     double *__restrict__ dx, double *__restrict__ scal) {
+  __shared__ double red[1024];
+  const int tid = threadIdx.x;
   double q = 0.0;
-  for (int r = tid; r < nA; r += TPB) {
+  for (int r = tid; r < nA; r += 1024) {
     const int p = perm[r];
     if (p < n) {
-      const double x = y[r];
-      dx[p] = x;
-      q += x * (u * H[(size_t)p * n + p] * x - g[p]);
+      const double xv = x[r];
+      dx[p] = xv;
+      q += xv * (u * H[(size_t)p * n + p] * xv - g[p]);
     }
   }
   red[tid] = q;
   __syncthreads();
-  for (int s = TPB / 2; s > 0; s >>= 1) {
+  for (int s = 512; s > 0; s >>= 1) {
     if (tid < s) red[tid] += red[tid + s];
     __syncthreads();
   }
@@ -360,14 +356,18 @@ void launch_solve(balm_ctx *c, double u, bool new_hessian) {
     const int m = nA - c0 - NB;                 // square part still to factor
     const int rows = m + NB;                    // + right-hand side tile
     hipLaunchKernelGGL(k_ldl_panel, dim3((rows + PANEL_ROWS - 1) / PANEL_ROWS), dim3(256), 0, s, c->d_A, nA, c0,
-                       c->d_dvec, c->d_Wp);
+                       c->d_dvec, c->d_Wp, c->d_z);
     if (m > 0) {
       const int mt = m / NB;
       hipLaunchKernelGGL(k_ldl_trail, dim3((3 * mt + 3) / 4, mt + 1), dim3(256), 0, s, c->d_A, nA, c0, c->d_Wp, mt);
     }
   }
-  size_t lds = (size_t)(nA + NB + TPB) * sizeof(double);
-  hipLaunchKernelGGL(k_ldl_backsolve, dim3(1), dim3(TPB), lds, s, c->d_A, nA, n, c->d_perm, c->d_H, c->d_g, u, c->d_dx,
+  for (int p = P - 1; p >= 0; p--) {
+    const int c0 = p * NB;
+    hipLaunchKernelGGL(k_ldl_back_panel, dim3(c0 > 0 ? (c0 + 255) / 256 : 1), dim3(256), 0, s, c->d_A, nA, c0, c->d_z,
+                       c->d_x);
+  }
+  hipLaunchKernelGGL(k_ldl_finish, dim3(1), dim3(1024), 0, s, c->d_x, nA, n, c->d_perm, c->d_H, c->d_g, u, c->d_dx,
                      c->d_scal);
 }
 
