@@ -100,13 +100,15 @@ __global__ __launch_bounds__(256) void k_world_moments(const double *__restrict_
 #pragma unroll
     for (int c = 0; c < 10; c++) acc[c] = 0.0;
     for (int i = lane; i < W; i += 64) {
+      // all ten streams are loaded unconditionally: one memory latency per observation, not two
+      double P[6], v[3];
       const double N = ca[(size_t)9 * W + i];
+#pragma unroll
+      for (int c = 0; c < 6; c++) P[c] = ca[(size_t)c * W + i];
+#pragma unroll
+      for (int c = 0; c < 3; c++) v[c] = ca[(size_t)(6 + c) * W + i];
       if ((int)N > 0) {
-        double P[6], v[3], R[9], p[3];
-#pragma unroll
-        for (int c = 0; c < 6; c++) P[c] = ca[(size_t)c * W + i];
-#pragma unroll
-        for (int c = 0; c < 3; c++) v[c] = ca[(size_t)(6 + c) * W + i];
+        double R[9], p[3];
 #pragma unroll
         for (int c = 0; c < 9; c++) R[c] = sp[c * W + i];
 #pragma unroll
@@ -294,6 +296,16 @@ __global__ __launch_bounds__(256) void k_feature_factors(const double *__restric
   for (int t = threadIdx.x; t < DACC * W; t += blockDim.x) sacc[t] = 0.0;
   __syncthreads();
 
+  // cluster of (feature a, pose i): ten coalesced streams, loaded one feature ahead of its use
+  double nxt[10];
+  auto fetch = [&](int a, int i) {
+    const double *ca = cl + (size_t)a * 10 * W + i;
+#pragma unroll
+    for (int c = 0; c < 10; c++) nxt[c] = ca[(size_t)c * W];
+  };
+  const int i_first = threadIdx.x < (unsigned)W ? threadIdx.x : 0;
+  if (f0 + (int)blockIdx.x < f1) fetch(f0 + blockIdx.x, i_first);
+
   for (int a = f0 + blockIdx.x; a < f1; a += gridDim.x) {
     const double *f = feat + (size_t)a * FEAT_STRIDE;
     const double NN = f[FT_NN];
@@ -308,13 +320,22 @@ __global__ __launch_bounds__(256) void k_feature_factors(const double *__restric
 
     for (int i = threadIdx.x; i < W; i += blockDim.x) {
       double col0[6], col1[6], col2[6];
-      const double N = ca[(size_t)9 * W + i];
-      if ((int)N > 0) {
-        double P[6], v[3], R[9], p[3];
+      double P[6], v[3];
+      if (i == (int)threadIdx.x) {          // first pose slot of this lane: prefetched
+#pragma unroll
+        for (int c = 0; c < 6; c++) P[c] = nxt[c];
+#pragma unroll
+        for (int c = 0; c < 3; c++) v[c] = nxt[6 + c];
+      } else {                               // W > blockDim.x: further slots are loaded in place
 #pragma unroll
         for (int c = 0; c < 6; c++) P[c] = ca[(size_t)c * W + i];
 #pragma unroll
         for (int c = 0; c < 3; c++) v[c] = ca[(size_t)(6 + c) * W + i];
+      }
+      const double N = i == (int)threadIdx.x ? nxt[9] : ca[(size_t)9 * W + i];
+      if (i == (int)threadIdx.x && a + (int)gridDim.x < f1) fetch(a + gridDim.x, i_first);
+      if ((int)N > 0) {
+        double R[9], p[3];
 #pragma unroll
         for (int c = 0; c < 9; c++) R[c] = sp[c * W + i];
 #pragma unroll
@@ -519,6 +540,12 @@ void launch_factors(hipStream_t s, int form, const double *cl, const double *pos
   int dacc = form == 0 ? DACC_LEFT : DACC_RIGHT;
   size_t lds = (size_t)(12 + dacc) * W * sizeof(double);
   int bs = W <= 64 ? 64 : (W <= 128 ? 128 : 256);
+  static bool attr_set = false;
+  if (!attr_set) {   // windows above ~200 poses need more than the default 64 KiB of dynamic LDS
+    hipFuncSetAttribute((const void *)k_feature_factors<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void *)k_feature_factors<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
   if (form == 0)
     hipLaunchKernelGGL(k_feature_factors<0>, dim3(nblk), dim3(bs), lds, s, cl, poses, feat, W, npad, f0, f1, Gt, dpart);
   else

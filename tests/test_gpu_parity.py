@@ -53,6 +53,21 @@ def test_evaluate_matches_oracle(case, form):
     c.close()
 
 
+@pytest.mark.parametrize("W,F,form", [(177, 60, 0), (230, 40, 0), (230, 40, 1), (320, 30, 0), (480, 24, 0), (480, 24, 1)])
+def test_wide_windows(W, F, form):
+    """windows beyond one LDS default (W > 210), the shipped data's W=177 and the W=480 ceiling;
+    evaluate + one damped solve against the oracle"""
+    sc, _ = make_scene(90 + W, W, F, 4, drop=0.3, mode=1)
+    c = ctx_for(sc)
+    H, g, r = c.evaluate(form, sc.poses_init)
+    Ho, go, ro = orc.evaluate_threads(form, sc.clusters, None, sc.coeffs, sc.poses_init, 8)
+    assert abs(r - ro) / ro < 1e-12 and rel_err(g, go) < HTOL and rel_err(H, Ho) < HTOL
+    dx, q1 = c.solve_damped(Ho, go, 0.5)
+    A = Ho + 0.5 * np.diag(np.diag(Ho))
+    assert np.linalg.norm(A @ dx + go) / np.linalg.norm(go) < 1e-8
+    c.close()
+
+
 def test_evaluate_is_deterministic_run_to_run():
     sc, _ = make_scene(11, 40, 200, 6)
     c = ctx_for(sc)
