@@ -555,10 +555,9 @@ void launch_factors(hipStream_t s, int form, const double *cl, const double *pos
 // ------------------------------------------------------------------------------------------------
 // K3: hessian_syrk.  part[sg][tile] = Gt[I-rows, kslice] * Gt[J-rows, kslice]^T for the upper
 // triangle of 80x80 tiles.  One wavefront owns a full 80x80 accumulator (25 v_mfma_f64_16x16x4_f64
-// tiles = 200 accumulator VGPRs, one wave per SIMD); the four waves of a block take four
-// consecutive k sub-slices of the same tile and are summed through LDS, so split-K partial traffic
-// stays at SG (not 4 SG) tiles.  Operands come straight from HBM/L2: lane l of an MFMA operand is
-// Gt[k0 + (l>>4)][row0 + (l&15)] -- four 128-byte row segments per instruction.
+// tiles = 200 accumulator AGPRs, one wave per SIMD) over one k-slice; no LDS, no barriers.
+// Operands come straight from L2: lane l of an MFMA operand is Gt[k0 + (l>>4)][row0 + (l&15)] --
+// four 128-byte row segments per instruction.
 // ------------------------------------------------------------------------------------------------
 #include "syrk_mfma_asm.inc"
 
@@ -596,91 +595,72 @@ __device__ __forceinline__ void syrk_sweep(const double *__restrict__ pa, const 
   }
 }
 
-__global__ __launch_bounds__(256) void k_hessian_syrk(const double *__restrict__ Gt, int npad, int ntiles,
-                                                      const int *__restrict__ tileIJ, int units_per_slice,
-                                                      long nblocks, double *__restrict__ part) {
-  extern __shared__ __attribute__((aligned(16))) double sred[];   // [3][100][64]
-  // XCD-aware remap: hardware places block b on XCD b % 8; give every XCD a contiguous run of
-  // logical blocks (same k-slice group, neighbouring tiles) so shared Gt panels hit its L2.
+__global__ __launch_bounds__(64) void k_hessian_syrk(const double *__restrict__ Gt, int npad, int ntiles,
+                                                     const int *__restrict__ tileIJ, int nsteps, long nblocks,
+                                                     double *__restrict__ part) {
+  // One wavefront per (tile, k-slice).  XCD-aware remap: hardware places workgroup b on XCD b % 8;
+  // every XCD gets a contiguous run of logical workgroups = ALL tiles of one k-slice after the other.
+  // An XCD holds 128 of these one-wave workgroups (4 per CU), i.e. the 120 tiles of a slice run side
+  // by side and sweep k in lockstep (they are all MFMA-paced), so each 128-byte line of Gt is pulled
+  // into that XCD's L2 once and serves the ~15 tiles that need it.
   long bid = blockIdx.x;
   if ((nblocks & 7) == 0) bid = (bid & 7) * (nblocks >> 3) + (bid >> 3);
   const int tile = (int)(bid % ntiles);
   const int sg = (int)(bid / ntiles);
   const int I = tileIJ[2 * tile], J = tileIJ[2 * tile + 1];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  // the block owns 4 * units_per_slice * 8 consecutive columns of Gt; its four waves interleave the
-  // k-steps (wave w takes steps w, w+4, ...), so that all waves of the block -- and of the blocks of
-  // the same slice group running beside it on this XCD -- sweep one narrow window of Gt together
-  const size_t k_begin = (size_t)sg * 4 * units_per_slice * 8 + 4 * wv;
+  const int lane = threadIdx.x;
+  const size_t k_begin = (size_t)sg * nsteps * 4;
   const double *base = Gt + (k_begin + (lane >> 4)) * (size_t)npad + (lane & 15);
   const double *pa = base + I * TILE;
   const double *pb = base + J * TILE;
-  const size_t step = (size_t)16 * npad;
+  const size_t step = (size_t)4 * npad;
 
   BALM_SYRK_ZERO_ACC();
-  if (I == J) syrk_sweep<true>(pa, pb, step, 2 * units_per_slice);
-  else syrk_sweep<false>(pa, pb, step, 2 * units_per_slice);
+  if (I == J) syrk_sweep<true>(pa, pb, step, nsteps);
+  else syrk_sweep<false>(pa, pb, step, nsteps);
   // MFMA (16 passes) -> v_accvgpr_read needs wait states the assembler will not insert for asm
   asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
 
-  // sum the four k sub-slices of this block through LDS (register-major layout, conflict-free)
-  if (wv > 0) {
-    double *dst = sred + (size_t)(wv - 1) * TILE_ELEMS + lane;
+  double *out = part + ((size_t)sg * ntiles + tile) * TILE_ELEMS + lane;     // register-major: coalesced
 #define BALM_X(T)                                                                             \
   {                                                                                           \
     unsigned U[8];                                                                            \
     BALM_SYRK_READ_##T(U);                                                                    \
-    _Pragma("unroll") for (int e = 0; e < 4; e++) dst[(T * 4 + e) * 64] = __hiloint2double(U[2 * e + 1], U[2 * e]); \
+    _Pragma("unroll") for (int e = 0; e < 4; e++) out[(T * 4 + e) * 64] = __hiloint2double(U[2 * e + 1], U[2 * e]); \
   }
-    BALM_SYRK_FOR_TILES(BALM_X)
+  BALM_SYRK_FOR_TILES(BALM_X)
 #undef BALM_X
-  }
-  __syncthreads();
-  if (wv == 0) {
-    double *out = part + ((size_t)sg * ntiles + tile) * TILE_ELEMS + lane;
-#define BALM_X(T)                                                                             \
-  {                                                                                           \
-    unsigned U[8];                                                                            \
-    BALM_SYRK_READ_##T(U);                                                                    \
-    _Pragma("unroll") for (int e = 0; e < 4; e++) {                                           \
-      const int o = (T * 4 + e) * 64;                                                         \
-      out[o] = __hiloint2double(U[2 * e + 1], U[2 * e]) + sred[o + lane] + sred[TILE_ELEMS + o + lane] + \
-               sred[2 * TILE_ELEMS + o + lane];                                               \
-    }                                                                                         \
-  }
-    BALM_SYRK_FOR_TILES(BALM_X)
-#undef BALM_X
-  }
 }
 
 SyrkPlan plan_syrk(int ntiles, long K) {
   SyrkPlan p;
-  long units = (K + 7) / 8;
-  if (units < 1) units = 1;
-  long sg = (3840 + ntiles - 1) / ntiles;           // ~15 rounds of 256 CUs at W=200
-  long max_sg = units / (4 * 8);                    // keep >= 64 columns per wave
+  long steps = (K + 3) / 4;                         // MFMA k-steps (4 columns of Gt each)
+  if (steps < 1) steps = 1;
+  long max_sg = steps / 64;                         // keep >= 256 columns per wave
   if (max_sg < 1) max_sg = 1;
+  // ~4 resident rounds of the 1024 wave slots (128 per XCD): pick the slice count in that
+  // neighbourhood whose last round is fullest
+  long base = (4096 + ntiles - 1) / ntiles, sg = base;
+  double best = -1.0;
+  for (long c = (base > 6 ? base - 6 : 1); c <= base + 6; c++) {
+    const double per_xcd = (double)ntiles * c / 8.0;
+    const double rounds = (double)(long)((per_xcd + 127.0) / 128.0);
+    const double eff = per_xcd / (rounds * 128.0);
+    if (eff > best + 1e-9) { best = eff; sg = c; }
+  }
   if (sg > max_sg) sg = max_sg;
-  if (sg < 1) sg = 1;
-  long slices = sg * 4;
-  long ups = (units + slices - 1) / slices;
-  ups = (ups + 1) / 2 * 2;                           // 2*ups k-steps per wave, a multiple of the prefetch ring
+  long nst = (steps + sg - 1) / sg;
+  nst = (nst + SYRK_NBUF - 1) / SYRK_NBUF * SYRK_NBUF;      // whole turns of the prefetch ring
   p.SG = (int)sg;
-  p.units_per_slice = (int)ups;
-  p.Kpad = (int)(slices * ups * 8);
+  p.units_per_slice = (int)nst;                     // k-steps per wave
+  p.Kpad = (int)(sg * nst * 4);
   p.nblocks = sg * ntiles;
   return p;
 }
 
 void launch_syrk(hipStream_t s, const double *Gt, int npad, int ntiles, const int *tileIJ, const SyrkPlan &p,
                  double *part) {
-  size_t lds = (size_t)3 * TILE_ELEMS * sizeof(double);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipFuncSetAttribute((const void *)k_hessian_syrk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
-  hipLaunchKernelGGL(k_hessian_syrk, dim3((unsigned)p.nblocks), dim3(256), lds, s, Gt, npad, ntiles, tileIJ,
+  hipLaunchKernelGGL(k_hessian_syrk, dim3((unsigned)p.nblocks), dim3(64), 0, s, Gt, npad, ntiles, tileIJ,
                      p.units_per_slice, p.nblocks, part);
 }
 
