@@ -14,8 +14,8 @@ LIB_PATH = os.path.join(_HERE, "lib", "libbalm_hip.so")
 FORM_LEFT, FORM_RIGHT = 0, 1
 OK, ERR_ARG, ERR_HIP, ERR_STATE, ERR_TOO_FEW_PLANES, ERR_NUMERIC = range(6)
 FLAG_TIMING = 1
-T_MOMENTS, T_FACTORS, T_SYRK, T_ASSEMBLE, T_SOLVE, T_UPDATE, T_COUNT = range(7)
-TIMING_NAMES = ["moments", "factors", "syrk", "assemble", "solve", "update"]
+T_MOMENTS, T_FACTORS, T_SYRK, T_ASSEMBLE, T_SOLVE, T_UPDATE, T_BUILD, T_COUNT = range(8)
+TIMING_NAMES = ["moments", "factors", "syrk", "assemble", "solve", "update", "build"]
 
 # every symbol include/balm_hip.h declares
 EXPORTS = ["balm_create", "balm_destroy", "balm_set_features", "balm_evaluate", "balm_only_residual",

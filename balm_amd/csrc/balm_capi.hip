@@ -290,7 +290,10 @@ int balm_build_clusters(balm_ctx *ctx, int F, const float *xyz, const int *feat_
   if (e == hipSuccess) e = hipMemcpyAsync(d_p, pose_id, (size_t)n_pts * sizeof(int), hipMemcpyHostToDevice, ctx->stream);
   if (e == hipSuccess) e = hipMemsetAsync(ctx->d_cl, 0, count * sizeof(double), ctx->stream);
   if (e == hipSuccess) {
-    launch_build_clusters(ctx->stream, d_xyz, d_f, d_p, n_pts, F, W, ctx->d_cl);
+    {
+      Span sp(ctx, BALM_T_BUILD);
+      launch_build_clusters(ctx->stream, d_xyz, d_f, d_p, n_pts, F, W, ctx->d_cl);
+    }
     e = hipStreamSynchronize(ctx->stream);
   }
   if (d_xyz) hipFree(d_xyz);

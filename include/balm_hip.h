@@ -127,7 +127,8 @@ enum {
   BALM_T_ASSEMBLE = 3,  /* split-K reduce + assemble H, g                                      */
   BALM_T_SOLVE = 4,     /* permute + blocked LDL^T + triangular solves                        */
   BALM_T_UPDATE = 5,    /* pose update + gain-ratio scalars                                   */
-  BALM_T_COUNT = 6
+  BALM_T_BUILD = 6,     /* cluster build from points (balm_build_clusters kernel only)        */
+  BALM_T_COUNT = 7
 };
 int balm_get_timing(balm_ctx *ctx, double *ms, long *count);
 int balm_reset_timing(balm_ctx *ctx);
