@@ -120,3 +120,22 @@ def log(R):
     w = np.zeros(3)
     lib().ref_log(_p(_c(np.asarray(R).T)), _p(w))
     return w
+
+
+def realworld_features(data_dir, voxel_size=2.0, max_poses=0):
+    """benchmark_realworld's input pipeline (ROS-free): read the shipped alidarPose.csv + full<m>.pcd, run
+    the reference's own cut_voxel / recut / tras_opt, return (clusters [F,W,10], fix [F,10], coeffs [F],
+    poses [W,12], n_points)."""
+    L = lib()
+    L.ref_rw_open.restype = C.c_void_p
+    h = L.ref_rw_open(data_dir.encode(), C.c_double(voxel_size), int(max_poses))
+    if not h:
+        raise FileNotFoundError(data_dir)
+    h = C.c_void_p(h)
+    W, F, npts = C.c_int(0), C.c_int(0), C.c_long(0)
+    L.ref_rw_dims(h, C.byref(W), C.byref(F), C.byref(npts))
+    cl = np.zeros((F.value, W.value, 10)); fx = np.zeros((F.value, 10)); co = np.zeros(F.value)
+    poses = np.zeros((W.value, 12))
+    L.ref_rw_export(h, _p(cl), _p(fx), _p(co), _p(poses))
+    L.ref_rw_close(h)
+    return cl, fx, co, poses, npts.value

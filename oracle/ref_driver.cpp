@@ -13,6 +13,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstring>
+#include <string>
 
 #include "tools.hpp"
 #include "bavoxel.hpp"
@@ -210,6 +211,94 @@ double ref_time_solve(int n, const double *Hess, const double *JacT, double u) {
   auto t1 = std::chrono::steady_clock::now();
   return std::chrono::duration<double>(t1 - t0).count();
 }
+
+// ---- real-world pipeline of benchmark_realworld.cpp:144-218, minus ROS/RViz ------------------------
+// read_pose (:31-73) and read_file (:75-106) restated for the shipped files (alidarPose.csv: 4 text
+// lines per pose, rows of [R|t], element (3,3) = timestamp; full<m>.pcd: 11 ASCII header lines ending
+// "DATA binary", then 32-byte records x y z intensity normal_x normal_y normal_z curvature, all f32);
+// the association itself (cut_voxel -> recut -> tras_opt -> VOX_HESS::push_voxel) is the reference's.
+struct RwHandle {
+  std::vector<IMUST> x_buf;
+  std::unordered_map<VOXEL_LOC, OCTO_TREE_ROOT *> surf_map;
+  VOX_HESS voxhess;
+  long n_points = 0;
+  ~RwHandle() { for (auto &kv : surf_map) delete kv.second; }
+};
+
+void *ref_rw_open(const char *dir, double vsize, int max_poses) {
+  RwHandle *h = new RwHandle();
+  std::string pre(dir);
+  if (pre.back() != '/') pre += '/';
+  FILE *f = fopen((pre + "alidarPose.csv").c_str(), "r");
+  if (!f) { delete h; return nullptr; }
+  std::vector<double> nums;
+  double v; int ch;
+  while (fscanf(f, "%lf", &v) == 1) { nums.push_back(v); do { ch = fgetc(f); } while (ch == ',' || ch == ' ' || ch == '\r' || ch == '\n'); if (ch != EOF) ungetc(ch, f); }
+  fclose(f);
+  int W = (int)(nums.size() / 16);
+  if (max_poses > 0 && W > max_poses) W = max_poses;
+  std::vector<pcl::PointCloud<PointType>::Ptr> pl_fulls;
+  for (int m = 0; m < W; m++) {
+    IMUST curr;
+    for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) curr.R(r, c) = nums[16 * m + 4 * r + c]; curr.p[r] = nums[16 * m + 4 * r + 3]; }
+    curr.t = nums[16 * m + 15];
+    h->x_buf.push_back(curr);
+    pcl::PointCloud<PointType>::Ptr pl(new pcl::PointCloud<PointType>());
+    FILE *pf = fopen((pre + "full" + std::to_string(m) + ".pcd").c_str(), "rb");
+    if (!pf) { delete h; return nullptr; }
+    char line[256]; long npts = 0;
+    while (fgets(line, sizeof line, pf)) {
+      if (!strncmp(line, "POINTS", 6)) npts = atol(line + 7);
+      if (!strncmp(line, "DATA", 4)) break;
+    }
+    std::vector<float> rec((size_t)npts * 8);
+    size_t got = fread(rec.data(), 32, (size_t)npts, pf);
+    fclose(pf);
+    pl->reserve(got);
+    for (size_t k = 0; k < got; k++) { PointType ap; ap.x = rec[8 * k]; ap.y = rec[8 * k + 1]; ap.z = rec[8 * k + 2]; ap.intensity = rec[8 * k + 3]; pl->push_back(ap); }
+    h->n_points += (long)got;
+    pl_fulls.push_back(pl);
+  }
+  // benchmark_realworld.cpp:163-170
+  IMUST es0 = h->x_buf[0];
+  for (uint i = 0; i < h->x_buf.size(); i++) {
+    h->x_buf[i].p = es0.R.transpose() * (h->x_buf[i].p - es0.p);
+    h->x_buf[i].R = es0.R.transpose() * h->x_buf[i].R;
+  }
+  win_size = h->x_buf.size();
+  voxel_size = vsize;
+  // :183-200
+  eigen_value_array[0] = 1.0 / 16; eigen_value_array[1] = 1.0 / 16; eigen_value_array[2] = 1.0 / 9;
+  for (int i = 0; i < win_size; i++) cut_voxel(h->surf_map, *pl_fulls[i], h->x_buf[i], i);
+  for (auto iter = h->surf_map.begin(); iter != h->surf_map.end(); iter++) {
+    iter->second->recut(win_size);
+    iter->second->tras_opt(h->voxhess, win_size);
+  }
+  return h;
+}
+
+void ref_rw_dims(void *hh, int *W, int *F, long *n_points) {
+  RwHandle *h = (RwHandle *)hh;
+  *W = (int)h->x_buf.size(); *F = (int)h->voxhess.plvec_voxels.size(); *n_points = h->n_points;
+}
+
+void ref_rw_export(void *hh, double *clusters, double *fix, double *coeffs, double *poses) {
+  RwHandle *h = (RwHandle *)hh;
+  const int W = (int)h->x_buf.size();
+  const size_t F = h->voxhess.plvec_voxels.size();
+  auto put = [](const PointCluster &c, double *q) {
+    q[0] = c.P(0, 0); q[1] = c.P(0, 1); q[2] = c.P(0, 2); q[3] = c.P(1, 1); q[4] = c.P(1, 2); q[5] = c.P(2, 2);
+    q[6] = c.v[0]; q[7] = c.v[1]; q[8] = c.v[2]; q[9] = c.N;
+  };
+  for (size_t a = 0; a < F; a++) {
+    for (int i = 0; i < W; i++) put((*h->voxhess.plvec_voxels[a])[i], clusters + (a * W + i) * 10);
+    put(*h->voxhess.sig_vecs[a], fix + a * 10);
+    coeffs[a] = h->voxhess.coeffs[a];
+  }
+  store_poses(h->x_buf, poses);
+}
+
+void ref_rw_close(void *hh) { delete (RwHandle *)hh; }
 
 void ref_exp(const double *w, double *R9) {
   Eigen::Matrix3d R = Exp(Eigen::Vector3d(w[0], w[1], w[2]));

@@ -87,3 +87,17 @@ def test_push_voxel_weight_and_filter():
         assert kept == (nobs >= 2)                                  # bavoxel.hpp:32-37
         if kept:
             assert coe == sc.clusters[a, :, 9].sum() == sc.coeffs[a]   # :42-44 (scene.sparsify mirrors it)
+
+
+def test_oracle_matches_reference_on_realworld_window():
+    """the shipped real-world window (if the fixture was built): oracle vs the reference's optimizer"""
+    from conftest import ROOT
+    path = os.path.join(ROOT, "oracle", "_ref", "realworld_features.npz")
+    if not os.path.exists(path):
+        pytest.skip("oracle/_ref/realworld_features.npz not built")
+    g = dict(np.load(path))
+    out, lg = orc.damping_iter(0, g["clusters"], None, g["coeffs"], g["poses"], 0.01, 10, threads=8)
+    assert len(lg) == len(g["ref_log"])
+    assert np.allclose(lg[:, :2], g["ref_log"][:, :2], rtol=1e-9, atol=2e-6)
+    rot, tr = pose_errors(out, g["ref_poses"])
+    assert rot.max() < 1e-9 and tr.max() < 1e-9

@@ -318,3 +318,30 @@ def test_allreduce_hook_over_rccl_single_rank():
         c.set_allreduce(None)
         dist.destroy_process_group()
     c.close()
+
+
+def test_realworld_window_matches_reference_optimizer():
+    """BASELINE configs[4] input: the shipped benchmark_realworld data (W=177 scans, 13.4 M points)
+    associated by the reference's own cut_voxel/recut/tras_opt (tools/make_realworld_fixture.py ->
+    oracle/_ref/realworld_features.npz: 2281 plane features, 15 % block fill).  The HIP LM loop must
+    land on the poses of the reference's BALM2::damping_iter."""
+    import time
+    from conftest import ROOT
+    path = _os.path.join(ROOT, "oracle", "_ref", "realworld_features.npz")
+    if not _os.path.exists(path):
+        pytest.skip("oracle/_ref/realworld_features.npz not built (needs /root/reference/datas)")
+    g = dict(np.load(path))
+    cl, co, P = g["clusters"], g["coeffs"], g["poses"]
+    c = capi.Context(cl.shape[1])
+    c.set_features(cl, None, co)
+    out, lg = c.damping_iter(P, form=0, u0=0.01, max_iter=10, min_planes=20)     # warm (allocations)
+    t0 = time.perf_counter()
+    out, lg = c.damping_iter(P, form=0, u0=0.01, max_iter=10, min_planes=20)
+    dt = time.perf_counter() - t0
+    assert len(lg) == len(g["ref_log"])
+    assert np.allclose(lg[:, :2], g["ref_log"][:, :2], rtol=1e-9, atol=2e-6)
+    rot, tr = pose_errors(out, g["ref_poses"])
+    print("real-world window: %d LM iterations in %.2f ms on the GPU (reference CPU: %.2f s); max pose diff %.2e rad %.2e m"
+          % (len(lg), dt * 1e3, float(g["ref_seconds_lm"]), rot.max(), tr.max()))
+    assert rot.max() <= ROT_TOL_RAD and tr.max() <= TRANS_TOL_M
+    c.close()
