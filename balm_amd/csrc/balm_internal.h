@@ -99,7 +99,7 @@ int launch_feature_eigen(hipStream_t s, const double *C, const double *fix, cons
 int factors_grid(int W, int nfeat, int form);
 void launch_factors(hipStream_t s, int form, const double *cl, const double *poses, const double *feat, int W,
                     int npad, int f0, int f1, double *Gt, double *dpart, int nblk);
-struct SyrkPlan { int SG; int units_per_slice; int Kpad; long nblocks; };
+struct SyrkPlan { int SG; int nsteps; int Kpad; long nblocks; };   // k-slices, MFMA k-steps per wave, padded K, workgroups
 SyrkPlan plan_syrk(int ntiles, long K);
 void launch_syrk(hipStream_t s, const double *Gt, int npad, int ntiles, const int *tileIJ, const SyrkPlan &p,
                  double *part);

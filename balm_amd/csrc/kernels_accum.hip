@@ -652,7 +652,7 @@ SyrkPlan plan_syrk(int ntiles, long K) {
   long nst = (steps + sg - 1) / sg;
   nst = (nst + SYRK_NBUF - 1) / SYRK_NBUF * SYRK_NBUF;      // whole turns of the prefetch ring
   p.SG = (int)sg;
-  p.units_per_slice = (int)nst;                     // k-steps per wave
+  p.nsteps = (int)nst;                     // k-steps per wave
   p.Kpad = (int)(sg * nst * 4);
   p.nblocks = sg * ntiles;
   return p;
@@ -661,7 +661,7 @@ SyrkPlan plan_syrk(int ntiles, long K) {
 void launch_syrk(hipStream_t s, const double *Gt, int npad, int ntiles, const int *tileIJ, const SyrkPlan &p,
                  double *part) {
   hipLaunchKernelGGL(k_hessian_syrk, dim3((unsigned)p.nblocks), dim3(64), 0, s, Gt, npad, ntiles, tileIJ,
-                     p.units_per_slice, p.nblocks, part);
+                     p.nsteps, p.nblocks, part);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -345,3 +345,52 @@ def test_realworld_window_matches_reference_optimizer():
           % (len(lg), dt * 1e3, float(g["ref_seconds_lm"]), rot.max(), tr.max()))
     assert rot.max() <= ROT_TOL_RAD and tr.max() <= TRANS_TOL_M
     c.close()
+
+
+def _two_rank_worker(rank, world, port, seed, W, F, pts, drop, q):
+    import torch.distributed as dist
+    from balm_amd import dist as bdist
+    _os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                       MASTER_PORT=str(port))
+    bdist.init_process_group("gloo")          # two ranks share the one GPU of the box: RCCL refuses that, gloo does not
+    sc, _ = make_scene(seed, W, F, pts, drop)
+    nobs = (sc.clusters[..., 9] > 0).sum(1)
+    lo, hi = bdist.partition_features(nobs, world)[rank]
+    c = capi.Context(W, 0)
+    c.set_features(sc.clusters[lo:hi], None, sc.coeffs[lo:hi])
+    hook = bdist.install_allreduce(c)
+    H, g, r = c.evaluate(0, sc.poses_init)
+    out, lg = c.damping_iter(sc.poses_init, u0=0.01, max_iter=10)
+    if rank == 0:
+        q.put((H, g, r, out, lg, hook.zero_copy))
+    dist.barrier()
+    c.close()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_sharded_on_one_gpu():
+    """the N>1 path end to end on the GPU: two processes, each with its own feature shard and context,
+    summing the device payload through the balm_set_allreduce hook; results must equal the
+    single-process run (feature sums are order-insensitive to ~1e-13)."""
+    import socket
+    import torch.multiprocessing as mp
+    seed, W, F, pts, drop = 81, 24, 120, 6, 0.25
+    sc, _ = make_scene(seed, W, F, pts, drop)
+    c = ctx_for(sc)
+    H1, g1, r1 = c.evaluate(0, sc.poses_init)
+    out1, lg1 = c.damping_iter(sc.poses_init, u0=0.01, max_iter=10)
+    c.close()
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_two_rank_worker, args=(r, 2, port, seed, W, F, pts, drop, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    H2, g2, r2, out2, lg2, zc = q.get(timeout=600)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert rel_err(H2, H1) < 1e-12 and rel_err(g2, g1) < 1e-12 and abs(r2 - r1) / r1 < 1e-13
+    assert len(lg2) == len(lg1) and np.allclose(lg2[:, :3], lg1[:, :3], rtol=1e-9)
+    rot, tr = pose_errors(out2, out1)
+    assert rot.max() < 1e-9 and tr.max() < 1e-9
