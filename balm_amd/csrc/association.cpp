@@ -1,0 +1,321 @@
+// Host side of the path's caller ("next" row N2 of SURVEY.md 8f): ROS/PCL-free input pipeline of
+// the reference's real-world driver -- pose CSV + binary PCD readers and the adaptive-voxel point
+// association that produces the plane features the optimizer consumes.  CPU C++ by design (SURVEY 8:
+// the association stays on the host and calls the GPU path through the C ABI); no GPU code here.
+//
+// Restates (same decisions, same float/double types where they decide voxel membership):
+//   src/benchmark/benchmark_realworld.cpp:31-106  read_pose / read_file (formats of the shipped data)
+//   src/benchmark/bavoxel.hpp:1170-1223           cut_voxel      (world point -> root voxel key)
+//   src/benchmark/bavoxel.hpp:654-699             judge_eigen    (lambda0/lambda1 < threshold[layer])
+//   src/benchmark/bavoxel.hpp:701-776             cut_func / recut (<= 2 subdivisions into octants)
+//   src/benchmark/bavoxel.hpp:908-929, 30-51      tras_opt / VOX_HESS::push_voxel (filters, weight = sum N)
+// Sliding-window marginalisation (to_margi, :778-816) is not used by benchmark_realworld and is not
+// restated: fix clusters are empty.
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+namespace {
+
+struct V3 { double x, y, z; };
+
+struct Cluster {                      // include/tools.hpp:290-349
+  double P[6] = {0, 0, 0, 0, 0, 0};  // xx xy xz yy yz zz
+  double v[3] = {0, 0, 0};
+  int N = 0;
+  void push(const V3 &p) {
+    N++;
+    P[0] += p.x * p.x; P[1] += p.x * p.y; P[2] += p.x * p.z; P[3] += p.y * p.y; P[4] += p.y * p.z; P[5] += p.z * p.z;
+    v[0] += p.x; v[1] += p.y; v[2] += p.z;
+  }
+  void add(const Cluster &o) {
+    for (int k = 0; k < 6; k++) P[k] += o.P[k];
+    for (int k = 0; k < 3; k++) v[k] += o.v[k];
+    N += o.N;
+  }
+};
+
+// eigenvalues of the 3x3 covariance, ascending (cyclic Jacobi; stands in for SelfAdjointEigenSolver)
+void eigvals3(double a00, double a01, double a02, double a11, double a12, double a22, double lam[3]) {
+  for (int sweep = 0; sweep < 60; sweep++) {
+    const double off = a01 * a01 + a02 * a02 + a12 * a12, dia = a00 * a00 + a11 * a11 + a22 * a22;
+    if (off <= 1e-300 || off <= 1e-34 * dia) break;
+    auto rot = [](double &app, double &aqq, double &apq, double &arp, double &arq) {
+      if (apq == 0.0) return;
+      const double theta = (aqq - app) / (2.0 * apq);
+      const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+      const double c = 1.0 / std::sqrt(t * t + 1.0), s = t * c;
+      app -= t * apq; aqq += t * apq; apq = 0.0;
+      const double rp = c * arp - s * arq, rq = s * arp + c * arq;
+      arp = rp; arq = rq;
+    };
+    rot(a00, a11, a01, a02, a12);
+    rot(a00, a22, a02, a01, a12);
+    rot(a11, a22, a12, a01, a02);
+  }
+  lam[0] = a00; lam[1] = a11; lam[2] = a22;
+  std::sort(lam, lam + 3);
+}
+
+struct Params {
+  int win = 0;
+  double voxel_size = 1.0;
+  float eigen_thr[4] = {1.0f / 16, 1.0f / 16, 1.0f / 16, 1.0f / 16};   // bavoxel.hpp:11 (floats)
+  int layer_limit = 2, min_ps = 15;
+  int layer_size[4] = {30, 30, 30, 30};
+};
+
+struct Node {                         // OCTO_TREE_NODE, bavoxel.hpp:626-931
+  int octo_state = 0, push_state = 0, layer = 0;
+  std::vector<std::vector<V3>> vec_orig, vec_tran;
+  std::vector<Cluster> sig_orig, sig_tran;
+  Node *leaves[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  float voxel_center[3] = {0, 0, 0};
+  float quater_length = 0;
+  double decision = 0;
+  explicit Node(int win) : vec_orig(win), vec_tran(win), sig_orig(win), sig_tran(win) {}
+  ~Node() { for (Node *l : leaves) delete l; }
+
+  bool judge_eigen(const Params &pr, int win_count) {        // :654-699 (fix cluster empty)
+    Cluster c;
+    for (int i = 0; i < win_count; i++) c.add(sig_tran[i]);
+    const double n = c.N, cx = c.v[0] / n, cy = c.v[1] / n, cz = c.v[2] / n;
+    double lam[3];
+    eigvals3(c.P[0] / n - cx * cx, c.P[1] / n - cx * cy, c.P[2] / n - cx * cz, c.P[3] / n - cy * cy,
+             c.P[4] / n - cy * cz, c.P[5] / n - cz * cz, lam);
+    decision = lam[0] / lam[1];
+    return decision < pr.eigen_thr[layer];
+  }
+
+  void cut_func(const Params &pr, int ci) {                   // :701-735
+    std::vector<V3> &po = vec_orig[ci], &pt = vec_tran[ci];
+    for (size_t j = 0; j < pt.size(); j++) {
+      const double q[3] = {pt[j].x, pt[j].y, pt[j].z};
+      int xyz[3] = {0, 0, 0};
+      for (int k = 0; k < 3; k++) if (q[k] > voxel_center[k]) xyz[k] = 1;
+      const int leafnum = 4 * xyz[0] + 2 * xyz[1] + xyz[2];
+      if (!leaves[leafnum]) {
+        Node *l = leaves[leafnum] = new Node(pr.win);
+        for (int k = 0; k < 3; k++) l->voxel_center[k] = voxel_center[k] + (2 * xyz[k] - 1) * quater_length;
+        l->quater_length = quater_length / 2;
+        l->layer = layer + 1;
+      }
+      Node *l = leaves[leafnum];
+      l->vec_orig[ci].push_back(po[j]);
+      l->vec_tran[ci].push_back(pt[j]);
+      if (l->octo_state != 1) { l->sig_orig[ci].push(po[j]); l->sig_tran[ci].push(pt[j]); }
+    }
+    std::vector<V3>().swap(po);
+    std::vector<V3>().swap(pt);
+  }
+
+  void recut(const Params &pr, int win_count) {               // :737-776
+    if (octo_state != 1) {
+      int point_size = 0;
+      for (int i = 0; i < win_count; i++) point_size += sig_orig[i].N;
+      push_state = 0;
+      if (point_size <= pr.min_ps) return;
+      if (judge_eigen(pr, win_count)) {
+        if (octo_state == 0 && point_size > pr.layer_size[layer]) octo_state = 2;
+        if (point_size > pr.min_ps) push_state = 1;
+        return;
+      } else if (layer == pr.layer_limit) {
+        octo_state = 2;
+        return;
+      }
+      octo_state = 1;
+      std::vector<Cluster>().swap(sig_orig);
+      std::vector<Cluster>().swap(sig_tran);
+      for (int i = 0; i < win_count; i++) cut_func(pr, i);
+    } else {
+      cut_func(pr, win_count - 1);
+    }
+    for (Node *l : leaves) if (l) l->recut(pr, win_count);
+  }
+
+  // tras_opt (:908-929) + VOX_HESS::push_voxel (:30-51)
+  void collect(const Params &pr, int win_count, std::vector<const Node *> &out) const {
+    if (octo_state != 1) {
+      int points_size = 0;
+      for (int i = 0; i < win_count; i++) points_size += sig_orig[i].N;
+      if (points_size < pr.min_ps) return;
+      if (push_state != 1) return;
+      int process_size = 0;
+      for (int i = 0; i < pr.win; i++) if (sig_orig[i].N != 0) process_size++;
+      if (process_size < 2) return;
+      out.push_back(this);
+    } else {
+      for (const Node *l : leaves) if (l) l->collect(pr, win_count, out);
+    }
+  }
+};
+
+struct Key {
+  int64_t x, y, z;
+  bool operator==(const Key &o) const { return x == o.x && y == o.y && z == o.z; }
+};
+struct KeyHash {
+  size_t operator()(const Key &k) const {
+    return (size_t)(((uint64_t)k.z * 116101ull + (uint64_t)k.y) * 116101ull + (uint64_t)k.x);
+  }
+};
+
+struct Assoc {
+  Params pr;
+  std::unordered_map<Key, Node *, KeyHash> map;
+  std::vector<const Node *> feats;
+  long n_points = 0;
+  ~Assoc() { for (auto &kv : map) delete kv.second; }
+};
+
+}  // namespace
+
+extern "C" {
+
+void *balm_assoc_create(int win_size, double voxel_size, const float *eigen_thresholds3, int layer_limit, int min_ps) {
+  Assoc *a = new Assoc();
+  a->pr.win = win_size;
+  a->pr.voxel_size = voxel_size;
+  if (eigen_thresholds3) for (int k = 0; k < 3; k++) a->pr.eigen_thr[k] = eigen_thresholds3[k];
+  a->pr.layer_limit = layer_limit;
+  a->pr.min_ps = min_ps;
+  return a;
+}
+
+void balm_assoc_destroy(void *h) { delete (Assoc *)h; }
+
+// cut_voxel (bavoxel.hpp:1170-1223): xyz = n body-frame points (float x,y,z), pose = 12 doubles.
+int balm_assoc_add_frame(void *h, int frame, const float *xyz, long n, const double *pose) {
+  Assoc *a = (Assoc *)h;
+  if (frame < 0 || frame >= a->pr.win) return 1;
+  const double *R = pose, *t = pose + 9;    // R column-major
+  for (long k = 0; k < n; k++) {
+    const V3 po{(double)xyz[3 * k], (double)xyz[3 * k + 1], (double)xyz[3 * k + 2]};
+    const V3 pt{R[0] * po.x + R[3] * po.y + R[6] * po.z + t[0], R[1] * po.x + R[4] * po.y + R[7] * po.z + t[1],
+                R[2] * po.x + R[5] * po.y + R[8] * po.z + t[2]};
+    const double q[3] = {pt.x, pt.y, pt.z};
+    float loc[3];
+    for (int j = 0; j < 3; j++) {
+      loc[j] = q[j] / a->pr.voxel_size;
+      if (loc[j] < 0) loc[j] -= 1.0;
+    }
+    const Key key{(int64_t)loc[0], (int64_t)loc[1], (int64_t)loc[2]};
+    auto it = a->map.find(key);
+    Node *nd;
+    if (it != a->map.end()) {
+      nd = it->second;
+      if (nd->octo_state != 2) { nd->vec_orig[frame].push_back(po); nd->vec_tran[frame].push_back(pt); }
+      if (nd->octo_state != 1) { nd->sig_orig[frame].push(po); nd->sig_tran[frame].push(pt); }
+    } else {
+      nd = new Node(a->pr.win);
+      nd->vec_orig[frame].push_back(po); nd->vec_tran[frame].push_back(pt);
+      nd->sig_orig[frame].push(po); nd->sig_tran[frame].push(pt);
+      nd->voxel_center[0] = (0.5 + key.x) * a->pr.voxel_size;
+      nd->voxel_center[1] = (0.5 + key.y) * a->pr.voxel_size;
+      nd->voxel_center[2] = (0.5 + key.z) * a->pr.voxel_size;
+      nd->quater_length = a->pr.voxel_size / 4.0;
+      nd->layer = 0;
+      a->map[key] = nd;
+    }
+  }
+  a->n_points += n;
+  return 0;
+}
+
+// recut + tras_opt over every root voxel (benchmark_realworld.cpp:195-200).  Returns the number of features.
+int balm_assoc_finish(void *h) {
+  Assoc *a = (Assoc *)h;
+  a->feats.clear();
+  for (auto &kv : a->map) {
+    kv.second->recut(a->pr, a->pr.win);
+    kv.second->collect(a->pr, a->pr.win, a->feats);
+  }
+  return (int)a->feats.size();
+}
+
+// clusters F*W*10 (layout of include/balm_hip.h), coeffs F (= sum_i N_i, bavoxel.hpp:42-44), layer F (optional)
+void balm_assoc_export(void *h, double *clusters, double *coeffs, int *layer) {
+  Assoc *a = (Assoc *)h;
+  const int W = a->pr.win;
+  for (size_t f = 0; f < a->feats.size(); f++) {
+    const Node *nd = a->feats[f];
+    double coe = 0;
+    for (int i = 0; i < W; i++) {
+      const Cluster &c = nd->sig_orig[i];
+      double *q = clusters + (f * W + i) * 10;
+      for (int k = 0; k < 6; k++) q[k] = c.P[k];
+      for (int k = 0; k < 3; k++) q[6 + k] = c.v[k];
+      q[9] = c.N;
+      coe += c.N;
+    }
+    coeffs[f] = coe;
+    if (layer) layer[f] = nd->layer;
+  }
+}
+
+// alidarPose.csv (benchmark_realworld.cpp:31-73): 4 text lines per pose, rows of [R|t], element (3,3) is the
+// timestamp.  poses: up to max_poses * 12 doubles (R column-major, p); stamps optional.  Returns #poses, <0 on error.
+int balm_read_pose_csv(const char *path, int max_poses, double *poses, double *stamps) {
+  FILE *f = fopen(path, "r");
+  if (!f) return -1;
+  std::vector<double> nums;
+  double v;
+  int ch;
+  while (fscanf(f, "%lf", &v) == 1) {
+    nums.push_back(v);
+    do { ch = fgetc(f); } while (ch == ',' || ch == ' ' || ch == '\r' || ch == '\n');
+    if (ch != EOF) ungetc(ch, f);
+  }
+  fclose(f);
+  int W = (int)(nums.size() / 16);
+  if (W > max_poses) W = max_poses;
+  for (int m = 0; m < W; m++) {
+    double *q = poses + 12 * m;
+    for (int r = 0; r < 3; r++) {
+      for (int c = 0; c < 3; c++) q[3 * c + r] = nums[16 * m + 4 * r + c];
+      q[9 + r] = nums[16 * m + 4 * r + 3];
+    }
+    if (stamps) stamps[m] = nums[16 * m + 15];
+  }
+  return W;
+}
+
+// binary PCD with FIELDS x y z ... (all 4-byte floats; the shipped files have 8 fields = 32-byte records).
+// Pass xyz = NULL to query the point count.  Returns #points written, <0 on error.
+long balm_read_pcd_xyz(const char *path, float *xyz, long max_points) {
+  FILE *f = fopen(path, "rb");
+  if (!f) return -1;
+  char line[512];
+  long npts = -1;
+  int nfields = 0;
+  bool binary = false;
+  while (fgets(line, sizeof line, f)) {
+    if (!strncmp(line, "FIELDS", 6)) { for (char *p = line + 6; *p; p++) if (*p == ' ' && p[1] != ' ' && p[1] != '\n') nfields++; }
+    if (!strncmp(line, "POINTS", 6)) npts = atol(line + 7);
+    if (!strncmp(line, "DATA", 4)) { binary = !strncmp(line + 5, "binary", 6) && strncmp(line + 5, "binary_compressed", 17); break; }
+  }
+  if (npts < 0 || nfields < 3 || !binary) { fclose(f); return -2; }
+  if (!xyz) { fclose(f); return npts; }
+  if (npts > max_points) npts = max_points;
+  std::vector<float> rec((size_t)nfields * 4096);
+  long done = 0;
+  while (done < npts) {
+    const long want = std::min<long>(4096, npts - done);
+    const size_t got = fread(rec.data(), sizeof(float) * nfields, (size_t)want, f);
+    for (size_t k = 0; k < got; k++) {
+      xyz[3 * (done + k)] = rec[k * nfields]; xyz[3 * (done + k) + 1] = rec[k * nfields + 1]; xyz[3 * (done + k) + 2] = rec[k * nfields + 2];
+    }
+    done += (long)got;
+    if ((long)got < want) break;
+  }
+  fclose(f);
+  return done;
+}
+
+}  // extern "C"

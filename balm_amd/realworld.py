@@ -1,0 +1,126 @@
+"""ROS/PCL-free real-world pipeline: what the reference's benchmark_realworld driver
+does around the optimizer (src/benchmark/benchmark_realworld.cpp:144-218) -- read alidarPose.csv and the
+binary PCD scans, express poses relative to pose 0, associate points to plane features by adaptive
+voxelisation (csrc/association.cpp restating bavoxel.hpp's cut_voxel / recut / tras_opt) -- feeding the
+GPU path through the C ABI.  The association is host C++ by design; only the optimizer is on the GPU.
+
+    python -m balm_amd.realworld /path/to/datas/benchmark_realworld [--voxel 2.0]
+"""
+import ctypes as C
+import os
+import sys
+import time
+
+import numpy as np
+
+from . import scene
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _lib():
+    L = scene.host_lib()
+    L.balm_assoc_create.restype = C.c_void_p
+    L.balm_read_pcd_xyz.restype = C.c_long
+    return L
+
+
+def read_pose_csv(path, max_poses=100000):
+    buf = np.zeros((max_poses, 12))
+    stamps = np.zeros(max_poses)
+    n = _lib().balm_read_pose_csv(path.encode(), max_poses, _p(buf), _p(stamps))
+    if n < 0:
+        raise FileNotFoundError(path)
+    return buf[:n].copy(), stamps[:n].copy()
+
+
+def read_pcd_xyz(path):
+    L = _lib()
+    n = L.balm_read_pcd_xyz(path.encode(), None, C.c_long(0))
+    if n < 0:
+        raise IOError("cannot read binary PCD %s (%d)" % (path, n))
+    xyz = np.zeros((n, 3), dtype=np.float32)
+    got = L.balm_read_pcd_xyz(path.encode(), _p(xyz), C.c_long(n))
+    return xyz[:got]
+
+
+def relative_to_first(poses):
+    """benchmark_realworld.cpp:163-168: p_i <- R_0^T (p_i - p_0), R_i <- R_0^T R_i"""
+    R = poses[:, :9].reshape(-1, 3, 3).transpose(0, 2, 1)
+    p = poses[:, 9:]
+    Rn = np.einsum("ji,njk->nik", R[0], R)
+    pn = (p - p[0]) @ R[0]
+    out = np.zeros_like(poses)
+    out[:, :9] = Rn.transpose(0, 2, 1).reshape(-1, 9)
+    out[:, 9:] = pn
+    return out
+
+
+def associate(frames_xyz, poses, voxel_size=2.0, eigen_thresholds=(1.0 / 16, 1.0 / 16, 1.0 / 9), layer_limit=2,
+              min_ps=15):
+    """frames_xyz: list of [n_i,3] float32 body-frame scans; poses [W,12].  Returns (clusters [F,W,10],
+    coeffs [F], layer [F]).  Defaults = benchmark_realworld.cpp:183-185 + launch/benchmark_realworld.launch:4."""
+    L = _lib()
+    W = len(frames_xyz)
+    thr = np.asarray(eigen_thresholds, dtype=np.float32)
+    h = C.c_void_p(L.balm_assoc_create(W, C.c_double(voxel_size), _p(thr), layer_limit, min_ps))
+    try:
+        poses = np.ascontiguousarray(poses, dtype=np.float64)
+        for i, xyz in enumerate(frames_xyz):
+            xyz = np.ascontiguousarray(xyz, dtype=np.float32)
+            rc = L.balm_assoc_add_frame(h, i, _p(xyz), C.c_long(xyz.shape[0]), _p(poses[i]))
+            assert rc == 0
+        F = L.balm_assoc_finish(h)
+        cl = np.zeros((F, W, 10))
+        co = np.zeros(F)
+        layer = np.zeros(F, dtype=np.int32)
+        L.balm_assoc_export(h, _p(cl), _p(co), _p(layer))
+    finally:
+        L.balm_assoc_destroy(h)
+    return cl, co, layer
+
+
+def load_window(data_dir, max_poses=None):
+    poses, stamps = read_pose_csv(os.path.join(data_dir, "alidarPose.csv"))
+    if max_poses:
+        poses = poses[:max_poses]
+    frames = [read_pcd_xyz(os.path.join(data_dir, "full%d.pcd" % m)) for m in range(poses.shape[0])]
+    return relative_to_first(poses), frames
+
+
+def main(argv=None):
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("data_dir")
+    ap.add_argument("--voxel", type=float, default=2.0)
+    ap.add_argument("--device", type=int, default=0)
+    ap.add_argument("--out", default=None, help="write optimised poses (W x 12) here as .npy")
+    a = ap.parse_args(argv)
+    from . import capi
+    t = time.time()
+    poses, frames = load_window(a.data_dir)
+    t_read = time.time() - t
+    t = time.time()
+    cl, co, _ = associate(frames, poses, a.voxel)
+    t_assoc = time.time() - t
+    W, F = poses.shape[0], cl.shape[0]
+    print("The size of poses: %d" % W)                                   # benchmark_realworld.cpp:171
+    print("read %d points in %.1f s; %d plane features in %.1f s" % (sum(f.shape[0] for f in frames), t_read, F, t_assoc))
+    if F < 3 * W:                                                        # :209-215
+        print("Initial error too large.\nPlease loose plane determination criteria for more planes.\n"
+              "The optimization is terminated.")
+        return 1
+    ctx = capi.Context(W, a.device)
+    ctx.set_features(cl, None, co)
+    t = time.time()
+    out, lg = ctx.damping_iter(poses, form=capi.FORM_LEFT, u0=0.01, max_iter=10, min_planes=20, verbose=True)
+    print("optimised in %d LM iterations, %.2f ms" % (len(lg), (time.time() - t) * 1e3))
+    if a.out:
+        np.save(a.out, out)
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -1,6 +1,7 @@
 """Synthetic plane-cloud scenes: the ROS-free restatement of the reference's benchmark_virtual
 generator (csrc/virtual_scene.cpp; /root/reference/src/benchmark/benchmark_virtual.cpp:547-606,
-:486-503).  Host-only input generation; nothing here is on the GPU hot path.
+:486-503).  Host-only input generation; nothing here is on the GPU hot path.  The same host library
+(libbalm_scene.so) carries the real-world input pipeline (csrc/association.cpp, see realworld.py).
 """
 import ctypes as C
 import os
@@ -11,15 +12,19 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "lib", "libbalm_scene.so")
-_SRC = os.path.join(_HERE, "csrc", "virtual_scene.cpp")
+_SRCS = [os.path.join(_HERE, "csrc", "virtual_scene.cpp"), os.path.join(_HERE, "csrc", "association.cpp")]
 _LIB = None
 
 
 def build(force=False):
     os.makedirs(os.path.dirname(_SO), exist_ok=True)
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SRC) > os.path.getmtime(_SO):
-        subprocess.check_call(["g++", "-std=c++14", "-O3", "-fPIC", "-pthread", "-shared", "-o", _SO, _SRC])
+    if force or not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in _SRCS):
+        subprocess.check_call(["g++", "-std=c++14", "-O3", "-fPIC", "-pthread", "-shared", "-o", _SO] + _SRCS)
     return _SO
+
+
+def host_lib():
+    return _lib()
 
 
 def _lib():

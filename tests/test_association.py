@@ -1,0 +1,105 @@
+"""N2: the product's ROS-free real-world input pipeline -- pose CSV / binary PCD readers
+and the adaptive-voxel association (balm_amd/csrc/association.cpp) -- against the reference's own
+cut_voxel / recut / tras_opt compiled in oracle/_ref.  Integer/index work: bit-exact (as feature sets;
+the reference's feature ORDER is its unordered_map's iteration order)."""
+import os
+
+import numpy as np
+import pytest
+
+from balm_amd import realworld as rw
+from balm_amd import scene
+from oracle import numpy_oracle as npo
+from oracle import ref
+
+needs_ref = pytest.mark.skipif(not ref.available(), reason="oracle/_ref not built (needs /root/reference)")
+
+
+def canon(cl):
+    """order-free canonical form of a feature set [F,W,10]"""
+    flat = cl.reshape(cl.shape[0], -1)
+    return cl[np.lexsort(flat[:, ::-1].T)]
+
+
+def write_window(tmp, poses, frames):
+    """the shipped formats: alidarPose.csv = 4 lines per pose, rows of [R|t] with a trailing comma, element
+    (3,3) = timestamp; full<m>.pcd = 11 header lines + 32-byte records x y z intensity nx ny nz curvature"""
+    R, p = npo.pose_R(poses), npo.pose_p(poses)
+    with open(os.path.join(tmp, "alidarPose.csv"), "w") as f:
+        for m in range(poses.shape[0]):
+            for r in range(3):
+                f.write("%.9f,%.9f,%.9f,%.9f,\n" % (R[m, r, 0], R[m, r, 1], R[m, r, 2], p[m, r]))
+            f.write("0.000000,0.000000,0.000000,%.6f,\n" % (1630577758.5 + 0.5 * m))
+    for m, xyz in enumerate(frames):
+        n = xyz.shape[0]
+        rec = np.zeros((n, 8), dtype=np.float32)
+        rec[:, :3] = xyz
+        rec[:, 3] = m
+        hdr = ("# .PCD v0.7 - Point Cloud Data file format\nVERSION 0.7\nFIELDS x y z intensity normal_x normal_y "
+               "normal_z curvature\nSIZE 4 4 4 4 4 4 4 4\nTYPE F F F F F F F F\nCOUNT 1 1 1 1 1 1 1 1\nWIDTH %d\n"
+               "HEIGHT 1\nVIEWPOINT 0 0 0 1 0 0 0\nPOINTS %d\nDATA binary\n" % (n, n))
+        with open(os.path.join(tmp, "full%d.pcd" % m), "wb") as f:
+            f.write(hdr.encode())
+            f.write(rec.tobytes())
+
+
+def synthetic_window(seed, W, F, pts):
+    sc = scene.generate(seed, W, F, pts, surf_range=15.0, keep_points=True)
+    # odometry-grade start: a fifth of the generator's pose noise
+    R0, Ri = npo.pose_R(sc.poses_gt), npo.pose_R(sc.poses_init)
+    p0, pi = npo.pose_p(sc.poses_gt), npo.pose_p(sc.poses_init)
+    R = np.stack([R0[i] @ npo.exp_so3(0.2 * _log(R0[i].T @ Ri[i])) for i in range(W)])
+    poses = npo.make_poses(R, p0 + 0.2 * (pi - p0))
+    frames = [sc.points[:, i].reshape(-1, 3).copy() for i in range(W)]
+    return poses, frames
+
+
+def _log(R):
+    c = np.clip((np.trace(R) - 1) / 2, -1, 1)
+    th = np.arccos(c)
+    k = np.array([R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1]])
+    return 0.5 * k if th < 1e-3 else 0.5 * th / np.sin(th) * k
+
+
+def test_readers_roundtrip(tmp_path):
+    poses, frames = synthetic_window(3, 6, 20, 30)
+    write_window(str(tmp_path), poses, frames)
+    got_poses, stamps = rw.read_pose_csv(str(tmp_path / "alidarPose.csv"))
+    assert got_poses.shape == (6, 12) and np.allclose(got_poses, poses, atol=1e-8)
+    assert np.allclose(np.diff(stamps), 0.5)
+    for m in range(6):
+        assert np.array_equal(rw.read_pcd_xyz(str(tmp_path / ("full%d.pcd" % m))), frames[m])
+    rel = rw.relative_to_first(got_poses)
+    assert np.allclose(npo.pose_R(rel)[0], np.eye(3), atol=1e-8) and np.allclose(npo.pose_p(rel)[0], 0)
+
+
+@needs_ref
+@pytest.mark.parametrize("seed,W,F,pts,voxel", [(1, 12, 80, 40, 1.0), (2, 20, 150, 30, 2.0), (5, 8, 40, 60, 0.5)])
+def test_association_matches_reference_on_synthetic_scans(tmp_path, seed, W, F, pts, voxel):
+    poses, frames = synthetic_window(seed, W, F, pts)
+    write_window(str(tmp_path), poses, frames)
+    cl_r, fx_r, co_r, poses_r, npts = ref.realworld_features(str(tmp_path), voxel)
+    poses_p, frames_p = rw.load_window(str(tmp_path))
+    assert npts == sum(f.shape[0] for f in frames_p)
+    assert np.abs(poses_p - poses_r).max() < 1e-14
+    cl_p, co_p, layer = rw.associate(frames_p, poses_r, voxel)      # same poses bit for bit -> same voxel keys
+    assert cl_p.shape == cl_r.shape and cl_p.shape[0] > 0
+    assert np.array_equal(canon(cl_p), canon(cl_r))                 # bit-exact feature set
+    assert np.array_equal(np.sort(co_p), np.sort(co_r))
+    assert not (fx_r[:, 9] > 0).any()
+
+
+def test_association_matches_reference_on_shipped_data():
+    """the shipped benchmark_realworld window (177 scans) against the fixture made by the reference's code"""
+    from conftest import ROOT
+    data = os.environ.get("BALM_REFERENCE_ROOT", "/root/reference") + "/datas/benchmark_realworld"
+    fix = os.path.join(ROOT, "oracle", "_ref", "realworld_features.npz")
+    if not (os.path.isdir(data) and os.path.exists(fix)):
+        pytest.skip("shipped data or oracle/_ref/realworld_features.npz not present")
+    g = dict(np.load(fix))
+    poses, frames = rw.load_window(data)
+    assert np.abs(poses - g["poses"]).max() < 1e-13
+    cl, co, layer = rw.associate(frames, g["poses"], 2.0)
+    assert cl.shape == g["clusters"].shape == (2281, 177, 10)
+    assert np.array_equal(canon(cl), canon(g["clusters"]))
+    assert list(np.bincount(layer)) == [797, 449, 1035]

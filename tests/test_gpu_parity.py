@@ -394,3 +394,25 @@ def test_two_ranks_sharded_on_one_gpu():
     assert len(lg2) == len(lg1) and np.allclose(lg2[:, :3], lg1[:, :3], rtol=1e-9)
     rot, tr = pose_errors(out2, out1)
     assert rot.max() < 1e-9 and tr.max() < 1e-9
+
+
+def test_realworld_driver_end_to_end(tmp_path):
+    """N2 product pipeline on the GPU box: scans + pose CSV in the shipped formats -> readers ->
+    association (host C++) -> C ABI -> HIP LM loop; the oracle optimises the same features on the CPU."""
+    from balm_amd import realworld as rw
+    from test_association import synthetic_window, write_window
+    poses, frames = synthetic_window(1, 20, 150, 40)
+    write_window(str(tmp_path), poses, frames)
+    P, fr = rw.load_window(str(tmp_path))
+    cl, co, layer = rw.associate(fr, P, 1.0)
+    assert cl.shape[0] >= 3 * 20                                     # benchmark_realworld.cpp:209
+    c = capi.Context(20)
+    c.set_features(cl, None, co)
+    out, lg = c.damping_iter(P, form=0, u0=0.01, max_iter=10, min_planes=20)
+    oo, lo = orc.damping_iter(0, cl, None, co, P, 0.01, 10)
+    assert len(lg) == len(lo)
+    rot, tr = pose_errors(out, oo)
+    assert rot.max() <= ROT_TOL_RAD and tr.max() <= TRANS_TOL_M
+    assert lg[-1, 1] < lg[0, 0]
+    c.close()
+    assert rw.main([str(tmp_path), "--voxel", "1.0"]) == 0
