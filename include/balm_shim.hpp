@@ -62,7 +62,7 @@ class BALM2_HIP {
 
   // bavoxel.hpp:1069
   void damping_iter(std::vector<IMUST> &x_stats, VOX_HESS &voxhess) {
-    upload(voxhess);
+    upload(voxhess, /*force=*/true);      // one upload per optimisation: the container may have been refilled
     std::vector<double> poses = flatten_poses(x_stats);
     balm_lm_opts o;
     o.form = form; o.u0 = u0; o.max_iter = max_iter; o.rel_tol = rel_tol;
@@ -112,11 +112,13 @@ class BALM2_HIP {
     }
   }
 
-  // VOX_HESS holds borrowed pointers (bavoxel.hpp:24-26); flatten them into the ABI's arrays
-  void upload(VOX_HESS &vh) {
+  // VOX_HESS holds borrowed pointers (bavoxel.hpp:24-26); flatten them into the ABI's arrays.  The
+  // evaluators (divide_thread_*, only_residual) reuse the upload while they are called on the same
+  // container object of the same size, as the reference's damping_iter does within one optimisation.
+  void upload(VOX_HESS &vh, bool force = false) {
     ensure_ctx();
     const size_t F = vh.plvec_voxels.size();
-    if (loaded_ == (const void *)&vh && loaded_F_ == F) return;
+    if (!force && loaded_ == (const void *)&vh && loaded_F_ == F) return;
     const int W = win_size;
     std::vector<double> cl(F * (size_t)W * 10), fx(F * 10), co(F);
     bool any_fix = false;
