@@ -47,7 +47,6 @@ struct balm_ctx {
   double *d_cl = nullptr;           // [F][10][W]  per-feature SoA
   double *d_fix = nullptr;          // [F][10] or null
   double *d_coe = nullptr;          // [F]
-  size_t cap_F = 0;
   // poses
   double *d_poses = nullptr;        // [W][12] current
   double *d_poses_tmp = nullptr;    // [W][12] trial
@@ -64,8 +63,7 @@ struct balm_ctx {
   size_t cap_part = 0;
   double *d_dpart = nullptr;        // [nblk_factors][DACC][W]
   size_t cap_dpart = 0;
-  double *d_rpart = nullptr;        // residual partials
-  size_t cap_rpart = 0;
+  double *d_rpart = nullptr;        // residual partials at the current poses
   double *d_red = nullptr;          // [ntiles*6400 | DACC_MAX*W | r | pad]   all-reduce payload
   size_t red_len = 0;
   int *d_tileIJ = nullptr;          // [ntiles][2]

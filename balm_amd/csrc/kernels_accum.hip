@@ -585,7 +585,6 @@ __device__ __forceinline__ void syrk_sweep(const double *__restrict__ pa, const 
   for (int s = 0; s < nsteps; s += SYRK_NBUF) {       // nsteps is a multiple of SYRK_NBUF
 #pragma unroll
     for (int j = 0; j < SYRK_NBUF; j++) {
-      constexpr int dummy = 0; (void)dummy;
       const int nb = (j + SYRK_NBUF - 1) % SYRK_NBUF;
       load5(pa, a[nb]);                               // the last steps prefetch past the slice (allocated)
       if (!DIAG) load5(pb, b[nb]);
