@@ -101,8 +101,9 @@ constexpr int PANEL_ROWS = 64;                     // rows below the diagonal bl
 constexpr int PANEL_LR = NB + PANEL_ROWS;          // local rows: 48 diagonal + 64 own = 7 tiles of 16
 static_assert(PANEL_LR == 112 && NB == 48, "k_ldl_panel is written for 3 + 4 row tiles of 16");
 
-__device__ __forceinline__ double rcp_nr(double d) {        // 1/d: v_rcp_f64 + one Newton step
+__device__ __forceinline__ double rcp_nr(double d) {        // 1/d: v_rcp_f64 + two Newton steps (<= 1 ulp)
   double x = __builtin_amdgcn_rcp(d);
+  x = __builtin_fma(__builtin_fma(-d, x, 1.0), x, x);
   x = __builtin_fma(__builtin_fma(-d, x, 1.0), x, x);
   return (fabs(d) > DBL_MIN) ? x : 0.0;                      // Eigen's D^+ rule for a vanished pivot
 }
