@@ -416,3 +416,28 @@ def test_realworld_driver_end_to_end(tmp_path):
     assert lg[-1, 1] < lg[0, 0]
     c.close()
     assert rw.main([str(tmp_path), "--voxel", "1.0"]) == 0
+
+
+def test_edge_cases_single_feature_two_observers_and_blind_pose():
+    """domain edge cases: one feature only; a feature seen by exactly two poses (push_voxel's minimum,
+    bavoxel.hpp:32-37); a pose that observes nothing (its 6x6 block of H and D is exactly zero: the
+    damped matrix is singular, Eigen's LDLT leaves a zero pivot and its solve returns 0 there)."""
+    sc, _ = make_scene(95, 9, 6, 25)
+    sc.clusters[:, 4] = 0.0                     # pose 4 is blind
+    sc.clusters[0, 2:] = 0.0                    # feature 0: poses 0 and 1 only
+    sc.coeffs[:] = sc.clusters[..., 9].sum(1)
+    for F in (1, 6):
+        cl, co = sc.clusters[:F], sc.coeffs[:F]
+        c = capi.Context(sc.W)
+        c.set_features(cl, None, co)
+        H, g, r = c.evaluate(0, sc.poses_init)
+        Ho, go, ro = orc.evaluate(0, cl, None, co, sc.poses_init)
+        assert abs(r - ro) / ro < 1e-12 and rel_err(g, go) < HTOL and rel_err(H, Ho) < HTOL
+        assert not H[24:30].any() and not g[24:30].any()            # blind pose: exact zeros
+        dx, q1 = c.solve_damped(Ho, go, 0.1)
+        dxo, q1o = orc.solve_damped(Ho, go, 0.1)
+        assert np.all(dx[24:30] == 0.0) and np.all(dxo[24:30] == 0.0)
+        live = np.abs(dxo) > 0
+        if F == 6:                                                   # F = 1 leaves the system rank deficient everywhere
+            assert rel_err(dx[live], dxo[live]) < 1e-6
+        c.close()
