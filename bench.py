@@ -97,7 +97,7 @@ def main():
             print("bench.py: --gpus %d needs torch.distributed.run (WORLD_SIZE=%d)" % (args.gpus, world),
                   file=sys.stderr)
             sys.exit(2)
-    multi = world > 1
+    multi = world > 1 or os.environ.get("BALM_BENCH_FORCE_DIST") == "1"   # the latter: exercise the N>1 code path on one GPU
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible; the HIP path has no CPU fallback", file=sys.stderr)
         sys.exit(3)
@@ -142,6 +142,11 @@ def main():
 
     timing = ctx.timing()
     wm = ctx.work_model()
+    if multi:
+        import torch.distributed as dist
+        ctx.set_allreduce(None)
+        dist.barrier()
+        dist.destroy_process_group()
     if rank != 0:
         return
 
