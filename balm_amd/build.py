@@ -10,7 +10,9 @@ import sys
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIBDIR = os.path.join(_HERE, "lib")
-HIP_SOURCES = ["kernels_accum.hip", "kernels_solve.hip", "kernels_build.hip", "balm_capi.hip"]
+HIP_SOURCES = ["kernels_accum.hip", "kernels_solve.hip", "kernels_build.hip", "kernels_voxel.hip", "balm_capi.hip"]
+# association decisions must reproduce the reference's un-fused float/double arithmetic bit for bit
+EXTRA_FLAGS = {"kernels_voxel.hip": ["-ffp-contract=off"]}
 HIP_DEPS = ["balm_internal.h", "syrk_mfma_asm.inc", os.path.join("..", "..", "include", "balm_hip.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=on", "-Wall",
@@ -33,7 +35,7 @@ def build_hip(force=False, verbose=False):
         o = os.path.join(LIBDIR, src.replace(".hip", ".o"))
         objs.append(o)
         if force or _newer(s, o) or any(_newer(d, o) for d in deps):
-            cmd = [HIPCC] + HIP_FLAGS + ["-c", s, "-o", o]
+            cmd = [HIPCC] + HIP_FLAGS + EXTRA_FLAGS.get(src, []) + ["-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd), flush=True)
             procs.append((cmd, subprocess.Popen(cmd)))

@@ -14,12 +14,13 @@ LIB_PATH = os.path.join(_HERE, "lib", "libbalm_hip.so")
 FORM_LEFT, FORM_RIGHT = 0, 1
 OK, ERR_ARG, ERR_HIP, ERR_STATE, ERR_TOO_FEW_PLANES, ERR_NUMERIC = range(6)
 FLAG_TIMING = 1
-T_MOMENTS, T_FACTORS, T_SYRK, T_ASSEMBLE, T_SOLVE, T_UPDATE, T_BUILD, T_COUNT = range(8)
-TIMING_NAMES = ["moments", "factors", "syrk", "assemble", "solve", "update", "build"]
+T_MOMENTS, T_FACTORS, T_SYRK, T_ASSEMBLE, T_SOLVE, T_UPDATE, T_BUILD, T_VOXEL, T_COUNT = range(9)
+TIMING_NAMES = ["moments", "factors", "syrk", "assemble", "solve", "update", "build", "voxel"]
 
 # every symbol include/balm_hip.h declares
 EXPORTS = ["balm_create", "balm_destroy", "balm_set_features", "balm_evaluate", "balm_only_residual",
-           "balm_solve_damped", "balm_damping_iter", "balm_build_clusters", "balm_set_allreduce",
+           "balm_solve_damped", "balm_damping_iter", "balm_build_clusters", "balm_associate", "balm_get_features",
+           "balm_set_allreduce",
            "balm_get_timing", "balm_reset_timing", "balm_work_model", "balm_last_error", "balm_version"]
 
 
@@ -32,6 +33,10 @@ class LMOpts(C.Structure):
     _fields_ = [("form", C.c_int), ("u0", C.c_double), ("max_iter", C.c_int), ("rel_tol", C.c_double),
                 ("min_planes_per_pose", C.c_int), ("force_hess", C.c_int), ("no_stop", C.c_int),
                 ("verbose", C.c_int), ("reanchor", C.c_int)]
+
+
+class VoxelOpts(C.Structure):
+    _fields_ = [("voxel_size", C.c_double), ("eigen_thr", C.c_float * 3), ("min_ps", C.c_int)]
 
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_long, C.c_void_p)
@@ -66,6 +71,9 @@ def lib():
                                         C.POINTER(C.c_int)]
         L.balm_build_clusters.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long,
                                           C.c_void_p, C.c_void_p, C.c_void_p]
+        L.balm_associate.argtypes = [C.c_void_p, C.POINTER(VoxelOpts), C.c_void_p, C.c_void_p, C.c_long, C.c_void_p,
+                                     C.POINTER(C.c_int), C.POINTER(C.c_long)]
+        L.balm_get_features.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.balm_set_allreduce.argtypes = [C.c_void_p, ALLREDUCE_FN, C.c_void_p]
         L.balm_get_timing.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.balm_reset_timing.argtypes = [C.c_void_p]
@@ -132,6 +140,25 @@ class Context:
                                                _p(fix), _p(coeffs), _p(out)))
         self.F = F
         return out
+
+    def associate(self, xyz, frame_id, poses, voxel_size=2.0, eigen_thresholds=(1.0 / 16, 1.0 / 16, 1.0 / 9),
+                  min_ps=15, want_features=True):
+        """Adaptive-voxel association on the device; installs the features.  -> (F, n_root_voxels,
+        (clusters [F,W,10], coeffs [F], layer [F]) or None)"""
+        xyz = _c(xyz, np.float32).reshape(-1, 3)
+        frame_id, poses = _c(frame_id, np.int32), _c(poses)
+        o = VoxelOpts(voxel_size, (C.c_float * 3)(*[float(t) for t in eigen_thresholds]), min_ps)
+        F, nr = C.c_int(0), C.c_long(0)
+        self._check(self.L.balm_associate(self.h, C.byref(o), _p(xyz), _p(frame_id), xyz.shape[0], _p(poses),
+                                          C.byref(F), C.byref(nr)))
+        self.F = F.value
+        feats = None
+        if want_features and self.F > 0:
+            cl, co = np.zeros((self.F, self.W, 10)), np.zeros(self.F)
+            layer = np.zeros(self.F, dtype=np.int32)
+            self._check(self.L.balm_get_features(self.h, _p(cl), _p(co), _p(layer)))
+            feats = (cl, co, layer)
+        return self.F, nr.value, feats
 
     def evaluate(self, form, poses, head=0, end=None, want_hess=True):
         """-> (Hess [n,n] or None, JacT [n], residual)"""

@@ -207,7 +207,7 @@ void balm_destroy(balm_ctx *ctx) {
   if (ctx->stream) hipStreamSynchronize(ctx->stream);
   void *ptrs[] = {ctx->d_cl, ctx->d_fix, ctx->d_coe, ctx->d_poses, ctx->d_poses_tmp, ctx->d_C, ctx->d_feat,
                   ctx->d_Gt, ctx->d_part, ctx->d_dpart, ctx->d_rpart, ctx->d_feat_tmp, ctx->d_rpart_tmp, ctx->d_red, ctx->d_tileIJ, ctx->d_H,
-                  ctx->d_g, ctx->d_A, ctx->d_Wp, ctx->d_dvec, ctx->d_z, ctx->d_x, ctx->d_perm, ctx->d_dx, ctx->d_scal};
+                  ctx->d_g, ctx->d_A, ctx->d_Wp, ctx->d_dvec, ctx->d_z, ctx->d_x, ctx->d_perm, ctx->d_dx, ctx->d_scal, ctx->d_arena};
   for (void *p : ptrs) if (p) hipFree(p);
   if (ctx->h_scal) hipHostFree(ctx->h_scal);
   for (auto &sp : ctx->timer.pending) { hipEventDestroy(sp.a); hipEventDestroy(sp.b); }
@@ -321,6 +321,87 @@ int balm_build_clusters(balm_ctx *ctx, int F, const float *xyz, const int *feat_
   ctx->work_S = S; ctx->work_B = B;
   if ((rc = install_feature_buffers(ctx, F, fix, coeffs))) return rc;
   return sync_stream(ctx);
+}
+
+int balm_associate(balm_ctx *ctx, const balm_voxel_opts *opts, const float *xyz, const int *frame_id, long n_pts,
+                   const double *poses, int *F_out, long *n_root_voxels) {
+  if (!ctx) return BALM_ERR_ARG;
+  if (!opts || !xyz || !frame_id || !poses || !F_out || n_pts < 1 || !(opts->voxel_size > 0)) {
+    ctx->err = "balm_associate: bad argument"; return BALM_ERR_ARG;
+  }
+  const int W = ctx->W;
+  if (W > 512) { ctx->err = "balm_associate: win_size > 512 not supported"; return BALM_ERR_ARG; }
+  for (long k = 0; k < n_pts; k++)
+    if (frame_id[k] < 0 || frame_id[k] >= W) { ctx->err = "balm_associate: frame_id out of range"; return BALM_ERR_ARG; }
+  HIP_TRY(hipSetDevice(ctx->device));
+  *F_out = 0;
+  ctx->F = 0;
+  ctx->assoc_clusters.clear(); ctx->assoc_coeffs.clear(); ctx->assoc_layer.clear();
+  float *d_xyz = nullptr; int *d_f = nullptr;
+  double *d_out = nullptr, *d_coe = nullptr; int *d_lay = nullptr;
+  int F = 0; long nroots = 0; int arc = 0;
+  size_t need = 0;
+  if (!ctx->d_arena) {                  // first call: ~100 B per point covers the per-point arrays + sort scratch
+    const size_t want = (size_t)n_pts * 100 + (64u << 20);
+    if (hipMalloc(&ctx->d_arena, want) == hipSuccess) ctx->arena_cap = want; else { ctx->d_arena = nullptr; hipGetLastError(); }
+  }
+  HIP_TRY(hipMalloc((void **)&d_xyz, (size_t)n_pts * 3 * sizeof(float)));
+  hipError_t e = hipMalloc((void **)&d_f, (size_t)n_pts * sizeof(int));
+  if (e == hipSuccess) e = hipMemcpyAsync(d_xyz, xyz, (size_t)n_pts * 3 * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_f, frame_id, (size_t)n_pts * sizeof(int), hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(ctx->d_poses, poses, (size_t)12 * W * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) {
+    Span sp(ctx, BALM_T_VOXEL);
+    arc = associate_device(ctx->stream, d_xyz, d_f, ctx->d_poses, n_pts, W, opts->voxel_size, opts->eigen_thr, opts->min_ps,
+                           ctx->d_arena, ctx->arena_cap, &need, &F, &d_out, &d_coe, &d_lay, &nroots);
+  }
+  if (need > ctx->arena_cap) {          // grow for the next call of this size
+    hipStreamSynchronize(ctx->stream);
+    if (ctx->d_arena) hipFree(ctx->d_arena);
+    ctx->arena_cap = need + need / 8;
+    if (hipMalloc(&ctx->d_arena, ctx->arena_cap) != hipSuccess) { ctx->d_arena = nullptr; ctx->arena_cap = 0; hipGetLastError(); }
+  }
+  if (d_xyz) hipFree(d_xyz);
+  if (d_f) hipFree(d_f);
+  HIP_TRY(e);
+  if (arc) { ctx->err = arc == -2 ? "balm_associate: unsupported size" : "balm_associate: device failure"; return BALM_ERR_HIP; }
+  if (n_root_voxels) *n_root_voxels = nroots;
+  if (F == 0) return BALM_OK;
+  const size_t count = (size_t)F * W * 10;
+  ctx->assoc_clusters.resize(count); ctx->assoc_coeffs.resize(F); ctx->assoc_layer.resize(F);
+  int rc = dalloc(ctx, &ctx->d_cl, count);
+  if (!rc) {
+    launch_transpose_clusters(ctx->stream, d_out, ctx->d_cl, F, W);
+    e = hipMemcpyAsync(ctx->assoc_clusters.data(), d_out, count * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(ctx->assoc_coeffs.data(), d_coe, (size_t)F * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(ctx->assoc_layer.data(), d_lay, (size_t)F * sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  }
+  hipFree(d_out); hipFree(d_coe); hipFree(d_lay);
+  if (rc) return rc;
+  HIP_TRY(e);
+  ctx->planes_per_pose.assign(W, 0);
+  double S = 0, B = 0;
+  for (int a = 0; a < F; a++) {
+    int na = 0;
+    for (int i = 0; i < W; i++)
+      if (ctx->assoc_clusters[((size_t)a * W + i) * 10 + 9] != 0) { ctx->planes_per_pose[i]++; na++; }
+    S += na; B += 0.5 * na * (na + 1.0);
+  }
+  ctx->work_S = S; ctx->work_B = B;
+  if ((rc = install_feature_buffers(ctx, F, nullptr, ctx->assoc_coeffs.data()))) return rc;
+  if ((rc = sync_stream(ctx))) return rc;
+  *F_out = F;
+  return BALM_OK;
+}
+
+int balm_get_features(balm_ctx *ctx, double *clusters, double *coeffs, int *layer) {
+  if (!ctx) return BALM_ERR_ARG;
+  if (ctx->assoc_coeffs.empty()) { ctx->err = "balm_get_features: no balm_associate result"; return BALM_ERR_STATE; }
+  if (clusters) std::memcpy(clusters, ctx->assoc_clusters.data(), ctx->assoc_clusters.size() * sizeof(double));
+  if (coeffs) std::memcpy(coeffs, ctx->assoc_coeffs.data(), ctx->assoc_coeffs.size() * sizeof(double));
+  if (layer) std::memcpy(layer, ctx->assoc_layer.data(), ctx->assoc_layer.size() * sizeof(int));
+  return BALM_OK;
 }
 
 int balm_set_allreduce(balm_ctx *ctx, balm_allreduce_fn fn, void *user) {

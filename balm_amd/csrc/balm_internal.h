@@ -82,6 +82,10 @@ struct balm_ctx {
   // host bookkeeping
   std::vector<int> planes_per_pose;
   double work_S = 0, work_B = 0;
+  std::vector<double> assoc_clusters, assoc_coeffs;   // host copies of the last balm_associate
+  std::vector<int> assoc_layer;
+  void *d_arena = nullptr;          // balm_associate scratch, grown to what the last call needed
+  size_t arena_cap = 0;
   balm_allreduce_fn allreduce = nullptr;
   void *allreduce_user = nullptr;
   balm::Timer timer;
@@ -113,6 +117,9 @@ void launch_update_poses(hipStream_t s, int form, int W, const double *poses, co
 void launch_reanchor(hipStream_t s, int W, double *poses);
 
 // launchers (kernels_build.hip)
+int associate_device(hipStream_t s, const float *d_xyz, const int *d_frame, const double *d_poses, long n, int W,
+                     double voxel_size, const float thr[3], int min_ps, void *arena, size_t arena_cap, size_t *arena_need,
+                     int *F_out, double **d_out, double **d_coe, int **d_layer, long *n_roots);
 void launch_build_clusters(hipStream_t s, const float *xyz, const int *feat_id, const int *pose_id, long n_pts,
                            int F, int W, double *soa);
 void launch_soa_to_aos(hipStream_t s, const double *soa, double *aos, int F, int W);

@@ -1,0 +1,589 @@
+// Adaptive-voxel point association on gfx950 ("next" row N3 of SURVEY.md 8f): the last CPU stage of
+// the real-world pipeline.  Same decisions as the host restatement (csrc/association.cpp), i.e. as the
+// reference's cut_voxel / recut / tras_opt (src/benchmark/bavoxel.hpp:1170-1223, :654-776, :908-929):
+// a point's root voxel, octants and every plane test are evaluated with the reference's float/double
+// types and WITHOUT fused multiply-adds (this file is compiled -ffp-contract=off; the reference is built
+// without -march, so it has none), so integer/index results are bit-exact.
+//
+// Instead of growing an octree point by point the GPU evaluates all three levels at once:
+//   1  per point: world position, root voxel key, octant at level 1 and level 2
+//   2  radix sort by root key -> dense root ids; then, per level L = 0,1,2, a stable radix sort by
+//      (root, octant prefix of L, frame): the scan order of the points survives inside every
+//      (node, frame) segment, which is the order the reference pushes them in (cut_voxel / cut_func)
+//   3  one lane per segment accumulates the body-frame and world-frame PointCluster sequentially
+//      (tools.hpp:311-316 order -> the sums are bit-exact at every level); node totals add the
+//      per-frame world clusters in frame order (judge_eigen's loop)
+//   4  plane tests top-down (recut), feature list (tras_opt + push_voxel's >= 2 observing poses),
+//      per-(feature, pose) body clusters copied from the feature's level.
+// HBM-bound: ~20 B/point read a handful of times; the four sorts dominate.
+#include <algorithm>
+#include <cstring>
+#include <type_traits>
+
+#include <hip/hip_runtime.h>
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+
+#include "balm_internal.h"
+
+namespace balm {
+
+namespace {
+
+struct VoxParams {
+  double voxel_size;
+  float thr[3];
+  int min_ps;
+  int W;
+};
+
+__device__ __forceinline__ void world_point(const float *__restrict__ xyz, const double *__restrict__ pose, long p,
+                                            double q[3], double po[3]) {
+  po[0] = (double)xyz[3 * p]; po[1] = (double)xyz[3 * p + 1]; po[2] = (double)xyz[3 * p + 2];
+#pragma unroll
+  for (int r = 0; r < 3; r++)   // ((R(r,0) x + R(r,1) y) + R(r,2) z) + t(r), one rounding per operation
+    q[r] = __dadd_rn(__dadd_rn(__dadd_rn(__dmul_rn(pose[r], po[0]), __dmul_rn(pose[3 + r], po[1])),
+                               __dmul_rn(pose[6 + r], po[2])), pose[9 + r]);
+}
+
+// cut_voxel's key (bavoxel.hpp:1178-1184): loc = (float)(q / voxel_size), shifted down for negatives, truncated
+__device__ __forceinline__ long long voxel_key(double q, double vs) {
+  float loc = (float)(q / vs);
+  if (loc < 0) loc = (float)((double)loc - 1.0);
+  return (long long)loc;
+}
+
+// pass A: range of the voxel keys per axis (to pack them into as few radix digits as possible); keys are
+// saturated to +-2^30 here -- anything beyond 2^21 voxels per axis is rejected by the host anyway.
+// One row of {min[3], max[3]} per block; the host folds the rows.
+constexpr int RANGE_BLOCKS = 1024;
+__global__ __launch_bounds__(256) void k_vox_range(const float *__restrict__ xyz, const int *__restrict__ frame,
+                                                   const double *__restrict__ poses, long n, double vs,
+                                                   int *__restrict__ range /* [gridDim.x][6] */) {
+  __shared__ int red[4][6];
+  int lo[3] = {1 << 30, 1 << 30, 1 << 30}, hi[3] = {-(1 << 30), -(1 << 30), -(1 << 30)};
+  for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (long)gridDim.x * blockDim.x) {
+    double q[3], po[3];
+    world_point(xyz, poses + 12 * (long)frame[p], p, q, po);
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      const long long k = voxel_key(q[j], vs);
+      const int ki = (int)max(-(1ll << 30), min(1ll << 30, k));
+      lo[j] = min(lo[j], ki); hi[j] = max(hi[j], ki);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 3; j++)
+    for (int d = 32; d >= 1; d >>= 1) {
+      lo[j] = min(lo[j], __shfl_xor(lo[j], d, 64));
+      hi[j] = max(hi[j], __shfl_xor(hi[j], d, 64));
+    }
+  if ((threadIdx.x & 63) == 0)
+#pragma unroll
+    for (int j = 0; j < 3; j++) { red[threadIdx.x >> 6][j] = lo[j]; red[threadIdx.x >> 6][3 + j] = hi[j]; }
+  __syncthreads();
+  if (threadIdx.x < 6) {
+    int v = red[0][threadIdx.x];
+    for (int w = 1; w < 4; w++) v = threadIdx.x < 3 ? min(v, red[w][threadIdx.x]) : max(v, red[w][threadIdx.x]);
+    range[blockIdx.x * 6 + threadIdx.x] = v;
+  }
+}
+
+struct KeyPack { long long off[3]; int bits[3]; };
+
+// pass B: packed root key + cut_func's octants (bavoxel.hpp:709-720) for both subdivision levels; the sort
+// value carries (point index, octants, frame) so that later passes never gather per-point attributes
+template <class K>
+__global__ __launch_bounds__(256) void k_vox_keys(const float *__restrict__ xyz, const int *__restrict__ frame,
+                                                  const double *__restrict__ poses, long n, double vs, KeyPack kp,
+                                                  K *__restrict__ k0, unsigned long long *__restrict__ val) {
+  const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  double q[3], po[3];
+  const int fr = frame[p];
+  world_point(xyz, poses + 12 * (long)fr, p, q, po);
+  const float q1 = (float)(vs / 4.0);
+  unsigned long long key = 0;
+  int o1 = 0, o2 = 0;
+#pragma unroll
+  for (int j = 0; j < 3; j++) {
+    const long long kj = voxel_key(q[j], vs);
+    const float c0 = (float)((0.5 + (double)kj) * vs);
+    const int b1 = q[j] > (double)c0;
+    const float c1 = __fadd_rn(c0, __fmul_rn((float)(2 * b1 - 1), q1));
+    const int b2 = q[j] > (double)c1;
+    key = (key << kp.bits[j]) | (unsigned long long)(kj - kp.off[j]);
+    o1 = (o1 << 1) | b1;
+    o2 = (o2 << 1) | b2;
+  }
+  k0[p] = (K)key;
+  val[p] = ((unsigned long long)p << 15) | ((unsigned long long)((o1 << 3) | o2) << 9) | (unsigned long long)fr;
+}
+
+template <class T>
+__global__ void k_head_flags(const T *__restrict__ key, long n, int shift, unsigned int *__restrict__ flag) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) flag[i] = (i == 0 || (key[i] >> shift) != (key[i - 1] >> shift)) ? 1u : 0u;
+}
+
+// composite key of level L: (root id, octant prefix, frame); oct_mask = 0, 0x38, 0x3f for L = 0, 1, 2
+template <class K>
+__global__ void k_make_ck(const unsigned int *__restrict__ rootid_incl, const unsigned long long *__restrict__ val, long n,
+                          unsigned long long attr_mask, K *__restrict__ ck, unsigned int *__restrict__ idx) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const unsigned long long v = val[i];
+  ck[i] = (K)(((unsigned long long)(rootid_incl[i] - 1) << 15) | (v & attr_mask));
+  idx[i] = (unsigned int)(v >> 15);
+}
+
+// segment s = run of equal composite keys: its first position and key
+template <class K>
+__global__ void k_seg_heads(const K *__restrict__ cks, const unsigned int *__restrict__ segid_incl,
+                            long n, unsigned int *__restrict__ seg_start, unsigned long long *__restrict__ seg_ck) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (i == 0 || cks[i] != cks[i - 1]) {
+    const unsigned int s = segid_incl[i] - 1;
+    seg_start[s] = (unsigned int)i;
+    seg_ck[s] = cks[i];
+  }
+}
+
+// PointCluster::push in scan order (tools.hpp:311-316), body frame (sig_orig) and world frame (sig_tran).
+// The sums are sequential in scan order (that is what makes them equal to the reference's bit for bit), so
+// the parallelism is across segments and across the 18 sums of a segment:
+//   short segments (<= SEG_SHORT points): one lane per segment
+//   long segments: one wave per segment; 64 points at a time are gathered and expanded into their 18 terms in
+//   parallel, parked in LDS, and lanes 0..17 each add one term column in order.
+constexpr int SEG_SHORT = 24;
+constexpr int SEG_TERMS = 18;          // 6 + 3 body, 6 + 3 world; N is the segment length
+constexpr int SEG_LD = 65;             // padded LDS row
+
+struct PointTerms { double t[SEG_TERMS]; };
+
+__device__ __forceinline__ PointTerms point_terms(const float x[3], const double P[12]) {
+  const double po[3] = {(double)x[0], (double)x[1], (double)x[2]};
+  double q[3];
+#pragma unroll
+  for (int r = 0; r < 3; r++)
+    q[r] = __dadd_rn(__dadd_rn(__dadd_rn(__dmul_rn(P[r], po[0]), __dmul_rn(P[3 + r], po[1])), __dmul_rn(P[6 + r], po[2])), P[9 + r]);
+  PointTerms o;
+  o.t[0] = __dmul_rn(po[0], po[0]); o.t[1] = __dmul_rn(po[0], po[1]); o.t[2] = __dmul_rn(po[0], po[2]);
+  o.t[3] = __dmul_rn(po[1], po[1]); o.t[4] = __dmul_rn(po[1], po[2]); o.t[5] = __dmul_rn(po[2], po[2]);
+  o.t[6] = po[0]; o.t[7] = po[1]; o.t[8] = po[2];
+  o.t[9] = __dmul_rn(q[0], q[0]); o.t[10] = __dmul_rn(q[0], q[1]); o.t[11] = __dmul_rn(q[0], q[2]);
+  o.t[12] = __dmul_rn(q[1], q[1]); o.t[13] = __dmul_rn(q[1], q[2]); o.t[14] = __dmul_rn(q[2], q[2]);
+  o.t[15] = q[0]; o.t[16] = q[1]; o.t[17] = q[2];
+  return o;
+}
+
+__global__ __launch_bounds__(256) void k_seg_clusters_short(const float *__restrict__ xyz, const double *__restrict__ poses,
+                                                            const unsigned int *__restrict__ idx,
+                                                            const unsigned int *__restrict__ seg_start,
+                                                            const unsigned long long *__restrict__ seg_ck, long NS,
+                                                            double *__restrict__ seg_body, double *__restrict__ seg_world) {
+  const long s = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= NS) return;
+  const unsigned int i0 = seg_start[s], i1 = seg_start[s + 1];
+  if (i1 - i0 > SEG_SHORT) return;
+  const double *pose = poses + 12 * (long)(seg_ck[s] & 511ull);
+  double P[12];
+#pragma unroll
+  for (int c = 0; c < 12; c++) P[c] = pose[c];
+  double acc[SEG_TERMS];
+#pragma unroll
+  for (int c = 0; c < SEG_TERMS; c++) acc[c] = 0.0;
+  for (unsigned int i = i0; i < i1; i++) {
+    const size_t p = idx[i];
+    const float x[3] = {xyz[3 * p], xyz[3 * p + 1], xyz[3 * p + 2]};
+    const PointTerms t = point_terms(x, P);
+#pragma unroll
+    for (int c = 0; c < SEG_TERMS; c++) acc[c] = __dadd_rn(acc[c], t.t[c]);
+  }
+#pragma unroll
+  for (int c = 0; c < 9; c++) { seg_body[s * 10 + c] = acc[c]; seg_world[s * 10 + c] = acc[9 + c]; }
+  seg_body[s * 10 + 9] = seg_world[s * 10 + 9] = (double)(i1 - i0);
+}
+
+__global__ __launch_bounds__(256) void k_seg_clusters_long(const float *__restrict__ xyz, const double *__restrict__ poses,
+                                                           const unsigned int *__restrict__ idx,
+                                                           const unsigned int *__restrict__ seg_start,
+                                                           const unsigned long long *__restrict__ seg_ck, long NS,
+                                                           double *__restrict__ seg_body, double *__restrict__ seg_world) {
+  __shared__ double lds[4][SEG_TERMS * SEG_LD];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const long s = (long)blockIdx.x * 4 + wv;
+  if (s >= NS) return;
+  const unsigned int i0 = seg_start[s], i1 = seg_start[s + 1];
+  if (i1 - i0 <= SEG_SHORT) return;
+  const double *pose = poses + 12 * (long)(seg_ck[s] & 511ull);
+  double P[12];
+#pragma unroll
+  for (int c = 0; c < 12; c++) P[c] = pose[c];
+  double *mine = lds[wv];
+  const int col = min(lane, SEG_TERMS - 1);
+  double acc = 0.0;
+  // two-deep software pipeline over the dependent gathers: index of chunk k+2, coordinates of chunk k+1
+  size_t pn = idx[min(i0 + lane, i1 - 1)];
+  float xn[3] = {xyz[3 * pn], xyz[3 * pn + 1], xyz[3 * pn + 2]};
+  pn = idx[min(i0 + 64 + lane, i1 - 1)];
+  for (unsigned int i = i0; i < i1; i += 64) {
+    const int cnt = (int)min(64u, i1 - i);
+    const float x[3] = {xn[0], xn[1], xn[2]};
+    xn[0] = xyz[3 * pn]; xn[1] = xyz[3 * pn + 1]; xn[2] = xyz[3 * pn + 2];
+    pn = idx[min(i + 128 + lane, i1 - 1)];
+    const PointTerms t = point_terms(x, P);
+#pragma unroll
+    for (int c = 0; c < SEG_TERMS; c++) mine[c * SEG_LD + lane] = t.t[c];
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);        // lgkmcnt(0): the wave's LDS writes have landed
+    const double *colp = mine + col * SEG_LD;
+    int l = 0;
+    for (; l + 8 <= cnt; l += 8) {
+      double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) v[u] = colp[l + u];
+#pragma unroll
+      for (int u = 0; u < 8; u++) acc = __dadd_rn(acc, v[u]);
+    }
+    for (; l < cnt; l++) acc = __dadd_rn(acc, colp[l]);
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (lane < 9) seg_body[s * 10 + lane] = acc;
+  else if (lane < SEG_TERMS) seg_world[s * 10 + lane - 9] = acc;
+  else if (lane == SEG_TERMS) seg_body[s * 10 + 9] = seg_world[s * 10 + 9] = (double)(i1 - i0);
+}
+
+// tree links over a level's sorted segment list: node -> first segment, node -> parent node,
+// parent node -> first child node
+__global__ void k_level_heads(const unsigned long long *__restrict__ seg_ck, const unsigned int *__restrict__ nid_incl,
+                              const unsigned int *__restrict__ pid_incl, long NS, int parent_shift,
+                              unsigned int *__restrict__ node_seg, unsigned int *__restrict__ node_parent) {
+  const long s = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= NS) return;
+  const unsigned long long ck = seg_ck[s];
+  if (s == 0 || (ck >> 9) != (seg_ck[s - 1] >> 9)) {
+    const unsigned int j = nid_incl[s] - 1;
+    node_seg[j] = (unsigned int)s;
+    node_parent[j] = parent_shift ? pid_incl[s] - 1 : (unsigned int)(ck >> 15);
+  }
+}
+
+__global__ void k_set_u32(unsigned int *p, unsigned int v) { *p = v; }
+
+struct NodeTot { double c[10]; int minf, maxf; };
+
+// node totals: the per-frame world clusters added in frame order (= judge_eigen's `covMat += sig_tran[i]`);
+// 16 lanes per node, lane c < 10 owns component c (coalesced 80-byte rows)
+__global__ __launch_bounds__(256) void k_node_totals(const double *__restrict__ seg_world,
+                                                     const unsigned long long *__restrict__ seg_ck,
+                                                     const unsigned int *__restrict__ node_seg, long NN, NodeTot *__restrict__ tot) {
+  const long j = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+  const int c = threadIdx.x & 15;
+  if (j >= NN) return;
+  const unsigned int s0 = node_seg[j], s1 = node_seg[j + 1];
+  if (c < 10) {
+    double t = 0.0;
+    for (unsigned int s = s0; s < s1; s++) t = __dadd_rn(t, seg_world[(size_t)s * 10 + c]);
+    tot[j].c[c] = t;
+  } else if (c == 10) {
+    tot[j].minf = (int)(seg_ck[s0] & 511ull);
+    tot[j].maxf = (int)(seg_ck[s1 - 1] & 511ull);
+  }
+}
+
+// eigenvalues of a symmetric 3x3 (cyclic Jacobi, same rotation order as csrc/association.cpp)
+__device__ void eigvals3(double a00, double a01, double a02, double a11, double a12, double a22, double lam[3]) {
+  for (int sweep = 0; sweep < 60; sweep++) {
+    const double off = a01 * a01 + a02 * a02 + a12 * a12, dia = a00 * a00 + a11 * a11 + a22 * a22;
+    if (off <= 1e-300 || off <= 1e-34 * dia) break;
+#define BALM_ROT(app, aqq, apq, arp, arq)                                                                   \
+  if (apq != 0.0) {                                                                                         \
+    const double theta = (aqq - app) / (2.0 * apq);                                                         \
+    const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));                 \
+    const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;                                                    \
+    app -= t * apq; aqq += t * apq; apq = 0.0;                                                              \
+    const double rp = c * arp - s * arq, rq = s * arp + c * arq;                                            \
+    arp = rp; arq = rq;                                                                                     \
+  }
+    BALM_ROT(a00, a11, a01, a02, a12)
+    BALM_ROT(a00, a22, a02, a01, a12)
+    BALM_ROT(a11, a22, a12, a01, a02)
+#undef BALM_ROT
+  }
+  double x = a00, y = a11, z = a22, t;
+  if (x > y) { t = x; x = y; y = t; }
+  if (y > z) { t = y; y = z; z = t; }
+  if (x > y) { t = x; x = y; y = t; }
+  lam[0] = x; lam[1] = y; lam[2] = z;
+}
+
+// per node: 0 = too few points (recut returns, bavoxel.hpp:744), 1 = plane (judge_eigen :654-699 accepts),
+// 2 = not a plane (the node is split, or dies at the last layer)
+enum { NODE_DEAD = 0, NODE_PLANE = 1, NODE_SPLIT = 2 };
+
+__global__ __launch_bounds__(128) void k_node_status(const NodeTot *__restrict__ tot, long NN, float thr, int min_ps,
+                                                     unsigned char *__restrict__ status) {
+  const long j = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= NN) return;
+  const NodeTot t = tot[j];
+  int st = NODE_DEAD;
+  if ((int)t.c[9] > min_ps) {
+    const double n = t.c[9], cx = t.c[6] / n, cy = t.c[7] / n, cz = t.c[8] / n;
+    double lam[3];
+    eigvals3(t.c[0] / n - cx * cx, t.c[1] / n - cx * cy, t.c[2] / n - cx * cz, t.c[3] / n - cy * cy, t.c[4] / n - cy * cz,
+             t.c[5] / n - cz * cz, lam);
+    st = lam[0] / lam[1] < (double)thr ? NODE_PLANE : NODE_SPLIT;
+  }
+  status[j] = (unsigned char)st;
+}
+
+// recut's descent (bavoxel.hpp:737-776) + tras_opt / push_voxel (:908-929, :30-37): a node is a feature when
+// every ancestor was split, it is a plane, and at least two scans observe it
+__global__ void k_feature_flags(int level, long NN, const NodeTot *__restrict__ tot, const unsigned char *__restrict__ st0,
+                                const unsigned char *__restrict__ st1, const unsigned char *__restrict__ st2,
+                                const unsigned int *__restrict__ parent1, const unsigned int *__restrict__ parent2,
+                                unsigned int *__restrict__ flag) {
+  const long j = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= NN) return;
+  bool live;
+  if (level == 0) live = st0[j] == NODE_PLANE;
+  else if (level == 1) live = st1[j] == NODE_PLANE && st0[parent1[j]] == NODE_SPLIT;
+  else {
+    const unsigned int p1 = parent2[j];
+    live = st2[j] == NODE_PLANE && st1[p1] == NODE_SPLIT && st0[parent1[p1]] == NODE_SPLIT;
+  }
+  flag[j] = (live && tot[j].minf != tot[j].maxf) ? 1u : 0u;
+}
+
+// per-(feature, pose) body clusters = the feature node's own segments (sig_orig), weight = sum_i N_i;
+// 16 lanes per node, lane c < 10 copies component c
+__global__ __launch_bounds__(256) void k_emit(long NN, const unsigned int *__restrict__ flag,
+                                              const unsigned int *__restrict__ fid_excl, unsigned int fid_base,
+                                              const unsigned int *__restrict__ node_seg, const unsigned long long *__restrict__ seg_ck,
+                                              const double *__restrict__ seg_body, const NodeTot *__restrict__ tot, int W, int layer,
+                                              double *__restrict__ out, double *__restrict__ coe, int *__restrict__ layer_out) {
+  const long j = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+  const int c = threadIdx.x & 15;
+  if (j >= NN || !flag[j]) return;
+  const size_t f = fid_base + fid_excl[j];
+  if (c < 10) {
+    for (unsigned int s = node_seg[j]; s < node_seg[j + 1]; s++)
+      out[(f * W + (size_t)(seg_ck[s] & 511ull)) * 10 + c] = seg_body[(size_t)s * 10 + c];
+  } else if (c == 10) {
+    coe[f] = tot[j].c[9];     // VOX_HESS::push_voxel weight = sum_i N_i (bavoxel.hpp:42-44)
+    layer_out[f] = layer;
+  }
+}
+
+// bump allocator over a caller-owned arena; whatever does not fit falls back to hipMalloc for this call and
+// raises `need`, so that the caller can grow the arena for the next call
+struct Scratch {
+  char *base; size_t cap, off = 0, need = 0;
+  std::vector<void *> extra;
+  bool ok = true;
+  Scratch(void *b, size_t c) : base((char *)b), cap(c) {}
+  template <class T> T *get(size_t n) {
+    const size_t bytes = ((n ? n : 1) * sizeof(T) + 255) & ~(size_t)255;
+    need += bytes;
+    if (off + bytes <= cap) { T *p = (T *)(base + off); off += bytes; return p; }
+    void *p = nullptr;
+    if (hipMalloc(&p, bytes) != hipSuccess) { ok = false; return nullptr; }
+    extra.push_back(p);
+    return (T *)p;
+  }
+  ~Scratch() { for (void *p : extra) hipFree(p); }
+};
+
+unsigned int last_u32(hipStream_t s, const unsigned int *d, long n) {
+  unsigned int v = 0;
+  if (n > 0) { hipMemcpyAsync(&v, d + n - 1, sizeof(v), hipMemcpyDeviceToHost, s); hipStreamSynchronize(s); }
+  return v;
+}
+
+void scan_incl(Scratch &sc, hipStream_t s, const unsigned int *in, unsigned int *out, long n) {
+  size_t tmp = 0;
+  rocprim::inclusive_scan(nullptr, tmp, in, out, (size_t)n, rocprim::plus<unsigned int>(), s);
+  void *d = sc.get<char>(tmp);
+  if (d) rocprim::inclusive_scan(d, tmp, in, out, (size_t)n, rocprim::plus<unsigned int>(), s);
+}
+
+void scan_excl(Scratch &sc, hipStream_t s, const unsigned int *in, unsigned int *out, long n) {
+  size_t tmp = 0;
+  rocprim::exclusive_scan(nullptr, tmp, in, out, 0u, (size_t)n, rocprim::plus<unsigned int>(), s);
+  void *d = sc.get<char>(tmp);
+  if (d) rocprim::exclusive_scan(d, tmp, in, out, 0u, (size_t)n, rocprim::plus<unsigned int>(), s);
+}
+
+template <class K, class V>
+void sort_pairs(Scratch &sc, hipStream_t s, const K *kin, K *kout, const V *vin, V *vout, long n, int end_bit) {
+  size_t tmp = 0;
+  rocprim::radix_sort_pairs(nullptr, tmp, kin, kout, vin, vout, (size_t)n, 0, end_bit, s);
+  void *d = sc.get<char>(tmp);
+  if (d) rocprim::radix_sort_pairs(d, tmp, kin, kout, vin, vout, (size_t)n, 0, end_bit, s);
+}
+
+inline int grid_for(long n, int bs) { return (int)((n + bs - 1) / bs); }
+
+struct Level {
+  long NS = 0, NN = 0;
+  unsigned long long *seg_ck = nullptr;
+  double *seg_body = nullptr;
+  unsigned int *node_seg = nullptr, *node_parent = nullptr, *flag = nullptr, *fid = nullptr;
+  unsigned char *status = nullptr;
+  NodeTot *tot = nullptr;
+};
+
+}  // namespace
+
+// Device-side association.  d_xyz [n][3], d_frame [n] (0..W-1, points of a frame in scan order), d_poses [W][12].
+// `arena` / `arena_cap`: caller-owned scratch (may be NULL / 0); *arena_need receives the bytes this call wanted.
+// On success *F_out features; *d_out = hipMalloc'ed [F][W][10] (caller frees), *d_coe = [F], *d_layer = [F].
+// Returns 0, or a negative code (-1 allocation / HIP failure, -2 unsupported size).
+int associate_device(hipStream_t s, const float *d_xyz, const int *d_frame, const double *d_poses, long n, int W,
+                     double voxel_size, const float thr[3], int min_ps, void *arena, size_t arena_cap, size_t *arena_need,
+                     int *F_out, double **d_out, double **d_coe, int **d_layer, long *n_roots) {
+  *F_out = 0; *d_out = nullptr; *d_coe = nullptr; *d_layer = nullptr; *n_roots = 0;
+  if (W > 512 || n <= 0 || n >= (1l << 31)) return -2;
+  Scratch sc(arena, arena_cap);
+  struct NeedOut { Scratch &sc; size_t *out; ~NeedOut() { *out = sc.need; } } need_out{sc, arena_need};
+  const int B = 256;
+  auto *k0 = sc.get<unsigned long long>(n), *k0s = sc.get<unsigned long long>(n);   // k0 is reused as the level key
+  auto *val = sc.get<unsigned long long>(n), *vals = sc.get<unsigned long long>(n);
+  auto *idx1 = sc.get<unsigned int>(n), *idxL = sc.get<unsigned int>(n);
+  auto *flag = sc.get<unsigned int>(n), *rootid = sc.get<unsigned int>(n), *incl = sc.get<unsigned int>(n);
+  auto *cks = sc.get<unsigned long long>(n);
+  auto *range = sc.get<int>(6 * RANGE_BLOCKS);
+  if (!sc.ok) return -1;
+
+  // pass A: key range -> digits needed per axis
+  const int rblocks = std::min(grid_for(n, B), RANGE_BLOCKS);
+  std::vector<int> h_rows((size_t)6 * rblocks);
+  hipLaunchKernelGGL(k_vox_range, dim3(rblocks), dim3(B), 0, s, d_xyz, d_frame, d_poses, n, voxel_size, range);
+  hipMemcpyAsync(h_rows.data(), range, h_rows.size() * sizeof(int), hipMemcpyDeviceToHost, s);
+  if (hipStreamSynchronize(s) != hipSuccess) return -1;
+  int h_range[6] = {1 << 30, 1 << 30, 1 << 30, -(1 << 30), -(1 << 30), -(1 << 30)};
+  for (int b = 0; b < rblocks; b++)
+    for (int j = 0; j < 3; j++) {
+      h_range[j] = std::min(h_range[j], h_rows[(size_t)6 * b + j]);
+      h_range[3 + j] = std::max(h_range[3 + j], h_rows[(size_t)6 * b + 3 + j]);
+    }
+  KeyPack kp;
+  int key_bits = 0;
+  for (int j = 0; j < 3; j++) {
+    if (h_range[j] <= -(1 << 21) || h_range[3 + j] >= (1 << 21)) return -2;   // not a LiDAR map at this voxel size
+    const unsigned long long span = (unsigned long long)((long long)h_range[3 + j] - h_range[j]);
+    int b = 1;
+    while (b < 63 && (span >> b)) b++;
+    kp.off[j] = h_range[j]; kp.bits[j] = b; key_bits += b;
+  }
+
+  auto root_keys = [&](auto *ka, auto *kb) {     // 32-bit radix keys whenever the packed key fits
+    using K = std::remove_pointer_t<decltype(ka)>;
+    hipLaunchKernelGGL((k_vox_keys<K>), dim3(grid_for(n, B)), dim3(B), 0, s, d_xyz, d_frame, d_poses, n, voxel_size, kp, ka, val);
+    sort_pairs(sc, s, ka, kb, val, vals, n, key_bits);
+    hipLaunchKernelGGL((k_head_flags<K>), dim3(grid_for(n, B)), dim3(B), 0, s, kb, n, 0, flag);
+  };
+  if (key_bits <= 32) root_keys((unsigned int *)k0, (unsigned int *)k0s);
+  else root_keys(k0, k0s);
+  scan_incl(sc, s, flag, rootid, n);
+  if (!sc.ok) return -1;
+  const long NR = last_u32(s, rootid, n);
+  int root_bits = 1;
+  while ((1l << root_bits) < NR) root_bits++;
+
+  VoxParams pr{voxel_size, {thr[0], thr[1], thr[2]}, min_ps, W};
+  Level lv[3];
+  const unsigned long long attr_mask[3] = {0x1ffull, (0x38ull << 9) | 0x1ffull, (0x3full << 9) | 0x1ffull};
+  for (int L = 0; L < 3; L++) {
+    Level &v = lv[L];
+    auto level_keys = [&](auto *ka, auto *kb) {
+      using K = std::remove_pointer_t<decltype(ka)>;
+      hipLaunchKernelGGL((k_make_ck<K>), dim3(grid_for(n, B)), dim3(B), 0, s, rootid, vals, n, attr_mask[L], ka, idx1);
+      sort_pairs(sc, s, ka, kb, idx1, idxL, n, 15 + root_bits);
+      hipLaunchKernelGGL((k_head_flags<K>), dim3(grid_for(n, B)), dim3(B), 0, s, kb, n, 0, flag);
+    };
+    const bool narrow = 15 + root_bits <= 32;
+    if (narrow) level_keys((unsigned int *)k0, (unsigned int *)cks);
+    else level_keys(k0, cks);
+    scan_incl(sc, s, flag, incl, n);
+    if (!sc.ok) return -1;
+    v.NS = last_u32(s, incl, n);
+    auto *seg_start = sc.get<unsigned int>(v.NS + 1);
+    v.seg_ck = sc.get<unsigned long long>(v.NS);
+    v.seg_body = sc.get<double>((size_t)v.NS * 10);
+    auto *seg_world = sc.get<double>((size_t)v.NS * 10);
+    auto *sf = sc.get<unsigned int>(v.NS), *nid = sc.get<unsigned int>(v.NS), *pid = sc.get<unsigned int>(v.NS);
+    if (!sc.ok) return -1;
+    if (narrow)
+      hipLaunchKernelGGL((k_seg_heads<unsigned int>), dim3(grid_for(n, B)), dim3(B), 0, s, (const unsigned int *)cks, incl, n,
+                         seg_start, v.seg_ck);
+    else
+      hipLaunchKernelGGL((k_seg_heads<unsigned long long>), dim3(grid_for(n, B)), dim3(B), 0, s, cks, incl, n, seg_start, v.seg_ck);
+    hipLaunchKernelGGL(k_set_u32, dim3(1), dim3(1), 0, s, seg_start + v.NS, (unsigned int)n);
+    hipLaunchKernelGGL(k_seg_clusters_short, dim3(grid_for(v.NS, B)), dim3(B), 0, s, d_xyz, d_poses, idxL, seg_start, v.seg_ck,
+                       v.NS, v.seg_body, seg_world);
+    hipLaunchKernelGGL(k_seg_clusters_long, dim3(grid_for(v.NS, 4)), dim3(256), 0, s, d_xyz, d_poses, idxL, seg_start, v.seg_ck,
+                       v.NS, v.seg_body, seg_world);
+    hipLaunchKernelGGL((k_head_flags<unsigned long long>), dim3(grid_for(v.NS, B)), dim3(B), 0, s, v.seg_ck, v.NS, 9, sf);
+    scan_incl(sc, s, sf, nid, v.NS);
+    const int pshift = L == 0 ? 0 : (L == 1 ? 15 : 12);
+    if (L > 0) {
+      hipLaunchKernelGGL((k_head_flags<unsigned long long>), dim3(grid_for(v.NS, B)), dim3(B), 0, s, v.seg_ck, v.NS, pshift, sf);
+      scan_incl(sc, s, sf, pid, v.NS);
+    }
+    if (!sc.ok) return -1;
+    v.NN = last_u32(s, nid, v.NS);
+    v.node_seg = sc.get<unsigned int>(v.NN + 1);
+    v.node_parent = sc.get<unsigned int>(v.NN);
+    v.tot = sc.get<NodeTot>(v.NN);
+    v.status = sc.get<unsigned char>(v.NN);
+    v.flag = sc.get<unsigned int>(v.NN + 1);
+    v.fid = sc.get<unsigned int>(v.NN + 1);
+    if (!sc.ok) return -1;
+    hipLaunchKernelGGL(k_level_heads, dim3(grid_for(v.NS, B)), dim3(B), 0, s, v.seg_ck, nid, pid, v.NS, pshift, v.node_seg,
+                       v.node_parent);
+    hipLaunchKernelGGL(k_set_u32, dim3(1), dim3(1), 0, s, v.node_seg + v.NN, (unsigned int)v.NS);
+    hipLaunchKernelGGL(k_node_totals, dim3(grid_for(v.NN * 16, B)), dim3(B), 0, s, seg_world, v.seg_ck, v.node_seg, v.NN, v.tot);
+    hipLaunchKernelGGL(k_node_status, dim3(grid_for(v.NN, 128)), dim3(128), 0, s, v.tot, v.NN, pr.thr[L], pr.min_ps, v.status);
+    hipMemsetAsync(v.flag + v.NN, 0, sizeof(unsigned int), s);
+  }
+  if (lv[0].NN != NR) return -1;
+  unsigned int FL[3];
+  for (int L = 0; L < 3; L++) {
+    hipLaunchKernelGGL(k_feature_flags, dim3(grid_for(lv[L].NN, B)), dim3(B), 0, s, L, lv[L].NN, lv[L].tot, lv[0].status,
+                       lv[1].status, lv[2].status, lv[1].node_parent, lv[2].node_parent, lv[L].flag);
+    scan_excl(sc, s, lv[L].flag, lv[L].fid, lv[L].NN + 1);
+  }
+  if (!sc.ok) return -1;
+  for (int L = 0; L < 3; L++) FL[L] = last_u32(s, lv[L].fid, lv[L].NN + 1);
+  const long F = (long)FL[0] + FL[1] + FL[2];
+  *n_roots = NR;
+  if (hipGetLastError() != hipSuccess) return -1;
+  if (F == 0) return 0;
+  double *out = nullptr, *coe = nullptr;
+  int *lay = nullptr;
+  if (hipMalloc((void **)&out, (size_t)F * W * 10 * sizeof(double)) != hipSuccess ||
+      hipMalloc((void **)&coe, (size_t)F * sizeof(double)) != hipSuccess ||
+      hipMalloc((void **)&lay, (size_t)F * sizeof(int)) != hipSuccess) {
+    if (out) hipFree(out);
+    if (coe) hipFree(coe);
+    return -1;
+  }
+  hipMemsetAsync(out, 0, (size_t)F * W * 10 * sizeof(double), s);
+  unsigned int base = 0;
+  for (int L = 0; L < 3; L++) {
+    hipLaunchKernelGGL(k_emit, dim3(grid_for(lv[L].NN * 16, B)), dim3(B), 0, s, lv[L].NN, lv[L].flag, lv[L].fid, base,
+                       lv[L].node_seg, lv[L].seg_ck, lv[L].seg_body, lv[L].tot, W, L, out, coe, lay);
+    base += FL[L];
+  }
+  if (hipStreamSynchronize(s) != hipSuccess || hipGetLastError() != hipSuccess) {
+    hipFree(out); hipFree(coe); hipFree(lay);
+    return -1;
+  }
+  *F_out = (int)F; *d_out = out; *d_coe = coe; *d_layer = lay;
+  return 0;
+}
+
+}  // namespace balm

@@ -2,9 +2,10 @@
 does around the optimizer (src/benchmark/benchmark_realworld.cpp:144-218) -- read alidarPose.csv and the
 binary PCD scans, express poses relative to pose 0, associate points to plane features by adaptive
 voxelisation (csrc/association.cpp restating bavoxel.hpp's cut_voxel / recut / tras_opt) -- feeding the
-GPU path through the C ABI.  The association is host C++ by design; only the optimizer is on the GPU.
+GPU path through the C ABI.  `associate` is the host C++ association; `associate_gpu` (--gpu-assoc) runs the
+same decisions on the device (balm_associate, csrc/kernels_voxel.hip).
 
-    python -m balm_amd.realworld /path/to/datas/benchmark_realworld [--voxel 2.0]
+    python -m balm_amd.realworld /path/to/datas/benchmark_realworld [--voxel 2.0] [--gpu-assoc]
 """
 import ctypes as C
 import os
@@ -82,6 +83,21 @@ def associate(frames_xyz, poses, voxel_size=2.0, eigen_thresholds=(1.0 / 16, 1.0
     return cl, co, layer
 
 
+def associate_gpu(ctx, frames_xyz, poses, voxel_size=2.0, eigen_thresholds=(1.0 / 16, 1.0 / 16, 1.0 / 9), min_ps=15,
+                  want_features=True):
+    """Same contract as `associate`, on the device through balm_associate; the features are installed in `ctx`."""
+    xyz = np.concatenate([np.ascontiguousarray(f, dtype=np.float32).reshape(-1, 3) for f in frames_xyz])
+    fid = np.concatenate([np.full(f.shape[0], i, dtype=np.int32) for i, f in enumerate(frames_xyz)])
+    return ctx.associate(xyz, fid, poses, voxel_size, eigen_thresholds, min_ps, want_features)
+
+
+def canonical_order(clusters, coeffs):
+    """Order-independent comparison key for feature sets (hash-map order on the host, key order on the device)."""
+    first = np.argmax(clusters[:, :, 9] > 0, axis=1)
+    head = clusters[np.arange(clusters.shape[0]), first]
+    return np.lexsort((head[:, 8], head[:, 7], head[:, 6], first, coeffs))
+
+
 def load_window(data_dir, max_poses=None):
     poses, stamps = read_pose_csv(os.path.join(data_dir, "alidarPose.csv"))
     if max_poses:
@@ -96,24 +112,30 @@ def main(argv=None):
     ap.add_argument("data_dir")
     ap.add_argument("--voxel", type=float, default=2.0)
     ap.add_argument("--device", type=int, default=0)
+    ap.add_argument("--gpu-assoc", action="store_true", help="adaptive voxelisation on the GPU (balm_associate)")
     ap.add_argument("--out", default=None, help="write optimised poses (W x 12) here as .npy")
     a = ap.parse_args(argv)
     from . import capi
     t = time.time()
     poses, frames = load_window(a.data_dir)
     t_read = time.time() - t
+    W = poses.shape[0]
+    ctx = capi.Context(W, a.device)
     t = time.time()
-    cl, co, _ = associate(frames, poses, a.voxel)
+    if a.gpu_assoc:
+        F = associate_gpu(ctx, frames, poses, a.voxel, want_features=False)[0]
+    else:
+        cl, co, _ = associate(frames, poses, a.voxel)
+        F = cl.shape[0]
     t_assoc = time.time() - t
-    W, F = poses.shape[0], cl.shape[0]
     print("The size of poses: %d" % W)                                   # benchmark_realworld.cpp:171
     print("read %d points in %.1f s; %d plane features in %.1f s" % (sum(f.shape[0] for f in frames), t_read, F, t_assoc))
     if F < 3 * W:                                                        # :209-215
         print("Initial error too large.\nPlease loose plane determination criteria for more planes.\n"
               "The optimization is terminated.")
         return 1
-    ctx = capi.Context(W, a.device)
-    ctx.set_features(cl, None, co)
+    if not a.gpu_assoc:
+        ctx.set_features(cl, None, co)
     t = time.time()
     out, lg = ctx.damping_iter(poses, form=capi.FORM_LEFT, u0=0.01, max_iter=10, min_planes=20, verbose=True)
     print("optimised in %d LM iterations, %.2f ms" % (len(lg), (time.time() - t) * 1e3))

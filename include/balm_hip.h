@@ -110,6 +110,27 @@ int balm_build_clusters(balm_ctx *ctx, int F, const float *xyz, const int *feat_
                         const int *pose_id, long n_pts, const double *fix, const double *coeffs,
                         double *clusters_out);
 
+/* Replaces the caller's association stage: cut_voxel over every scan, OCTO_TREE_NODE::recut and
+ * ::tras_opt over every root voxel (bavoxel.hpp:1170-1223, 654-776, 908-929;
+ * benchmark_realworld.cpp:183-200).  Points are body-frame floats with the index (0..W-1) of the
+ * scan they belong to, in scan order; `poses` are the W initial poses.  Every voxel-membership and
+ * plane decision uses the reference's float/double types and operation order, so the feature set
+ * (and every N) equals the reference's.  The features (body-frame clusters, weight = sum_i N_i,
+ * empty fix clusters) are installed like balm_set_features; their order is (layer, voxel key),
+ * not the reference's hash-map order -- the optimizer does not depend on it.  layer_limit is the
+ * reference's 2 (bavoxel.hpp:11).  *F_out = 0 (and BALM_OK) when no plane was found. */
+typedef struct balm_voxel_opts {
+  double voxel_size;        /* benchmark_realworld.cpp:150 -> 1.0 in the shipped launch file    */
+  float eigen_thr[3];       /* per layer; bavoxel.hpp:11 / launch file: 1/16, 1/16, 1/9         */
+  int min_ps;               /* bavoxel.hpp:12: 15                                               */
+} balm_voxel_opts;
+int balm_associate(balm_ctx *ctx, const balm_voxel_opts *opts, const float *xyz, const int *frame_id,
+                   long n_pts, const double *poses, int *F_out, long *n_root_voxels);
+
+/* Host copies of the feature table installed by the last balm_associate: clusters F*W*10, coeffs F,
+ * layer F (octree depth of the feature's voxel).  Any pointer may be NULL. */
+int balm_get_features(balm_ctx *ctx, double *clusters, double *coeffs, int *layer);
+
 /* Multi-GPU: features are sharded across one-process-per-GPU ranks; each rank installs its shard
  * with balm_set_features and a hook that sums a device buffer of n doubles across ranks in place
  * (RCCL allreduce over xGMI; replaces the serial `Hess += hessians[i]` at bavoxel.hpp:1049-1056).
@@ -128,7 +149,8 @@ enum {
   BALM_T_SOLVE = 4,     /* permute + blocked LDL^T + triangular solves                        */
   BALM_T_UPDATE = 5,    /* pose update + gain-ratio scalars                                   */
   BALM_T_BUILD = 6,     /* cluster build from points (balm_build_clusters kernel only)        */
-  BALM_T_COUNT = 7
+  BALM_T_VOXEL = 7,     /* adaptive-voxel association (balm_associate, device part only)      */
+  BALM_T_COUNT = 8
 };
 int balm_get_timing(balm_ctx *ctx, double *ms, long *count);
 int balm_reset_timing(balm_ctx *ctx);

@@ -60,9 +60,53 @@ class BALM2_HIP {
     return r;
   }
 
+  // Replaces the association block of the reference's drivers (benchmark_realworld.cpp:183-200: cut_voxel per
+  // scan into the surf_map, OCTO_TREE_ROOT::recut, ::tras_opt -> VOX_HESS::push_voxel) with one device call.
+  // Reads the same globals the reference's code reads: win_size, voxel_size, eigen_value_array, min_ps
+  // (bavoxel.hpp:11-17); layer_limit must be the reference's 2.  `Cloud` is pcl::PointCloud<PointType>::Ptr (any
+  // pointer to a container of points with float x, y, z).  Returns the number of plane features, which are
+  // installed on the device: follow with damping_iter(x_stats).
+  template <class CloudPtr>
+  int associate(const std::vector<CloudPtr> &pl_fulls, const std::vector<IMUST> &x_buf) {
+    ensure_ctx();
+    if (layer_limit != 2 || (int)pl_fulls.size() != win_size || (int)x_buf.size() != win_size) {
+      fprintf(stderr, "balm_hip: associate needs layer_limit == 2 and win_size scans and poses\n");
+      abort();
+    }
+    size_t n = 0;
+    for (const CloudPtr &pl : pl_fulls) n += pl->size();
+    std::vector<float> xyz(3 * n);
+    std::vector<int> frame(n);
+    size_t k = 0;
+    for (int i = 0; i < win_size; i++)
+      for (const auto &pt : *pl_fulls[(size_t)i]) {
+        xyz[3 * k] = pt.x; xyz[3 * k + 1] = pt.y; xyz[3 * k + 2] = pt.z;
+        frame[k++] = i;
+      }
+    std::vector<double> poses = flatten_poses(x_buf);
+    balm_voxel_opts o;
+    o.voxel_size = voxel_size;
+    for (int l = 0; l < 3; l++) o.eigen_thr[l] = eigen_value_array[l];
+    o.min_ps = min_ps;
+    int F = 0;
+    long roots = 0;
+    check(balm_associate(ctx_, &o, xyz.data(), frame.data(), (long)n, poses.data(), &F, &roots));
+    loaded_ = (const void *)this;        // the device features no longer mirror a VOX_HESS
+    loaded_F_ = (size_t)F;
+    return F;
+  }
+
+  // damping_iter on the features installed by associate()
+  void damping_iter(std::vector<IMUST> &x_stats) { run_lm(x_stats); }
+
   // bavoxel.hpp:1069
   void damping_iter(std::vector<IMUST> &x_stats, VOX_HESS &voxhess) {
     upload(voxhess, /*force=*/true);      // one upload per optimisation: the container may have been refilled
+    run_lm(x_stats);
+  }
+
+ private:
+  void run_lm(std::vector<IMUST> &x_stats) {
     std::vector<double> poses = flatten_poses(x_stats);
     balm_lm_opts o;
     o.form = form; o.u0 = u0; o.max_iter = max_iter; o.rel_tol = rel_tol;
@@ -87,7 +131,6 @@ class BALM2_HIP {
     }
   }
 
- private:
   balm_ctx *ctx_ = nullptr;
   int ctx_win_ = 0;
   const void *loaded_ = nullptr;

@@ -92,6 +92,18 @@ int main(int argc, char **argv) {
   BALM2_HIP opt_hip;
   opt_hip.damping_iter(x_hip, voxhess);                       // shim -> libbalm_hip.so, GPU
 
+  // ---- association on the device too: scans -> BALM2_HIP::associate -> damping_iter -----------------
+  std::vector<IMUST> x_dev = x_buf;
+  BALM2_HIP opt_dev;
+  opt_dev.verbose = false;
+  const int nfeat_dev = opt_dev.associate(pl_fulls, x_dev);
+  opt_dev.damping_iter(x_dev);
+  double dev_rot = 0, dev_tr = 0;
+  for (int i = 0; i < W; i++) {
+    dev_rot = std::max(dev_rot, Log(x_ref[i].R.transpose() * x_dev[i].R).norm());
+    dev_tr = std::max(dev_tr, (x_ref[i].p - x_dev[i].p).norm());
+  }
+
   double max_rot = 0, max_tr = 0;
   for (int i = 0; i < W; i++) {
     Eigen::Vector3d l = Log(x_ref[i].R.transpose() * x_hip[i].R);
@@ -107,8 +119,10 @@ int main(int argc, char **argv) {
   for (int c = 0; c < 6 * W; c++) for (int r = 0; r < 6 * W; r++) {
     hmax = std::max(hmax, std::fabs(H1(r, c))); hdiff = std::max(hdiff, std::fabs(H1(r, c) - H2(r, c)));
   }
-  printf("SHIM_DRIVER features=%zu iters_hip=%zu max_rot=%.3e max_trans=%.3e resid_rel=%.3e hess_rel=%.3e\n", nfeat,
-         opt_hip.last_log.size(), max_rot, max_tr, std::fabs(r1 - r2) / r1, hdiff / hmax);
+  printf("SHIM_DRIVER features=%zu iters_hip=%zu max_rot=%.3e max_trans=%.3e resid_rel=%.3e hess_rel=%.3e "
+         "dev_features=%d dev_rot=%.3e dev_trans=%.3e\n", nfeat,
+         opt_hip.last_log.size(), max_rot, max_tr, std::fabs(r1 - r2) / r1, hdiff / hmax, nfeat_dev, dev_rot, dev_tr);
   for (auto &kv : surf_map) delete kv.second;
-  return (max_rot <= 1e-5 && max_tr <= 1e-4 && hdiff / hmax < 1e-10) ? 0 : 1;
+  return (max_rot <= 1e-5 && max_tr <= 1e-4 && hdiff / hmax < 1e-10 && (size_t)nfeat_dev == nfeat && dev_rot <= 1e-5 &&
+          dev_tr <= 1e-4) ? 0 : 1;
 }

@@ -1,0 +1,179 @@
+"""N3: adaptive-voxel association on the GPU (balm_associate, csrc/kernels_voxel.hip) against
+the host association (csrc/association.cpp, itself pinned bit-exact to the reference's cut_voxel / recut /
+tras_opt in test_association.py) and against a fixture made by the reference's own code from the shipped
+scans.  Index / integer work: the feature SET is compared bit for bit (every cluster, every N); the order
+differs by design (hash-map order vs key order)."""
+import os
+
+import numpy as np
+import pytest
+
+from balm_amd import capi
+from balm_amd import realworld as rw
+from conftest import ROOT
+from oracle import numpy_oracle as npo
+from test_association import canon, synthetic_window
+
+pytestmark = pytest.mark.gpu
+
+
+def cluttered_window(seed, W, n_planes, pts_per_plane, n_clutter):
+    """scans of a box-like scene: planar patches of several sizes (so that root voxels, octants and
+    sub-octants all become features) plus uniform clutter (non-planar voxels that split and die)"""
+    rng = np.random.default_rng(seed)
+    R = np.stack([npo.exp_so3(0.02 * rng.standard_normal(3)) for _ in range(W)])
+    p = np.cumsum(0.15 * rng.standard_normal((W, 3)), axis=0)
+    R[0], p[0] = np.eye(3), 0
+    frames = []
+    normals = rng.standard_normal((n_planes, 3))
+    normals /= np.linalg.norm(normals, axis=1, keepdims=True)
+    centers = rng.uniform(-12, 12, (n_planes, 3))
+    sizes = rng.choice([0.3, 0.8, 2.5], n_planes)
+    for i in range(W):
+        world = []
+        for k in range(n_planes):
+            a = np.cross(normals[k], [0.3, 0.5, 0.8]); a /= np.linalg.norm(a)
+            b = np.cross(normals[k], a)
+            uv = rng.uniform(-sizes[k], sizes[k], (pts_per_plane, 2))
+            world.append(centers[k] + uv[:, :1] * a + uv[:, 1:] * b + 0.01 * rng.standard_normal((pts_per_plane, 1)) * normals[k])
+        world.append(rng.uniform(-12, 12, (n_clutter, 3)))
+        world = np.concatenate(world)
+        world = world[rng.permutation(world.shape[0])]
+        frames.append(((world - p[i]) @ R[i]).astype(np.float32))      # body = R^T (w - p)
+    return npo.make_poses(R, p), frames
+
+
+def check_same_features(ctx, frames, poses, voxel, thr=(1.0 / 16, 1.0 / 16, 1.0 / 9), min_ps=15):
+    cl_h, co_h, layer_h = rw.associate(frames, poses, voxel, thr, 2, min_ps)
+    F, nroots, feats = rw.associate_gpu(ctx, frames, poses, voxel, thr, min_ps)
+    assert F == cl_h.shape[0]
+    if F == 0:
+        return cl_h, layer_h
+    cl_g, co_g, layer_g = feats
+    assert np.array_equal(canon(cl_g), canon(cl_h))                    # bit-exact feature set
+    assert np.array_equal(np.sort(co_g), np.sort(co_h))
+    assert np.array_equal(np.bincount(layer_g, minlength=3), np.bincount(layer_h, minlength=3))
+    assert np.array_equal(co_g, cl_g[..., 9].sum(1))
+    return cl_g, layer_g
+
+
+@pytest.mark.parametrize("seed,W,voxel", [(1, 8, 1.0), (2, 20, 2.0), (3, 5, 4.0), (4, 33, 0.5)])
+def test_device_association_matches_host_on_cluttered_scans(seed, W, voxel):
+    poses, frames = cluttered_window(seed, W, 60, 120, 3000)
+    c = capi.Context(W)
+    cl, layer = check_same_features(c, frames, poses, voxel)
+    assert cl.shape[0] > 10
+    if voxel <= 2.0:
+        assert len(set(layer.tolist())) >= 2                            # several octree depths exercised
+    c.close()
+
+
+def test_device_association_feeds_the_optimizer():
+    """installing through balm_associate == installing the host association's features through balm_set_features"""
+    poses, frames = synthetic_window(1, 20, 150, 40)
+    c = capi.Context(20)
+    cl, _ = check_same_features(c, frames, poses, 1.0)
+    out_g, lg_g = c.damping_iter(poses, form=0, u0=0.01, max_iter=10, min_planes=20)
+    cl_h, co_h, _ = rw.associate(frames, poses, 1.0)
+    c2 = capi.Context(20)
+    c2.set_features(cl_h, None, co_h)
+    out_h, lg_h = c2.damping_iter(poses, form=0, u0=0.01, max_iter=10, min_planes=20)
+    assert len(lg_g) == len(lg_h)
+    assert np.abs(lg_g[:, :2] - lg_h[:, :2]).max() <= 1e-9 * lg_h[0, 0]     # feature order changes the summation order only
+    assert np.abs(out_g - out_h).max() < 1e-6          # well inside the path's pose tolerance (1e-5 rad / 1e-4 m)
+    c.close(); c2.close()
+
+
+def test_device_association_edge_cases():
+    c = capi.Context(4)
+    # nothing planar / too few points: zero features is a result, not an error; the context stays usable
+    rng = np.random.default_rng(0)
+    frames = [rng.uniform(-3, 3, (10, 3)).astype(np.float32) for _ in range(4)]
+    poses = npo.make_poses(np.stack([np.eye(3)] * 4), np.zeros((4, 3)))
+    F, nroots, feats = rw.associate_gpu(c, frames, poses, 1.0)
+    assert F == 0 and feats is None and nroots > 0
+    with pytest.raises(capi.BalmError):
+        c.evaluate(0, poses)
+    # a plane seen by ONE scan only is not a feature (push_voxel needs two observers, bavoxel.hpp:32-37);
+    # negative coordinates exercise the `loc < 0 -> loc - 1` key rule; empty scans are legal
+    uv = rng.uniform(-0.4, 0.4, (200, 2))
+    plane = np.column_stack([uv[:, 0] - 5.5, uv[:, 1] - 7.5, np.full(200, -2.5) + 0.002 * rng.standard_normal(200)])
+    frames = [plane.astype(np.float32), np.zeros((0, 3), np.float32), np.zeros((0, 3), np.float32), np.zeros((0, 3), np.float32)]
+    assert rw.associate_gpu(c, frames, poses, 1.0)[0] == 0 == rw.associate(frames, poses, 1.0)[0].shape[0]
+    frames[2] = plane[::-1].astype(np.float32).copy()
+    check_same_features(c, frames, poses, 1.0)
+    assert c.F >= 1
+    with pytest.raises(capi.BalmError):                                    # frame id out of range
+        c.associate(plane.astype(np.float32), np.full(200, 4, np.int32), poses, 1.0)
+    c.close()
+
+
+def test_device_association_matches_reference_on_shipped_scans():
+    """first 24 scans of the shipped benchmark_realworld window (1.76 M points) against the features the
+    reference's own cut_voxel/recut/tras_opt produced from them (tools/make_realworld_fixture.py)"""
+    path = os.path.join(ROOT, "oracle", "_ref", "realworld_scans_w24.npz")
+    if not os.path.exists(path):
+        pytest.skip("oracle/_ref/realworld_scans_w24.npz not built (needs /root/reference/datas)")
+    g = np.load(path)
+    counts = g["counts"]
+    frames = np.split(g["xyz"], np.cumsum(counts)[:-1])
+    c = capi.Context(len(counts), flags=capi.FLAG_TIMING)
+    F, nroots, (cl, co, layer) = rw.associate_gpu(c, frames, g["poses"], 2.0)
+    assert cl.shape == g["clusters"].shape
+    assert np.array_equal(canon(cl), canon(g["clusters"]))
+    assert np.array_equal(np.sort(co), np.sort(g["coeffs"]))
+    ms, n = c.timing()["voxel"]
+    print("balm_associate: %d points -> %d root voxels, %d features, device %.2f ms" % (counts.sum(), nroots, F, ms))
+    c.close()
+
+
+def test_benchmark_realworld_end_to_end_from_raw_scans():
+    """BASELINE configs[4] with nothing on the CPU between the files and the result: the 177 shipped scans
+    (13.4 M points) -> balm_associate -> device LM loop, against the reference's feature set (bit for bit)
+    and the poses the reference's BALM2::damping_iter reaches from them."""
+    scans = os.path.join(ROOT, "oracle", "_ref", "realworld_scans_w177.npz")
+    feats = os.path.join(ROOT, "oracle", "_ref", "realworld_features.npz")
+    if not (os.path.exists(scans) and os.path.exists(feats)):
+        pytest.skip("oracle/_ref/realworld_scans_w177.npz not built (needs /root/reference/datas)")
+    from util import ROT_TOL_RAD, TRANS_TOL_M, pose_errors
+    g, sdat = np.load(feats), np.load(scans)
+    counts = sdat["counts"]
+    xyz = sdat["xyz"]
+    fid = np.repeat(np.arange(len(counts), dtype=np.int32), counts)
+    c = capi.Context(len(counts), flags=capi.FLAG_TIMING)
+    c.associate(xyz, fid, g["poses"], 2.0, want_features=False)          # warm-up: sizes the scratch arena
+    c.reset_timing()
+    F, nroots, (cl, co, layer) = c.associate(xyz, fid, g["poses"], 2.0)
+    ms = c.timing()["voxel"][0]
+    assert cl.shape == g["clusters"].shape == (2281, 177, 10)
+    assert np.array_equal(canon(cl), canon(g["clusters"]))
+    assert list(np.bincount(layer)) == [797, 449, 1035]
+    out, lg = c.damping_iter(g["poses"], form=0, u0=0.01, max_iter=10, min_planes=20)
+    assert len(lg) == len(g["ref_log"])
+    rot, tr = pose_errors(out, g["ref_poses"])
+    assert rot.max() <= ROT_TOL_RAD and tr.max() <= TRANS_TOL_M
+    print("realworld from raw scans: %d points -> %d roots -> %d features in %.2f ms (reference CPU %.1f s); "
+          "LM %d iterations; pose diff %.1e rad %.1e m"
+          % (xyz.shape[0], nroots, F, ms, float(g["ref_seconds_association"]), len(lg), rot.max(), tr.max()))
+    c.close()
+
+
+def test_device_association_wide_keys():
+    """fine voxels over a large extent: the packed root key needs more than 32 bits and there are more than 2^17
+    root voxels, so both sorts take their 64-bit-key path (the common case runs on 32-bit keys)"""
+    rng = np.random.default_rng(11)
+    W = 3
+    poses = npo.make_poses(np.stack([npo.exp_so3(0.001 * rng.standard_normal(3)) for _ in range(W)]),
+                           0.0005 * rng.standard_normal((W, 3)))
+    frames = []
+    for i in range(W):
+        uv = rng.uniform(-0.003, 0.003, (400, 2))
+        patch = np.column_stack([5.002 + uv[:, 0], -3.004 + uv[:, 1], np.full(400, 1.005) + 2e-5 * rng.standard_normal(400)])
+        clutter = rng.uniform(-12, 12, (70000, 3))
+        pts = np.concatenate([patch, clutter])[rng.permutation(70400)]
+        R, p = npo.pose_R(poses)[i], npo.pose_p(poses)[i]
+        frames.append(((pts - p) @ R).astype(np.float32))
+    c = capi.Context(W)
+    cl, layer = check_same_features(c, frames, poses, 0.01)
+    assert cl.shape[0] >= 1
+    c.close()

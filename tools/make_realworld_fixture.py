@@ -25,3 +25,32 @@ nobs = (cl[..., 9] > 0).sum(1)
 print("W=%d F=%d S=%d points=%d  association %.1f s, reference LM %d iterations in %.2f s -> %s (%.1f MB)"
       % (cl.shape[1], cl.shape[0], nobs.sum(), npts, t_assoc, len(lg), t_lm, dst, os.path.getsize(dst) / 1e6))
 print(lg[:, :3])
+
+# --- sub-window with its raw scans, for the device association (N3): first 24 scans, the reference's own
+# cut_voxel/recut/tras_opt on them -> oracle/_ref/realworld_scans_w24.npz (~25 MB, git-ignored, travels)
+import tempfile
+from balm_amd import realworld as rw
+WS = 24
+with tempfile.TemporaryDirectory() as tmp:
+    with open(os.path.join(src, "alidarPose.csv")) as f:
+        lines = f.readlines()
+    with open(os.path.join(tmp, "alidarPose.csv"), "w") as f:
+        f.writelines(lines[:4 * WS])
+    for m in range(WS):
+        os.symlink(os.path.join(src, "full%d.pcd" % m), os.path.join(tmp, "full%d.pcd" % m))
+    cl, fx, co, poses, npts = ref.realworld_features(tmp, 2.0)
+    poses_p, frames = rw.load_window(tmp)
+assert np.abs(poses_p - poses).max() < 1e-13 and sum(f.shape[0] for f in frames) == npts
+dst = os.path.join(ROOT, "oracle", "_ref", "realworld_scans_w%d.npz" % WS)
+np.savez_compressed(dst, xyz=np.concatenate(frames), counts=np.array([f.shape[0] for f in frames]), poses=poses,
+                    clusters=cl, coeffs=co)
+print("sub-window W=%d: %d points, %d features -> %s (%.1f MB)" % (WS, npts, cl.shape[0], dst, os.path.getsize(dst) / 1e6))
+
+# --- the whole window's raw scans (13.4 M points, ~150 MB; git-ignored, travels): lets the GPU box run
+# benchmark_realworld end to end (scans -> balm_associate -> LM) against the reference's features and poses
+poses_p, frames = rw.load_window(src)
+g = np.load(os.path.join(ROOT, "oracle", "_ref", "realworld_features.npz"))
+assert np.abs(poses_p - g["poses"]).max() < 1e-13 and sum(f.shape[0] for f in frames) == int(g["n_points"])
+dst = os.path.join(ROOT, "oracle", "_ref", "realworld_scans_w177.npz")
+np.savez_compressed(dst, xyz=np.concatenate(frames), counts=np.array([f.shape[0] for f in frames]))
+print("full window: %d scans -> %s (%.1f MB)" % (len(frames), dst, os.path.getsize(dst) / 1e6))

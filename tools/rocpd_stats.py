@@ -13,5 +13,5 @@ rows = cur.execute("select %s, count(*), sum(end-start), avg(end-start), min(end
 tot = sum(r[2] for r in rows) or 1
 print('"Name","Calls","TotalDurationNs","AverageNs","MinNs","MaxNs","Percentage"')
 for r in rows:
-    nm = r[0].split("(")[0]
+    nm = r[0].replace("(anonymous namespace)::", "").split("(")[0]
     print('"%s",%d,%d,%.1f,%d,%d,%.2f' % (nm, r[1], r[2], r[3], r[4], r[5], 100.0 * r[2] / tot))
