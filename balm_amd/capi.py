@@ -14,12 +14,12 @@ LIB_PATH = os.path.join(_HERE, "lib", "libbalm_hip.so")
 FORM_LEFT, FORM_RIGHT = 0, 1
 OK, ERR_ARG, ERR_HIP, ERR_STATE, ERR_TOO_FEW_PLANES, ERR_NUMERIC = range(6)
 FLAG_TIMING = 1
-T_MOMENTS, T_FACTORS, T_SYRK, T_ASSEMBLE, T_SOLVE, T_UPDATE, T_BUILD, T_VOXEL, T_COUNT = range(9)
-TIMING_NAMES = ["moments", "factors", "syrk", "assemble", "solve", "update", "build", "voxel"]
+T_MOMENTS, T_FACTORS, T_SYRK, T_ASSEMBLE, T_SOLVE, T_UPDATE, T_BUILD, T_VOXEL, T_COV, T_COUNT = range(10)
+TIMING_NAMES = ["moments", "factors", "syrk", "assemble", "solve", "update", "build", "voxel", "cov"]
 
 # every symbol include/balm_hip.h declares
 EXPORTS = ["balm_create", "balm_destroy", "balm_set_features", "balm_evaluate", "balm_only_residual",
-           "balm_solve_damped", "balm_damping_iter", "balm_build_clusters", "balm_associate", "balm_get_features",
+           "balm_solve_damped", "balm_damping_iter", "balm_build_clusters", "balm_associate", "balm_get_features", "balm_pose_covariance",
            "balm_set_allreduce",
            "balm_get_timing", "balm_reset_timing", "balm_work_model", "balm_last_error", "balm_version"]
 
@@ -32,7 +32,7 @@ class IterLog(C.Structure):
 class LMOpts(C.Structure):
     _fields_ = [("form", C.c_int), ("u0", C.c_double), ("max_iter", C.c_int), ("rel_tol", C.c_double),
                 ("min_planes_per_pose", C.c_int), ("force_hess", C.c_int), ("no_stop", C.c_int),
-                ("verbose", C.c_int), ("reanchor", C.c_int)]
+                ("verbose", C.c_int), ("reanchor", C.c_int), ("abs_tol", C.c_double)]
 
 
 class VoxelOpts(C.Structure):
@@ -74,6 +74,7 @@ def lib():
         L.balm_associate.argtypes = [C.c_void_p, C.POINTER(VoxelOpts), C.c_void_p, C.c_void_p, C.c_long, C.c_void_p,
                                      C.POINTER(C.c_int), C.POINTER(C.c_long)]
         L.balm_get_features.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.balm_pose_covariance.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p]
         L.balm_set_allreduce.argtypes = [C.c_void_p, ALLREDUCE_FN, C.c_void_p]
         L.balm_get_timing.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.balm_reset_timing.argtypes = [C.c_void_p]
@@ -160,6 +161,17 @@ class Context:
             feats = (cl, co, layer)
         return self.F, nr.value, feats
 
+    def pose_covariance(self, poses, cluster_cov=None, point_sigma=0.0, want_raw=True):
+        """-> (Rcov [n,n], Rcov_raw [n,n] or None): H^-1 Rcov_raw H^-T and the point-noise image sum Ls c_cov Ls^T"""
+        poses = _c(poses)
+        cc = None
+        if cluster_cov is not None:
+            cc = _c(cluster_cov).reshape(self.F, self.W, 81)
+        R = np.zeros((self.n, self.n))
+        Rraw = np.zeros((self.n, self.n)) if want_raw else None
+        self._check(self.L.balm_pose_covariance(self.h, _p(poses), _p(cc), float(point_sigma), _p(R), _p(Rraw)))
+        return R, Rraw
+
     def evaluate(self, form, poses, head=0, end=None, want_hess=True):
         """-> (Hess [n,n] or None, JacT [n], residual)"""
         poses = _c(poses)
@@ -187,11 +199,11 @@ class Context:
         return dx, q1.value
 
     def damping_iter(self, poses, form=FORM_LEFT, u0=0.01, max_iter=10, rel_tol=1e-6, min_planes=0,
-                     force_hess=False, no_stop=False, verbose=False, reanchor=True):
+                     force_hess=False, no_stop=False, verbose=False, reanchor=True, abs_tol=0.0):
         """-> (poses_out [W,12], log [iters, 8]: r1 r2 u v q q1 accepted hess_evaluated)"""
         out = _c(poses).copy()
         o = LMOpts(form, u0, max_iter, rel_tol, min_planes, int(force_hess), int(no_stop), int(verbose),
-                   int(reanchor))
+                   int(reanchor), abs_tol)
         lg = (IterLog * max_iter)()
         it = C.c_int(0)
         self._check(self.L.balm_damping_iter(self.h, C.byref(o), _p(out), lg, C.byref(it)))

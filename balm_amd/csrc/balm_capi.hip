@@ -404,6 +404,70 @@ int balm_get_features(balm_ctx *ctx, double *clusters, double *coeffs, int *laye
   return BALM_OK;
 }
 
+int balm_pose_covariance(balm_ctx *ctx, const double *poses, const double *cluster_cov, double point_sigma, double *Rcov,
+                         double *Rcov_raw) {
+  if (!ctx) return BALM_ERR_ARG;
+  if (ctx->F < 1) { ctx->err = "balm_pose_covariance: no features installed"; return BALM_ERR_STATE; }
+  if (!poses || (!cluster_cov && !(point_sigma > 0))) { ctx->err = "balm_pose_covariance: bad argument"; return BALM_ERR_ARG; }
+  HIP_TRY(hipSetDevice(ctx->device));
+  const int W = ctx->W, n = ctx->n, nA = ctx->nA, F = ctx->F;
+  hipStream_t s = ctx->stream;
+  HIP_TRY(hipMemcpyAsync(ctx->d_poses, poses, (size_t)12 * W * sizeof(double), hipMemcpyHostToDevice, s));
+  ctx->feat_cur_valid = false;
+  int rc = evaluate_device(ctx, BALM_FORM_LEFT, ctx->d_poses, 0, F, 0);     // d_H, and the eigen records in d_feat
+  ctx->feat_cur_valid = false;
+  if (rc) return rc;
+  const SyrkPlan plan = plan_syrk(ctx->ntiles, 3L * F);
+  const size_t gcols = (size_t)plan.Kpad + 64, tiles = (size_t)ctx->ntiles * TILE_ELEMS;
+  if ((rc = ensure(ctx, &ctx->d_Gt, &ctx->cap_Gt, 2 * gcols * ctx->npad))) return rc;
+  if ((rc = ensure(ctx, &ctx->d_part, &ctx->cap_part, (size_t)plan.SG * tiles))) return rc;
+  const int nblk = cov_factors_grid(W, F);
+  if ((rc = ensure(ctx, &ctx->d_dpart, &ctx->cap_dpart, (size_t)nblk * DACC_MAX * W))) return rc;
+  // scratch: [redX | redY | S (21 W)] (one all-reduce payload) | Rraw | tmp | Rcov | Z (nA x n)
+  const size_t pay = 2 * tiles + (size_t)21 * W, nn = (size_t)n * n;
+  double *buf = nullptr, *d_cc = nullptr;
+  HIP_TRY(hipMalloc((void **)&buf, (pay + 3 * nn + (size_t)nA * n) * sizeof(double)));
+  double *redx = buf, *redy = buf + tiles, *sdiag = buf + 2 * tiles, *Rraw = buf + pay, *tmp = Rraw + nn, *Rc = tmp + nn,
+         *Z = Rc + nn;
+  hipError_t e = hipSuccess;
+  if (cluster_cov) {
+    e = hipMalloc((void **)&d_cc, (size_t)F * W * 81 * sizeof(double));
+    if (e == hipSuccess) e = hipMemcpyAsync(d_cc, cluster_cov, (size_t)F * W * 81 * sizeof(double), hipMemcpyHostToDevice, s);
+  }
+  double *Gx = ctx->d_Gt, *Gy = ctx->d_Gt + gcols * ctx->npad;
+  if (e == hipSuccess) {
+    Span sp(ctx, BALM_T_COV);
+    const size_t k0 = (size_t)3 * F;
+    hipMemsetAsync(Gx + k0 * ctx->npad, 0, (gcols - k0) * ctx->npad * sizeof(double), s);
+    hipMemsetAsync(Gy + k0 * ctx->npad, 0, (gcols - k0) * ctx->npad * sizeof(double), s);
+    launch_cov_factors(s, ctx->d_cl, d_cc, point_sigma * point_sigma, ctx->d_poses, ctx->d_feat, W, ctx->npad, F, Gx, Gy,
+                       ctx->d_dpart, nblk);
+    launch_syrk(s, Gx, ctx->npad, ctx->ntiles, ctx->d_tileIJ, plan, ctx->d_part);
+    launch_cov_reduce_tiles(s, ctx->d_part, plan.SG, (long)tiles, redx);
+    launch_syrk(s, Gy, ctx->npad, ctx->ntiles, ctx->d_tileIJ, plan, ctx->d_part);
+    launch_cov_reduce_tiles(s, ctx->d_part, plan.SG, (long)tiles, redy);
+    launch_cov_reduce_dacc(s, ctx->d_dpart, nblk, W, sdiag);
+  }
+  if (e == hipSuccess) rc = hook_allreduce(ctx, buf, (long)pay);
+  if (e == hipSuccess && !rc) {
+    Span sp(ctx, BALM_T_COV);
+    launch_cov_assemble(s, redx, redy, sdiag, ctx->d_tileIJ, ctx->ntiles, W, Rraw);
+    hipMemsetAsync(ctx->d_g, 0, (size_t)n * sizeof(double), s);
+    launch_solve(ctx, 0.0, true);                        // P H P^T = L D L^T stays in d_A / d_dvec / d_perm
+    launch_congruence_inverse(ctx, Rraw, Z, tmp, Rc);
+    if (Rcov) e = hipMemcpyAsync(Rcov, Rc, nn * sizeof(double), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess && Rcov_raw) e = hipMemcpyAsync(Rcov_raw, Rraw, nn * sizeof(double), hipMemcpyDeviceToHost, s);
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  if (e == hipSuccess) e = hipGetLastError();
+  hipFree(buf);
+  if (d_cc) hipFree(d_cc);
+  if (rc) return rc;
+  HIP_TRY(e);
+  collect_timing(ctx);
+  return BALM_OK;
+}
+
 int balm_set_allreduce(balm_ctx *ctx, balm_allreduce_fn fn, void *user) {
   if (!ctx) return BALM_ERR_ARG;
   ctx->allreduce = fn;
@@ -528,6 +592,7 @@ int balm_damping_iter(balm_ctx *ctx, const balm_lm_opts *o, double *poses, balm_
     }
     it++;
     if (!o->no_stop && std::fabs(r1 - r2) / r1 < o->rel_tol) break;   // :1155
+    if (!o->no_stop && o->abs_tol > 0 && std::fabs(r1 - r2) < o->abs_tol) break;   // BAs_left.hpp:1083
   }
   ctx->feat_cur_valid = false;
   if (o->reanchor) launch_reanchor(s, W, ctx->d_poses);

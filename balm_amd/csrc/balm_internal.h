@@ -120,6 +120,15 @@ void launch_reanchor(hipStream_t s, int W, double *poses);
 int associate_device(hipStream_t s, const float *d_xyz, const int *d_frame, const double *d_poses, long n, int W,
                      double voxel_size, const float thr[3], int min_ps, void *arena, size_t arena_cap, size_t *arena_need,
                      int *F_out, double **d_out, double **d_coe, int **d_layer, long *n_roots);
+// launchers (kernels_cov.hip)
+int cov_factors_grid(int W, int F);
+void launch_cov_factors(hipStream_t s, const double *cl, const double *ccov, double sigma2, const double *poses,
+                        const double *feat, int W, int npad, int F, double *Gx, double *Gy, double *dpart, int nblk);
+void launch_cov_reduce_tiles(hipStream_t s, const double *part, int SG, long tile_total, double *red);
+void launch_cov_reduce_dacc(hipStream_t s, const double *dpart, int nblk, int W, double *out);
+void launch_cov_assemble(hipStream_t s, const double *redx, const double *redy, const double *sdiag, const int *tileIJ,
+                         int ntiles, int W, double *Rout);
+void launch_congruence_inverse(balm_ctx *c, const double *Rraw, double *Z, double *tmp, double *Rcov);
 void launch_build_clusters(hipStream_t s, const float *xyz, const int *feat_id, const int *pose_id, long n_pts,
                            int F, int W, double *soa);
 void launch_soa_to_aos(hipStream_t s, const double *soa, double *aos, int F, int W);

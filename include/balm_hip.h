@@ -62,6 +62,8 @@ typedef struct balm_lm_opts {
   int no_stop;              /* benchmarking: ignore the rel_tol stop, run max_iter           */
   int verbose;              /* print the reference's per-iteration line                      */
   int reanchor;             /* express poses relative to pose 0 at the end (:1159-1164)      */
+  double abs_tol;           /* > 0: also stop when |r1-r2| < abs_tol (the consistency driver's
+                               criterion, src/simulation/BAs_left.hpp:1083, 1e-9 with max_iter 1000) */
 } balm_lm_opts;
 
 /* Replaces the global `int win_size` (bavoxel.hpp:17) + object construction.  `device` is the
@@ -131,6 +133,19 @@ int balm_associate(balm_ctx *ctx, const balm_voxel_opts *opts, const float *xyz,
  * layer F (octree depth of the feature's voxel).  Any pointer may be NULL. */
 int balm_get_features(balm_ctx *ctx, double *clusters, double *coeffs, int *layer);
 
+/* Replaces the covariance tail of the consistency experiment's BALM2::damping_iter
+ * (src/simulation/BAs_left.hpp:1089-1096): Hess at `poses` (left form), VOX_HESS::left_jacobian_point summed
+ * over all features (:342-473; BALM2::multi_second :995-1023) and `Rcov = Hess^-1 Rcov Hess^-T`.
+ * `cluster_cov` (F*W*81, row-major 9x9 per cluster, coordinates Pxx Pxy Pxz Pyy Pyz Pzz vx vy vz) is the
+ * PointCluster::c_cov of src/simulation/toolss.hpp:289,345; NULL means the isotropic point noise that
+ * PointCluster::push accumulates (toolss.hpp:321-345, p_cov = point_sigma^2 I), rebuilt on the device from the
+ * clusters themselves.  The reference's feature weight there is 1 (BAs_left.hpp:44); installed weights != 1
+ * scale a feature's contribution like its gradient.  Rcov and Rcov_raw (either may be NULL) are (6W)x(6W),
+ * symmetric.  Hess must be non-singular (a fix cluster or another gauge anchor), as in the reference.
+ * NEES (consistency.cpp:159-170) = 2*q1 of balm_solve_damped(ctx, Rcov, -err, 0, x, &q1). */
+int balm_pose_covariance(balm_ctx *ctx, const double *poses, const double *cluster_cov, double point_sigma,
+                         double *Rcov, double *Rcov_raw);
+
 /* Multi-GPU: features are sharded across one-process-per-GPU ranks; each rank installs its shard
  * with balm_set_features and a hook that sums a device buffer of n doubles across ranks in place
  * (RCCL allreduce over xGMI; replaces the serial `Hess += hessians[i]` at bavoxel.hpp:1049-1056).
@@ -150,7 +165,8 @@ enum {
   BALM_T_UPDATE = 5,    /* pose update + gain-ratio scalars                                   */
   BALM_T_BUILD = 6,     /* cluster build from points (balm_build_clusters kernel only)        */
   BALM_T_VOXEL = 7,     /* adaptive-voxel association (balm_associate, device part only)      */
-  BALM_T_COUNT = 8
+  BALM_T_COV = 8,       /* balm_pose_covariance: covariance factors, its two SYRKs, H^-1 R H^-T */
+  BALM_T_COUNT = 9
 };
 int balm_get_timing(balm_ctx *ctx, double *ms, long *count);
 int balm_reset_timing(balm_ctx *ctx);

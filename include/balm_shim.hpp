@@ -29,6 +29,8 @@ class BALM2_HIP {
   int form = BALM_FORM_LEFT;   // bavoxel.hpp:1109 (left) vs :1108 (right, commented out there)
   int device = 0;
   bool verbose = true;         // the reference always prints its per-iteration line (:1132)
+  bool reanchor = true;        // bavoxel.hpp:1159-1164 (the consistency driver does not: BAs_left.hpp:1087)
+  double abs_tol = 0;          // > 0: the consistency driver's stop rule |r1-r2| < 1e-9 (BAs_left.hpp:1083)
   std::vector<balm_iter_log> last_log;
 
   BALM2_HIP() {}
@@ -96,6 +98,37 @@ class BALM2_HIP {
     return F;
   }
 
+#ifdef POINT_NOISE
+  // The consistency driver's optimizer (src/simulation/BAs_left.hpp:1025-1098; compiled when the translation unit
+  // includes src/simulation/toolss.hpp, whose PointCluster carries the 9x9 noise covariance c_cov): LM loop with
+  // that file's constants (u0 = 0.01, up to 1000 iterations, stop at |r1 - r2| < 1e-9, no re-anchoring, no plane
+  // precheck), then `Rcov = Hess^-1 (sum Ls c_cov Ls^T) Hess^-T` at the result (:1089-1096).
+  void damping_iter(std::vector<IMUST> &x_stats, VOX_HESS &voxhess, Eigen::MatrixXd &Rcov, int covEnable = 1) {
+    upload(voxhess, /*force=*/true);
+    const int keep_iter = max_iter, keep_planes = min_planes_per_pose;
+    const double keep_rel = rel_tol, keep_abs = abs_tol;
+    const bool keep_anchor = reanchor;
+    max_iter = 1000; min_planes_per_pose = 0; rel_tol = 0; abs_tol = 1e-9; reanchor = false;
+    run_lm(x_stats);
+    max_iter = keep_iter; min_planes_per_pose = keep_planes; rel_tol = keep_rel; abs_tol = keep_abs; reanchor = keep_anchor;
+    if (!covEnable) return;
+    printf("Begin to compute covariance matrix...\n");          // :1091
+    const size_t F = voxhess.plvec_voxels.size();
+    const int W = win_size, n = 6 * W;
+    std::vector<double> cc(F * (size_t)W * 81);
+    for (size_t a = 0; a < F; a++)
+      for (int i = 0; i < W; i++) {
+        const PointCluster &c = (*voxhess.plvec_voxels[a])[(size_t)i];
+        double *q = cc.data() + (a * W + i) * 81;
+        for (int r = 0; r < 9; r++)
+          for (int k = 0; k < 9; k++) q[9 * r + k] = c.c_cov(r, k);
+      }
+    std::vector<double> poses = flatten_poses(x_stats);
+    Rcov.resize(n, n);
+    check(balm_pose_covariance(ctx_, poses.data(), cc.data(), 0.0, Rcov.data(), nullptr));
+  }
+#endif
+
   // damping_iter on the features installed by associate()
   void damping_iter(std::vector<IMUST> &x_stats) { run_lm(x_stats); }
 
@@ -111,7 +144,7 @@ class BALM2_HIP {
     balm_lm_opts o;
     o.form = form; o.u0 = u0; o.max_iter = max_iter; o.rel_tol = rel_tol;
     o.min_planes_per_pose = min_planes_per_pose; o.force_hess = 0; o.no_stop = 0;
-    o.verbose = verbose ? 1 : 0; o.reanchor = 1;
+    o.verbose = verbose ? 1 : 0; o.reanchor = reanchor ? 1 : 0; o.abs_tol = abs_tol;
     last_log.assign((size_t)max_iter, balm_iter_log());
     int iters = 0;
     int rc = balm_damping_iter(ctx_, &o, poses.data(), last_log.data(), &iters);

@@ -11,8 +11,18 @@ if [ ! -f "$REF/src/benchmark/bavoxel.hpp" ]; then
 fi
 mkdir -p "$HERE/_ref"
 OUT="$HERE/_ref/libbalm_ref.so"
-if [ "$OUT" -nt "$HERE/ref_driver.cpp" ] && [ "$OUT" -nt "$HERE/compat/Eigen/Core" ] && [ -z "$BALM_FORCE_BUILD" ]; then exit 0; fi
-g++ -std=c++14 -O3 -fPIC -pthread -shared -w \
-    -I"$HERE/compat" -I"$REF/include" -I"$REF/src/benchmark" \
-    -o "$OUT" "$HERE/ref_driver.cpp"
-echo "ref_build: built $OUT"
+if ! { [ "$OUT" -nt "$HERE/ref_driver.cpp" ] && [ "$OUT" -nt "$HERE/compat/Eigen/Core" ] && [ -z "$BALM_FORCE_BUILD" ]; }; then
+  g++ -std=c++14 -O3 -fPIC -pthread -shared -w \
+      -I"$HERE/compat" -I"$REF/include" -I"$REF/src/benchmark" \
+      -o "$OUT" "$HERE/ref_driver.cpp"
+  echo "ref_build: built $OUT"
+fi
+# the consistency / covariance sources (src/simulation) re-declare the same class names: separate object,
+# symbols bound locally
+OUT="$HERE/_ref/libbalm_ref_sim.so"
+if ! { [ "$OUT" -nt "$HERE/ref_sim_driver.cpp" ] && [ "$OUT" -nt "$HERE/compat/Eigen/Core" ] && [ -z "$BALM_FORCE_BUILD" ]; }; then
+  g++ -std=c++14 -O3 -fPIC -pthread -shared -w -Wl,-Bsymbolic \
+      -I"$HERE/compat" -I"$REF/src/simulation" \
+      -o "$OUT" "$HERE/ref_sim_driver.cpp"
+  echo "ref_build: built $OUT"
+fi

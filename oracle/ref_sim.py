@@ -1,0 +1,67 @@
+"""ctypes loader for oracle/_ref/libbalm_ref_sim.so -- the REFERENCE'S OWN consistency / covariance
+sources (src/simulation/toolss.hpp, BAs_left.hpp) compiled against oracle/compat/ (ref_sim_driver.cpp,
+ref_build.sh).  TEST INFRASTRUCTURE ONLY; may be absent (then `available()` is False)."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import ref
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO = os.path.join(_HERE, "_ref", "libbalm_ref_sim.so")
+_LIB = None
+
+
+def available():
+    if not os.path.exists(SO) and os.path.isdir("/root/reference"):
+        try:
+            ref.build()
+        except Exception:
+            return False
+    return os.path.exists(SO)
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        if not available():
+            raise ImportError("oracle/_ref/libbalm_ref_sim.so not built (needs /root/reference)")
+        _LIB = C.CDLL(SO)
+    return _LIB
+
+
+_p, _c = ref._p, ref._c
+
+
+def cluster_push(points, pn):
+    pts = _c(points).reshape(-1, 3)
+    cl, cc = np.zeros(10), np.zeros((9, 9))
+    lib().refsim_cluster_push(_p(pts), pts.shape[0], C.c_double(pn), _p(cl), _p(cc))
+    return cl, cc
+
+
+def point_cov(clusters, ccov, fix, poses, beg=0, end=None):
+    clusters, ccov, fix, poses = _c(clusters), _c(ccov), _c(fix), _c(poses)
+    F, W = clusters.shape[:2]
+    R = np.zeros((6 * W, 6 * W))
+    lib().refsim_point_cov(W, F, _p(clusters), _p(ccov), _p(fix), _p(poses), beg, F if end is None else end, _p(R))
+    return R.T.copy()
+
+
+def pose_cov(clusters, ccov, fix, poses):
+    """-> (Hess, Rcov) of the covariance tail of BALM2::damping_iter"""
+    clusters, ccov, fix, poses = _c(clusters), _c(ccov), _c(fix), _c(poses)
+    F, W = clusters.shape[:2]
+    H, R = np.zeros((6 * W, 6 * W)), np.zeros((6 * W, 6 * W))
+    lib().refsim_pose_cov(W, F, _p(clusters), _p(ccov), _p(fix), _p(poses), _p(H), _p(R))
+    return H.T.copy(), R.T.copy()
+
+
+def evaluate(clusters, fix, poses):
+    clusters, fix, poses = _c(clusters), _c(fix), _c(poses)
+    F, W = clusters.shape[:2]
+    H, g = np.zeros((6 * W, 6 * W)), np.zeros(6 * W)
+    r = C.c_double(0)
+    lib().refsim_evaluate(W, F, _p(clusters), _p(fix), _p(poses), _p(H), _p(g), C.byref(r))
+    return H.T.copy(), g, r.value

@@ -10,3 +10,8 @@ g++ -std=c++14 -O2 -w -pthread -I"$ROOT/oracle/compat" -I"$REF/include" -I"$REF/
     -o "$ROOT/oracle/_ref/shim_driver" "$ROOT/tests/cpp/shim_driver.cpp" \
     -L"$ROOT/balm_amd/lib" -lbalm_hip -ldl -Wl,-rpath,'$ORIGIN/../../balm_amd/lib'
 echo "built $ROOT/oracle/_ref/shim_driver"
+# the consistency driver's interface (src/simulation headers re-declare the same class names: separate binary)
+g++ -std=c++14 -O2 -w -pthread -I"$ROOT/oracle/compat" -I"$REF/src/simulation" -I"$ROOT/include" \
+    -o "$ROOT/oracle/_ref/shim_sim_driver" "$ROOT/tests/cpp/shim_sim_driver.cpp" \
+    -L"$ROOT/balm_amd/lib" -lbalm_hip -ldl -Wl,-rpath,'$ORIGIN/../../balm_amd/lib'
+echo "built $ROOT/oracle/_ref/shim_sim_driver"
