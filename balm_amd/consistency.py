@@ -1,6 +1,6 @@
 """Host side of the consistency experiment ("next" row N4): what src/simulation/consistency.cpp does around the
 optimizer -- the left-invariant pose error against ground truth and the NEES of one Monte-Carlo run -- on top
-of balm_pose_covariance / balm_solve_damped.  No oracle code here; the arithmetic that matters runs on the GPU."""
+of balm_pose_covariance / balm_solve_damped.  Only glue here: the arithmetic that matters runs on the GPU."""
 import numpy as np
 
 

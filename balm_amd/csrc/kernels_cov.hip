@@ -3,7 +3,7 @@
 //     Rcov_raw = sum_a sum_j Ls_{a,j} c_cov_{a,j} Ls_{a,j}^T     src/simulation/BAs_left.hpp:342-473 (left_jacobian_point)
 //     Rcov     = H^-1 Rcov_raw H^-T                              src/simulation/BAs_left.hpp:1089-1096
 // The reference builds a dense (6W x 9) Ls per (feature a, observing pose j) and adds a rank-9 6W x 6W update for
-// each: O(S W^2) with S = F W observations.  Ls has the structure (oracle/numpy_oracle.py point_cov_left_factored)
+// each: O(S W^2) with S = F W observations.  Ls has the structure (derivation: DESIGN.md 7d)
 //     block p of Ls_{a,j} = At_{a,p} Gm_{a,j} + [p == j] D_{a,j},   At (6x3), Gm (3x9), D (6x9),
 // where the columns of At are the Hessian's own factor vectors rescaled.  Summing over j per feature,
 //     Rcov_raw = X X^T - Y Y^T + blockdiag_j(S_j),   X = At Cq + Y,  Y = Rr Cq^-T,  Q = Cq Cq^T,
