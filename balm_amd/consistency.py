@@ -29,3 +29,67 @@ def nees(ctx, poses_est, poses_gt, Rcov):
     err = pose_error_left(poses_est, poses_gt)
     _, q1 = ctx.solve_damped(Rcov, -err, 0.0)       # q1 = 0.5 x.(0 - (-err)) with Rcov x = err
     return 2.0 * q1, err
+
+
+def load_window(data_dir, n_poses=101):
+    """consistency.cpp:57-94: lidarPose.csv (4 text lines per pose) + <m>.pcd, m = 1..n; translations relative to
+    pose 0 (rotations are kept, :87-88)"""
+    import os
+    from . import realworld as rw
+    poses, _ = rw.read_pose_csv(os.path.join(data_dir, "lidarPose.csv"), n_poses)
+    poses = poses.copy()
+    poses[:, 9:] -= poses[0, 9:].copy()
+    frames = [rw.read_pcd_xyz(os.path.join(data_dir, "%d.pcd" % (m + 1))) for m in range(poses.shape[0])]
+    return poses, frames
+
+
+def monte_carlo(ctx, frames, poses, pnoise=0.02, runs=1, seed=0, verbose=False):
+    """consistency.cpp:96-170 around the GPU path: associate the noise-free scans (first scan marginalised into
+    fix clusters), then per run corrupt every feature point with N(0, pnoise^2) (OCTO_TREE_NODE::corrupt,
+    BAs_left.hpp:886-906), rebuild the clusters on the device, optimise from the true poses, predict the covariance
+    and score the error.  ctx: a capi.Context for len(frames) - 1 poses.  -> list of NEES, number of features"""
+    from . import realworld as rw
+    cl, co, layer, fix, (xyz, fid, sid) = rw.associate(frames, poses, want_points=True, **rw.SIM_RULES)
+    F, W = cl.shape[0], cl.shape[1]
+    gt = poses[rw.SIM_RULES["fix_frames"]:]
+    out = []
+    for run in range(runs):
+        rng = np.random.default_rng(seed + run)
+        noisy = (xyz.astype(np.float64) + pnoise * rng.standard_normal(xyz.shape)).astype(np.float32)
+        ctx.build_clusters(F, noisy, fid, sid, fix, np.ones(F), want_clusters=False)     # weight 1: BAs_left.hpp:44
+        est, lg = ctx.damping_iter(gt, form=0, u0=0.01, max_iter=1000, rel_tol=0.0, abs_tol=1e-9, reanchor=False,
+                                   verbose=verbose)
+        Rcov, _ = ctx.pose_covariance(est, point_sigma=pnoise, want_raw=False)
+        v, _ = nees(ctx, est, gt, Rcov)
+        out.append(v)
+    return out, F
+
+
+def main(argv=None):
+    import argparse
+    import sys
+    import time
+    ap = argparse.ArgumentParser(description="the consistency experiment (src/simulation/consistency.cpp) on the GPU path")
+    ap.add_argument("data_dir", help=".../datas/consistency")
+    ap.add_argument("--pnoise", type=float, default=0.02)
+    ap.add_argument("--runs", type=int, default=1)
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--device", type=int, default=0)
+    a = ap.parse_args(argv)
+    from . import capi
+    poses, frames = load_window(a.data_dir)
+    W = poses.shape[0] - 1
+    print("The size of poses: %d" % W)                                                  # consistency.cpp:138
+    ctx = capi.Context(W, a.device)
+    t = time.time()
+    vals, F = monte_carlo(ctx, frames, poses, a.pnoise, a.runs, a.seed, verbose=a.runs == 1)
+    print("%d plane features, %d run(s) in %.2f s" % (F, a.runs, time.time() - t))
+    print("The expected NEES is 6*%d = %d." % (W, 6 * W))                              # :169
+    for v in vals:
+        print("The NEES for this Monto-Carlo experiment is %f." % v)                     # :170
+    return 0
+
+
+if __name__ == "__main__":
+    import sys
+    sys.exit(main())

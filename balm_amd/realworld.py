@@ -59,27 +59,53 @@ def relative_to_first(poses):
     return out
 
 
+# the consistency driver's association rules: src/simulation/BAs_left.hpp:18-23 (layer_limit 0, thresholds 1/64,
+# min_ps 10), :674 (max point-to-plane distance 1 mm, lambda2/lambda1 < 25, lambda0 < 1e-10), consistency.cpp:125-131
+# (first scan marginalised into fix clusters), BAs_left.hpp:38 (no observer minimum)
+SIM_RULES = dict(voxel_size=1.0, eigen_thresholds=(1.0 / 64, 1.0 / 64, 1.0 / 64), layer_limit=0, min_ps=10,
+                 strict=(0.001, 25.0, 1e-10), fix_frames=1, min_observers=0)
+
+
 def associate(frames_xyz, poses, voxel_size=2.0, eigen_thresholds=(1.0 / 16, 1.0 / 16, 1.0 / 9), layer_limit=2,
-              min_ps=15):
+              min_ps=15, strict=None, fix_frames=0, min_observers=2, want_points=False):
     """frames_xyz: list of [n_i,3] float32 body-frame scans; poses [W,12].  Returns (clusters [F,W,10],
-    coeffs [F], layer [F]).  Defaults = benchmark_realworld.cpp:183-185 + launch/benchmark_realworld.launch:4."""
+    coeffs [F], layer [F]).  Defaults = benchmark_realworld.cpp:183-185 + launch/benchmark_realworld.launch:4.
+    With fix_frames / strict / want_points (the consistency driver, `**SIM_RULES`): W counts the scans after the
+    marginalised ones and the result is (clusters, coeffs, layer, fix [F,10], points) with points = (xyz [n,3]
+    float32, feature [n], scan [n]) of every feature, or None."""
     L = _lib()
+    L.balm_assoc_export_points.restype = C.c_long
     W = len(frames_xyz)
     thr = np.asarray(eigen_thresholds, dtype=np.float32)
     h = C.c_void_p(L.balm_assoc_create(W, C.c_double(voxel_size), _p(thr), layer_limit, min_ps))
+    extended = strict is not None or fix_frames or want_points or min_observers != 2
     try:
+        if extended:
+            st = strict or (0.0, 0.0, 0.0)
+            L.balm_assoc_set_rules(h, C.c_double(st[0]), C.c_double(st[1]), C.c_double(st[2]), fix_frames, min_observers)
         poses = np.ascontiguousarray(poses, dtype=np.float64)
         for i, xyz in enumerate(frames_xyz):
             xyz = np.ascontiguousarray(xyz, dtype=np.float32)
             rc = L.balm_assoc_add_frame(h, i, _p(xyz), C.c_long(xyz.shape[0]), _p(poses[i]))
             assert rc == 0
         F = L.balm_assoc_finish(h)
-        cl = np.zeros((F, W, 10))
+        cl = np.zeros((F, W - fix_frames, 10))
         co = np.zeros(F)
         layer = np.zeros(F, dtype=np.int32)
         L.balm_assoc_export(h, _p(cl), _p(co), _p(layer))
+        if extended:
+            fix = np.zeros((F, 10))
+            L.balm_assoc_export_fix(h, _p(fix))
+            pts = None
+            if want_points:
+                n = L.balm_assoc_export_points(h, None, None, None)
+                xyz, fid, sid = np.zeros((n, 3), np.float32), np.zeros(n, np.int32), np.zeros(n, np.int32)
+                L.balm_assoc_export_points(h, _p(xyz), _p(fid), _p(sid))
+                pts = (xyz, fid, sid)
     finally:
         L.balm_assoc_destroy(h)
+    if extended:
+        return cl, co, layer, fix, pts
     return cl, co, layer
 
 

@@ -65,3 +65,18 @@ def evaluate(clusters, fix, poses):
     r = C.c_double(0)
     lib().refsim_evaluate(W, F, _p(clusters), _p(fix), _p(poses), _p(H), _p(g), C.byref(r))
     return H.T.copy(), g, r.value
+
+
+def associate(frames_xyz, poses, fix=1, voxel_size=1.0):
+    """consistency.cpp:96-150 with the reference's compiled cut_voxel / recut / marginalize / tras_opt
+    -> (clusters [F, W-fix, 10], fix clusters [F, 10])"""
+    xyz = np.ascontiguousarray(np.concatenate(frames_xyz), dtype=np.float32)
+    counts = np.array([f.shape[0] for f in frames_xyz], dtype=np.int64)
+    poses = _c(poses)
+    n = len(frames_xyz)
+    L = lib()
+    F = L.refsim_associate(n, fix, _p(xyz), _p(counts), _p(poses), C.c_double(voxel_size), None, None)
+    cl, fx = np.zeros((F, n - fix, 10)), np.zeros((F, 10))
+    if F:
+        L.refsim_associate(n, fix, _p(xyz), _p(counts), _p(poses), C.c_double(voxel_size), _p(cl), _p(fx))
+    return cl, fx

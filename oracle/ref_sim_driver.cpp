@@ -119,6 +119,54 @@ int refsim_pose_cov(int W, int F, const double *clusters, const double *ccov, co
   return 0;
 }
 
+// The association of consistency.cpp:96-150 on caller-supplied scans: cut_voxel per scan (BAs_left.hpp:1102), recut
+// (:713), marginalize the first `fix` scans (:754, :911), tras_opt (:794).  xyz: all scans concatenated, counts[n_scans].
+// Two calls: clusters == NULL returns the number of features; then clusters [F][win][10] and fixes [F][10].
+static std::vector<double> g_assoc_cl, g_assoc_fix;
+int refsim_associate(int n_scans, int fix, const float *xyz, const long *counts, const double *poses, double voxel,
+                     double *clusters, double *fixes) {
+  if (clusters) {
+    std::memcpy(clusters, g_assoc_cl.data(), g_assoc_cl.size() * sizeof(double));
+    std::memcpy(fixes, g_assoc_fix.data(), g_assoc_fix.size() * sizeof(double));
+    return (int)(g_assoc_fix.size() / 10);
+  }
+  win_size = n_scans - fix;
+  fix_size = fix;
+  voxel_size = voxel;
+  std::vector<IMUST> x_buf = load_poses(n_scans, poses);
+  std::unordered_map<VOXEL_LOC, OCTO_TREE_ROOT *> surf_map;
+  long off = 0;
+  for (int m = 0; m < n_scans; m++) {
+    pcl::PointCloud<PointType> pl;
+    for (long k = 0; k < counts[m]; k++) {
+      PointType ap; ap.x = xyz[3 * (off + k)]; ap.y = xyz[3 * (off + k) + 1]; ap.z = xyz[3 * (off + k) + 2];
+      pl.push_back(ap);
+    }
+    off += counts[m];
+    cut_voxel(surf_map, pl, x_buf[m], m);
+  }
+  std::vector<IMUST> x_buf2;
+  for (auto iter = surf_map.begin(); iter != surf_map.end(); ++iter) {
+    iter->second->recut(n_scans);
+    iter->second->marginalize(fix_size, x_buf2, n_scans);
+  }
+  VOX_HESS voxhess;
+  for (auto iter = surf_map.begin(); iter != surf_map.end(); iter++) iter->second->tras_opt(voxhess, win_size);
+  const size_t F = voxhess.plvec_voxels.size();
+  g_assoc_cl.assign(F * win_size * 10, 0.0);
+  g_assoc_fix.assign(F * 10, 0.0);
+  auto put = [](const PointCluster &c, double *q) {
+    q[0] = c.P(0, 0); q[1] = c.P(0, 1); q[2] = c.P(0, 2); q[3] = c.P(1, 1); q[4] = c.P(1, 2); q[5] = c.P(2, 2);
+    q[6] = c.v[0]; q[7] = c.v[1]; q[8] = c.v[2]; q[9] = c.N;
+  };
+  for (size_t a = 0; a < F; a++) {
+    for (int i = 0; i < win_size; i++) put((*voxhess.plvec_voxels[a])[i], g_assoc_cl.data() + (a * win_size + i) * 10);
+    put(*voxhess.sig_vecs[a], g_assoc_fix.data() + a * 10);
+  }
+  for (auto &kv : surf_map) delete kv.second;
+  return (int)F;
+}
+
 // VOX_HESS::left_evaluate_acc2 of the simulation copy (BAs_left.hpp), to confirm it is the same evaluator
 int refsim_evaluate(int W, int F, const double *clusters, const double *fix, const double *poses, double *Hess, double *JacT,
                     double *residual) {

@@ -103,3 +103,66 @@ def test_association_matches_reference_on_shipped_data():
     assert cl.shape == g["clusters"].shape == (2281, 177, 10)
     assert np.array_equal(canon(cl), canon(g["clusters"]))
     assert list(np.bincount(layer)) == [797, 449, 1035]
+
+
+# ---- the consistency driver's association rules (N4): src/simulation/BAs_left.hpp copy of the state machine ----
+def exact_plane_scans(seed, n_scans, n_planes, pts):
+    """simulator-like scans: points exactly on planes (the strict test wants lambda0 < 1e-10, max distance < 1 mm)"""
+    rng = np.random.default_rng(seed)
+    R = np.stack([npo.exp_so3(0.03 * rng.standard_normal(3)) for _ in range(n_scans)])
+    p = np.cumsum(0.1 * rng.standard_normal((n_scans, 3)), axis=0)
+    R[0], p[0] = np.eye(3), 0
+    normals = rng.standard_normal((n_planes, 3))
+    normals /= np.linalg.norm(normals, axis=1, keepdims=True)
+    centers = rng.uniform(-8, 8, (n_planes, 3))
+    frames = []
+    for i in range(n_scans):
+        w = []
+        for k in range(n_planes):
+            a = np.cross(normals[k], [0.3, 0.5, 0.8]); a /= np.linalg.norm(a)
+            b = np.cross(normals[k], a)
+            uv = rng.uniform(-0.35, 0.35, (pts, 2))
+            w.append(centers[k] + uv[:, :1] * a + uv[:, 1:] * b)
+        w.append(rng.uniform(-8, 8, (200, 3)))                       # clutter: never a plane
+        w = np.concatenate(w)
+        frames.append(((w - p[i]) @ R[i]).astype(np.float32))
+    return npo.make_poses(R, p), frames
+
+
+def _canon_with_fix(cl, fix):
+    both = np.concatenate([cl.reshape(cl.shape[0], -1), fix], axis=1)
+    return both[np.lexsort(both[:, ::-1].T)]
+
+
+def test_consistency_rules_match_reference_association(tmp_path):
+    from oracle import ref_sim
+    if not ref_sim.available():
+        pytest.skip("oracle/_ref/libbalm_ref_sim.so not built (needs /root/reference)")
+    poses, frames = exact_plane_scans(4, 9, 40, 60)
+    cl, co, layer, fix, pts = rw.associate(frames, poses, want_points=True, **rw.SIM_RULES)
+    clr, fxr = ref_sim.associate(frames, poses, 1, 1.0)
+    assert cl.shape == clr.shape and cl.shape[0] >= 10 and cl.shape[1] == 8
+    assert np.array_equal(_canon_with_fix(cl, fix), _canon_with_fix(clr, fxr))      # bit-exact feature set, fix included
+    assert (fix[:, 9] > 0).any() and not layer.any()                                # layer_limit 0: root voxels only
+    # the exported points rebuild the exported clusters
+    xyz, fid, sid = pts
+    N = np.zeros(cl.shape[:2])
+    np.add.at(N, (fid, sid), 1)
+    assert np.array_equal(N, cl[..., 9])
+    a, i = fid[0], sid[0]
+    sel = (fid == a) & (sid == i)
+    assert np.allclose(xyz[sel].astype(np.float64).sum(0), cl[a, i, 6:9], rtol=1e-12)
+
+
+def test_consistency_rules_on_shipped_scans():
+    from conftest import ROOT
+    from oracle import ref_sim
+    path = os.path.join(ROOT, "oracle", "_ref", "consistency_scans.npz")
+    if not (os.path.exists(path) and ref_sim.available()):
+        pytest.skip("oracle/_ref/consistency_scans.npz or libbalm_ref_sim.so not built")
+    d = np.load(path)
+    frames = np.split(d["xyz"], np.cumsum(d["counts"])[:-1])
+    cl, co, layer, fix, _ = rw.associate(frames, d["poses"], **rw.SIM_RULES)
+    clr, fxr = ref_sim.associate(frames, d["poses"], 1, 1.0)
+    assert cl.shape == clr.shape == (1096, 100, 10)
+    assert np.array_equal(_canon_with_fix(cl, fix), _canon_with_fix(clr, fxr))

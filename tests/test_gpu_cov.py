@@ -157,3 +157,21 @@ def test_cpp_shim_dropin_for_the_consistency_driver():
     assert line, p.stdout[-2000:] + p.stderr[-2000:]
     print(line[-1])
     assert p.returncode == 0, line[-1]
+
+
+def test_consistency_experiment_on_shipped_scans():
+    """src/simulation/consistency.cpp end to end on its own shipped data (datas/consistency: 101 simulated scans):
+    association with that driver's rules (host), per run noise -> device cluster build -> device LM -> device
+    covariance -> NEES.  The reference prints "The expected NEES is 6*100 = 600"."""
+    path = os.path.join(ROOT, "oracle", "_ref", "consistency_scans.npz")
+    if not os.path.exists(path):
+        pytest.skip("oracle/_ref/consistency_scans.npz not built (needs /root/reference/datas)")
+    d = np.load(path)
+    frames = np.split(d["xyz"], np.cumsum(d["counts"])[:-1])
+    c = capi.Context(100)
+    vals, F = consistency.monte_carlo(c, frames, d["poses"], pnoise=0.02, runs=4, seed=7)
+    c.close()
+    vals = np.array(vals)
+    print("consistency experiment: %d features, NEES %s (expected 600 +- 35)" % (F, np.round(vals, 1)))
+    assert F == 1096
+    assert np.all(np.abs(vals - 600) < 6 * np.sqrt(1200)) and abs(vals.mean() - 600) < 5 * np.sqrt(1200 / 4)

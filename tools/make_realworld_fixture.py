@@ -54,3 +54,10 @@ assert np.abs(poses_p - g["poses"]).max() < 1e-13 and sum(f.shape[0] for f in fr
 dst = os.path.join(ROOT, "oracle", "_ref", "realworld_scans_w177.npz")
 np.savez_compressed(dst, xyz=np.concatenate(frames), counts=np.array([f.shape[0] for f in frames]))
 print("full window: %d scans -> %s (%.1f MB)" % (len(frames), dst, os.path.getsize(dst) / 1e6))
+
+# --- the consistency experiment's shipped scans (datas/consistency: 101 x 28 800 points, simulator output) -> N4
+from balm_amd import consistency
+cposes, cframes = consistency.load_window(os.environ.get("BALM_REFERENCE_ROOT", "/root/reference") + "/datas/consistency")
+dst = os.path.join(ROOT, "oracle", "_ref", "consistency_scans.npz")
+np.savez_compressed(dst, xyz=np.concatenate(cframes), counts=np.array([f.shape[0] for f in cframes]), poses=cposes)
+print("consistency window: %d scans -> %s (%.1f MB)" % (len(cframes), dst, os.path.getsize(dst) / 1e6))
