@@ -175,3 +175,62 @@ def test_consistency_experiment_on_shipped_scans():
     print("consistency experiment: %d features, NEES %s (expected 600 +- 35)" % (F, np.round(vals, 1)))
     assert F == 1096
     assert np.all(np.abs(vals - 600) < 6 * np.sqrt(1200)) and abs(vals.mean() - 600) < 5 * np.sqrt(1200 / 4)
+
+
+def test_pose_covariance_wide_window():
+    """W > 256: every lane of the per-feature workgroups owns more than one pose; n = 1800 -> 38 LDL panels"""
+    W, F = 300, 14
+    cl, fix, poses, _, _ = anchored_scene(21, W, F, 8, sparse=True)
+    cc = npo.cluster_noise_cov_closed_form(cl, 0.03)
+    Rf = npo.point_cov_left_factored(cl, cc, fix, poses)[0]
+    H, _, _ = npo.left_evaluate(cl, fix, np.ones(F), poses)
+    c = capi.Context(W)
+    c.set_features(cl, fix, np.ones(F))
+    Rcov, Rraw = c.pose_covariance(poses, point_sigma=0.03)
+    assert rel(Rraw, Rf) < 1e-10
+    # few features over many poses: H is poorly conditioned, compare through the better-posed product H Rcov H^T
+    assert rel(H @ Rcov @ H.T, Rf) < 1e-7
+    c.close()
+
+
+def _cov_two_rank_worker(rank, world, port, seed, W, F, q):
+    import torch.distributed as dist
+    from balm_amd import dist as bdist
+    os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    bdist.init_process_group("gloo")          # two ranks on the box's one GPU: RCCL refuses that, gloo does not
+    cl, fix, poses, _, _ = anchored_scene(seed, W, F, 12, sparse=True)
+    nobs = (cl[..., 9] > 0).sum(1)
+    lo, hi = bdist.partition_features(nobs, world)[rank]
+    c = capi.Context(W, 0)
+    c.set_features(cl[lo:hi], fix[lo:hi], np.ones(hi - lo))
+    bdist.install_allreduce(c)
+    Rcov, Rraw = c.pose_covariance(poses, point_sigma=0.02)
+    if rank == 0:
+        q.put((Rcov, Rraw))
+    dist.barrier()
+    c.close()
+    dist.destroy_process_group()
+
+
+def test_pose_covariance_two_ranks_sharded_on_one_gpu():
+    """the N>1 path of the covariance stage: feature shards on two processes, [XX^T tiles | YY^T tiles | S] summed
+    through the balm_set_allreduce hook, the solves replicated; equals the single-process result"""
+    import socket
+    import torch.multiprocessing as mp
+    seed, W, F = 31, 16, 70
+    cl, fix, poses, _, _ = anchored_scene(seed, W, F, 12, sparse=True)
+    c = capi.Context(W)
+    c.set_features(cl, fix, np.ones(F))
+    Rcov1, Rraw1 = c.pose_covariance(poses, point_sigma=0.02)
+    c.close()
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_cov_two_rank_worker, args=(r, 2, port, seed, W, F, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    Rcov2, Rraw2 = q.get(timeout=600)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert rel(Rraw2, Rraw1) < 1e-12 and rel(Rcov2, Rcov1) < 1e-9
