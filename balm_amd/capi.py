@@ -19,7 +19,7 @@ TIMING_NAMES = ["moments", "factors", "syrk", "assemble", "solve", "update", "bu
 
 # every symbol include/balm_hip.h declares
 EXPORTS = ["balm_create", "balm_destroy", "balm_set_features", "balm_evaluate", "balm_only_residual",
-           "balm_solve_damped", "balm_damping_iter", "balm_build_clusters", "balm_associate", "balm_get_features", "balm_pose_covariance",
+           "balm_solve_damped", "balm_damping_iter", "balm_build_clusters", "balm_voxel_defaults", "balm_associate", "balm_get_features", "balm_get_association", "balm_pose_covariance",
            "balm_set_allreduce",
            "balm_get_timing", "balm_reset_timing", "balm_work_model", "balm_last_error", "balm_version"]
 
@@ -36,7 +36,9 @@ class LMOpts(C.Structure):
 
 
 class VoxelOpts(C.Structure):
-    _fields_ = [("voxel_size", C.c_double), ("eigen_thr", C.c_float * 3), ("min_ps", C.c_int)]
+    _fields_ = [("voxel_size", C.c_double), ("eigen_thr", C.c_float * 3), ("min_ps", C.c_int), ("layer_limit", C.c_int),
+                ("min_observers", C.c_int), ("fix_frames", C.c_int), ("max_plane_dist", C.c_double),
+                ("max_lambda21", C.c_double), ("max_lambda0", C.c_double), ("want_point_features", C.c_int)]
 
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_long, C.c_void_p)
@@ -74,6 +76,9 @@ def lib():
         L.balm_associate.argtypes = [C.c_void_p, C.POINTER(VoxelOpts), C.c_void_p, C.c_void_p, C.c_long, C.c_void_p,
                                      C.POINTER(C.c_int), C.POINTER(C.c_long)]
         L.balm_get_features.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.balm_get_association.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.balm_voxel_defaults.restype = None
+        L.balm_voxel_defaults.argtypes = [C.POINTER(VoxelOpts)]
         L.balm_pose_covariance.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p]
         L.balm_set_allreduce.argtypes = [C.c_void_p, ALLREDUCE_FN, C.c_void_p]
         L.balm_get_timing.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
@@ -143,12 +148,22 @@ class Context:
         return out
 
     def associate(self, xyz, frame_id, poses, voxel_size=2.0, eigen_thresholds=(1.0 / 16, 1.0 / 16, 1.0 / 9),
-                  min_ps=15, want_features=True):
+                  min_ps=15, want_features=True, layer_limit=2, min_observers=2, fix_frames=0, strict=None,
+                  want_points=False):
         """Adaptive-voxel association on the device; installs the features.  -> (F, n_root_voxels,
-        (clusters [F,W,10], coeffs [F], layer [F]) or None)"""
+        (clusters [F,W,10], coeffs [F], layer [F]) or None); with fix_frames / want_points the tuple continues
+        with fix [F,10] and the feature index of every point [n] (-1 = none)"""
         xyz = _c(xyz, np.float32).reshape(-1, 3)
         frame_id, poses = _c(frame_id, np.int32), _c(poses)
-        o = VoxelOpts(voxel_size, (C.c_float * 3)(*[float(t) for t in eigen_thresholds]), min_ps)
+        assert poses.shape[0] == self.W + fix_frames, "poses for the marginalised scans too"
+        o = VoxelOpts()
+        self.L.balm_voxel_defaults(C.byref(o))
+        o.voxel_size = voxel_size
+        o.eigen_thr = (C.c_float * 3)(*[float(t) for t in eigen_thresholds])
+        o.min_ps, o.layer_limit, o.min_observers, o.fix_frames = min_ps, layer_limit, min_observers, fix_frames
+        if strict is not None:
+            o.max_plane_dist, o.max_lambda21, o.max_lambda0 = strict
+        o.want_point_features = int(want_points)
         F, nr = C.c_int(0), C.c_long(0)
         self._check(self.L.balm_associate(self.h, C.byref(o), _p(xyz), _p(frame_id), xyz.shape[0], _p(poses),
                                           C.byref(F), C.byref(nr)))
@@ -159,6 +174,11 @@ class Context:
             layer = np.zeros(self.F, dtype=np.int32)
             self._check(self.L.balm_get_features(self.h, _p(cl), _p(co), _p(layer)))
             feats = (cl, co, layer)
+            if fix_frames or want_points:
+                fix = np.zeros((self.F, 10))
+                pf = np.zeros(xyz.shape[0], dtype=np.int32) if want_points else None
+                self._check(self.L.balm_get_association(self.h, _p(fix), _p(pf)))
+                feats = (cl, co, layer, fix, pf)
         return self.F, nr.value, feats
 
     def pose_covariance(self, poses, cluster_cov=None, point_sigma=0.0, want_raw=True):

@@ -323,22 +323,33 @@ int balm_build_clusters(balm_ctx *ctx, int F, const float *xyz, const int *feat_
   return sync_stream(ctx);
 }
 
+void balm_voxel_defaults(balm_voxel_opts *o) {
+  if (!o) return;
+  o->voxel_size = 1.0;                                        // bavoxel.hpp:15
+  o->eigen_thr[0] = 1.0f / 16; o->eigen_thr[1] = 1.0f / 16; o->eigen_thr[2] = 1.0f / 9;   // benchmark_realworld.cpp:183-185
+  o->min_ps = 15; o->layer_limit = 2; o->min_observers = 2; o->fix_frames = 0;
+  o->max_plane_dist = 0; o->max_lambda21 = 0; o->max_lambda0 = 0;
+  o->want_point_features = 0;
+}
+
 int balm_associate(balm_ctx *ctx, const balm_voxel_opts *opts, const float *xyz, const int *frame_id, long n_pts,
                    const double *poses, int *F_out, long *n_root_voxels) {
   if (!ctx) return BALM_ERR_ARG;
-  if (!opts || !xyz || !frame_id || !poses || !F_out || n_pts < 1 || !(opts->voxel_size > 0)) {
+  if (!opts || !xyz || !frame_id || !poses || !F_out || n_pts < 1 || !(opts->voxel_size > 0) || opts->fix_frames < 0 ||
+      opts->layer_limit < 0 || opts->layer_limit > 2 || opts->min_observers < 0) {
     ctx->err = "balm_associate: bad argument"; return BALM_ERR_ARG;
   }
-  const int W = ctx->W;
-  if (W > 512) { ctx->err = "balm_associate: win_size > 512 not supported"; return BALM_ERR_ARG; }
+  const int W = ctx->W, WT = W + opts->fix_frames;
+  if (WT > 512) { ctx->err = "balm_associate: more than 512 scans not supported"; return BALM_ERR_ARG; }
   for (long k = 0; k < n_pts; k++)
-    if (frame_id[k] < 0 || frame_id[k] >= W) { ctx->err = "balm_associate: frame_id out of range"; return BALM_ERR_ARG; }
+    if (frame_id[k] < 0 || frame_id[k] >= WT) { ctx->err = "balm_associate: frame_id out of range"; return BALM_ERR_ARG; }
   HIP_TRY(hipSetDevice(ctx->device));
   *F_out = 0;
   ctx->F = 0;
-  ctx->assoc_clusters.clear(); ctx->assoc_coeffs.clear(); ctx->assoc_layer.clear();
+  ctx->assoc_clusters.clear(); ctx->assoc_coeffs.clear(); ctx->assoc_layer.clear(); ctx->assoc_fix.clear();
+  ctx->assoc_point_feat.clear();
   float *d_xyz = nullptr; int *d_f = nullptr;
-  double *d_out = nullptr, *d_coe = nullptr; int *d_lay = nullptr;
+  double *d_out = nullptr, *d_coe = nullptr, *d_fix = nullptr, *d_pos = nullptr; int *d_lay = nullptr, *d_pf = nullptr;
   int F = 0; long nroots = 0; int arc = 0;
   size_t need = 0;
   if (!ctx->d_arena) {                  // first call: ~100 B per point covers the per-point arrays + sort scratch
@@ -347,13 +358,17 @@ int balm_associate(balm_ctx *ctx, const balm_voxel_opts *opts, const float *xyz,
   }
   HIP_TRY(hipMalloc((void **)&d_xyz, (size_t)n_pts * 3 * sizeof(float)));
   hipError_t e = hipMalloc((void **)&d_f, (size_t)n_pts * sizeof(int));
+  if (e == hipSuccess) e = hipMalloc((void **)&d_pos, (size_t)12 * WT * sizeof(double));
   if (e == hipSuccess) e = hipMemcpyAsync(d_xyz, xyz, (size_t)n_pts * 3 * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
   if (e == hipSuccess) e = hipMemcpyAsync(d_f, frame_id, (size_t)n_pts * sizeof(int), hipMemcpyHostToDevice, ctx->stream);
-  if (e == hipSuccess) e = hipMemcpyAsync(ctx->d_poses, poses, (size_t)12 * W * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_pos, poses, (size_t)12 * WT * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
   if (e == hipSuccess) {
     Span sp(ctx, BALM_T_VOXEL);
-    arc = associate_device(ctx->stream, d_xyz, d_f, ctx->d_poses, n_pts, W, opts->voxel_size, opts->eigen_thr, opts->min_ps,
-                           ctx->d_arena, ctx->arena_cap, &need, &F, &d_out, &d_coe, &d_lay, &nroots);
+    AssocOpts ao{WT, opts->voxel_size, {opts->eigen_thr[0], opts->eigen_thr[1], opts->eigen_thr[2]}, opts->min_ps,
+                 opts->layer_limit, opts->min_observers, opts->fix_frames, opts->max_plane_dist, opts->max_lambda21,
+                 opts->max_lambda0};
+    arc = associate_device(ctx->stream, d_xyz, d_f, d_pos, n_pts, ao, ctx->d_arena, ctx->arena_cap, &need, &F, &d_out, &d_coe,
+                           &d_fix, &d_lay, opts->want_point_features ? &d_pf : nullptr, &nroots);
   }
   if (need > ctx->arena_cap) {          // grow for the next call of this size
     hipStreamSynchronize(ctx->stream);
@@ -363,21 +378,27 @@ int balm_associate(balm_ctx *ctx, const balm_voxel_opts *opts, const float *xyz,
   }
   if (d_xyz) hipFree(d_xyz);
   if (d_f) hipFree(d_f);
+  if (d_pos) hipFree(d_pos);
   HIP_TRY(e);
   if (arc) { ctx->err = arc == -2 ? "balm_associate: unsupported size" : "balm_associate: device failure"; return BALM_ERR_HIP; }
   if (n_root_voxels) *n_root_voxels = nroots;
   if (F == 0) return BALM_OK;
   const size_t count = (size_t)F * W * 10;
-  ctx->assoc_clusters.resize(count); ctx->assoc_coeffs.resize(F); ctx->assoc_layer.resize(F);
+  ctx->assoc_clusters.resize(count); ctx->assoc_coeffs.resize(F); ctx->assoc_layer.resize(F); ctx->assoc_fix.resize((size_t)F * 10);
+  if (d_pf) ctx->assoc_point_feat.resize((size_t)n_pts);
   int rc = dalloc(ctx, &ctx->d_cl, count);
   if (!rc) {
     launch_transpose_clusters(ctx->stream, d_out, ctx->d_cl, F, W);
     e = hipMemcpyAsync(ctx->assoc_clusters.data(), d_out, count * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(ctx->assoc_coeffs.data(), d_coe, (size_t)F * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(ctx->assoc_fix.data(), d_fix, (size_t)F * 10 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(ctx->assoc_layer.data(), d_lay, (size_t)F * sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess && d_pf)
+      e = hipMemcpyAsync(ctx->assoc_point_feat.data(), d_pf, (size_t)n_pts * sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
   }
-  hipFree(d_out); hipFree(d_coe); hipFree(d_lay);
+  hipFree(d_out); hipFree(d_coe); hipFree(d_fix); hipFree(d_lay);
+  if (d_pf) hipFree(d_pf);
   if (rc) return rc;
   HIP_TRY(e);
   ctx->planes_per_pose.assign(W, 0);
@@ -389,7 +410,8 @@ int balm_associate(balm_ctx *ctx, const balm_voxel_opts *opts, const float *xyz,
     S += na; B += 0.5 * na * (na + 1.0);
   }
   ctx->work_S = S; ctx->work_B = B;
-  if ((rc = install_feature_buffers(ctx, F, nullptr, ctx->assoc_coeffs.data()))) return rc;
+  if ((rc = install_feature_buffers(ctx, F, opts->fix_frames > 0 ? ctx->assoc_fix.data() : nullptr, ctx->assoc_coeffs.data())))
+    return rc;
   if ((rc = sync_stream(ctx))) return rc;
   *F_out = F;
   return BALM_OK;
@@ -401,6 +423,17 @@ int balm_get_features(balm_ctx *ctx, double *clusters, double *coeffs, int *laye
   if (clusters) std::memcpy(clusters, ctx->assoc_clusters.data(), ctx->assoc_clusters.size() * sizeof(double));
   if (coeffs) std::memcpy(coeffs, ctx->assoc_coeffs.data(), ctx->assoc_coeffs.size() * sizeof(double));
   if (layer) std::memcpy(layer, ctx->assoc_layer.data(), ctx->assoc_layer.size() * sizeof(int));
+  return BALM_OK;
+}
+
+int balm_get_association(balm_ctx *ctx, double *fix, int *point_feature) {
+  if (!ctx) return BALM_ERR_ARG;
+  if (ctx->assoc_coeffs.empty()) { ctx->err = "balm_get_association: no balm_associate result"; return BALM_ERR_STATE; }
+  if (point_feature && ctx->assoc_point_feat.empty()) {
+    ctx->err = "balm_get_association: want_point_features was not set"; return BALM_ERR_STATE;
+  }
+  if (fix) std::memcpy(fix, ctx->assoc_fix.data(), ctx->assoc_fix.size() * sizeof(double));
+  if (point_feature) std::memcpy(point_feature, ctx->assoc_point_feat.data(), ctx->assoc_point_feat.size() * sizeof(int));
   return BALM_OK;
 }
 

@@ -83,7 +83,8 @@ struct balm_ctx {
   std::vector<int> planes_per_pose;
   double work_S = 0, work_B = 0;
   std::vector<double> assoc_clusters, assoc_coeffs;   // host copies of the last balm_associate
-  std::vector<int> assoc_layer;
+  std::vector<int> assoc_layer, assoc_point_feat;
+  std::vector<double> assoc_fix;
   void *d_arena = nullptr;          // balm_associate scratch, grown to what the last call needed
   size_t arena_cap = 0;
   balm_allreduce_fn allreduce = nullptr;
@@ -117,9 +118,16 @@ void launch_update_poses(hipStream_t s, int form, int W, const double *poses, co
 void launch_reanchor(hipStream_t s, int W, double *poses);
 
 // launchers (kernels_build.hip)
-int associate_device(hipStream_t s, const float *d_xyz, const int *d_frame, const double *d_poses, long n, int W,
-                     double voxel_size, const float thr[3], int min_ps, void *arena, size_t arena_cap, size_t *arena_need,
-                     int *F_out, double **d_out, double **d_coe, int **d_layer, long *n_roots);
+struct AssocOpts {
+  int W;                    // scans, the marginalised ones included
+  double voxel_size;
+  float thr[3];
+  int min_ps, layer_limit, min_observers, fix_frames;
+  double max_dis, ratio21_max, lam0_max;
+};
+int associate_device(hipStream_t s, const float *d_xyz, const int *d_frame, const double *d_poses, long n, const AssocOpts &o,
+                     void *arena, size_t arena_cap, size_t *arena_need, int *F_out, double **d_out, double **d_coe,
+                     double **d_fix, int **d_layer, int **d_point_feat, long *n_roots);
 // launchers (kernels_cov.hip)
 int cov_factors_grid(int W, int F);
 void launch_cov_factors(hipStream_t s, const double *cl, const double *ccov, double sigma2, const double *poses,

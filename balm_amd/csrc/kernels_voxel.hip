@@ -34,7 +34,11 @@ struct VoxParams {
   double voxel_size;
   float thr[3];
   int min_ps;
-  int W;
+  int W;                  // scans, the marginalised ones included
+  int layer_limit;        // deepest octree layer that may become a feature (bavoxel.hpp:8; 0..2)
+  int min_observers;      // push_voxel's minimum number of observing scans (bavoxel.hpp:32-37: 2; BAs_left.hpp:38: none)
+  int fix_frames;         // leading scans folded into world-frame fix clusters (to_margi, bavoxel.hpp:778-816)
+  double max_dis, ratio21_max, lam0_max;     // the consistency driver's plane test (BAs_left.hpp:674); 0 = off
 };
 
 __device__ __forceinline__ void world_point(const float *__restrict__ xyz, const double *__restrict__ pose, long p,
@@ -272,24 +276,39 @@ __global__ void k_level_heads(const unsigned long long *__restrict__ seg_ck, con
 
 __global__ void k_set_u32(unsigned int *p, unsigned int v) { *p = v; }
 
-struct NodeTot { double c[10]; int minf, maxf; };
+struct NodeTot {
+  double c[10];        // world cluster over all scans (judge_eigen)
+  double fixc[10];     // world cluster of the marginalised scans (fix_point after to_margi)
+  double nrest;        // points in the scans that stay
+  int nobs;            // scans that stay and observe the node
+};
 
 // node totals: the per-frame world clusters added in frame order (= judge_eigen's `covMat += sig_tran[i]`);
 // 16 lanes per node, lane c < 10 owns component c (coalesced 80-byte rows)
 __global__ __launch_bounds__(256) void k_node_totals(const double *__restrict__ seg_world,
                                                      const unsigned long long *__restrict__ seg_ck,
-                                                     const unsigned int *__restrict__ node_seg, long NN, NodeTot *__restrict__ tot) {
+                                                     const unsigned int *__restrict__ node_seg, long NN, int fix_frames,
+                                                     NodeTot *__restrict__ tot) {
   const long j = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
   const int c = threadIdx.x & 15;
   if (j >= NN) return;
   const unsigned int s0 = node_seg[j], s1 = node_seg[j + 1];
   if (c < 10) {
-    double t = 0.0;
-    for (unsigned int s = s0; s < s1; s++) t = __dadd_rn(t, seg_world[(size_t)s * 10 + c]);
+    double t = 0.0, fx = 0.0;
+    for (unsigned int s = s0; s < s1; s++) {
+      const double v = seg_world[(size_t)s * 10 + c];
+      t = __dadd_rn(t, v);
+      if ((int)(seg_ck[s] & 511ull) < fix_frames) fx = __dadd_rn(fx, v);
+    }
     tot[j].c[c] = t;
+    tot[j].fixc[c] = fx;
   } else if (c == 10) {
-    tot[j].minf = (int)(seg_ck[s0] & 511ull);
-    tot[j].maxf = (int)(seg_ck[s1 - 1] & 511ull);
+    double nrest = 0.0;
+    int nobs = 0;
+    for (unsigned int s = s0; s < s1; s++)
+      if ((int)(seg_ck[s] & 511ull) >= fix_frames) { nrest += seg_world[(size_t)s * 10 + 9]; nobs++; }
+    tot[j].nrest = nrest;
+    tot[j].nobs = nobs;
   }
 }
 
@@ -323,28 +342,104 @@ __device__ void eigvals3(double a00, double a01, double a02, double a11, double 
 // 2 = not a plane (the node is split, or dies at the last layer)
 enum { NODE_DEAD = 0, NODE_PLANE = 1, NODE_SPLIT = 2 };
 
-__global__ __launch_bounds__(128) void k_node_status(const NodeTot *__restrict__ tot, long NN, float thr, int min_ps,
-                                                     unsigned char *__restrict__ status) {
+// eigenvectors too (rotations accumulated in the same sweeps): the strict test needs the plane normal
+__device__ void eig3_vec(double a00, double a01, double a02, double a11, double a12, double a22, double lam[3], double nrm[3]) {
+  double A[3][3] = {{a00, a01, a02}, {a01, a11, a12}, {a02, a12, a22}};
+  double V[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+  for (int sweep = 0; sweep < 60; sweep++) {
+    const double off = A[0][1] * A[0][1] + A[0][2] * A[0][2] + A[1][2] * A[1][2];
+    const double dia = A[0][0] * A[0][0] + A[1][1] * A[1][1] + A[2][2] * A[2][2];
+    if (off <= 1e-300 || off <= 1e-34 * dia) break;
+#pragma unroll
+    for (int t = 0; t < 3; t++) {
+      const int p = t == 2 ? 1 : 0, q = t == 0 ? 1 : 2, r = 3 - p - q;
+      if (A[p][q] == 0.0) continue;
+      const double theta = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
+      const double tt = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+      const double c = 1.0 / sqrt(tt * tt + 1.0), sn = tt * c;
+      A[p][p] -= tt * A[p][q]; A[q][q] += tt * A[p][q]; A[p][q] = A[q][p] = 0.0;
+      const double rp = c * A[r][p] - sn * A[r][q], rq = sn * A[r][p] + c * A[r][q];
+      A[r][p] = A[p][r] = rp; A[r][q] = A[q][r] = rq;
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        const double vp = c * V[k][p] - sn * V[k][q], vq = sn * V[k][p] + c * V[k][q];
+        V[k][p] = vp; V[k][q] = vq;
+      }
+    }
+  }
+  int i0 = 0;
+  if (A[1][1] < A[i0][i0]) i0 = 1;
+  if (A[2][2] < A[i0][i0]) i0 = 2;
+  double x = A[0][0], y = A[1][1], z = A[2][2], t;
+  if (x > y) { t = x; x = y; y = t; }
+  if (y > z) { t = y; y = z; z = t; }
+  if (x > y) { t = x; x = y; y = t; }
+  lam[0] = x; lam[1] = y; lam[2] = z;
+  nrm[0] = V[0][i0]; nrm[1] = V[1][i0]; nrm[2] = V[2][i0];
+}
+
+// plane[j] (strict mode only): normal(3), centre(3) of the candidate planes, for the distance pass
+__global__ __launch_bounds__(128) void k_node_status(const NodeTot *__restrict__ tot, long NN, float thr, VoxParams pr,
+                                                     unsigned char *__restrict__ status, double *__restrict__ plane) {
   const long j = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= NN) return;
   const NodeTot t = tot[j];
   int st = NODE_DEAD;
-  if ((int)t.c[9] > min_ps) {
+  if ((int)t.c[9] > pr.min_ps) {
     const double n = t.c[9], cx = t.c[6] / n, cy = t.c[7] / n, cz = t.c[8] / n;
     double lam[3];
-    eigvals3(t.c[0] / n - cx * cx, t.c[1] / n - cx * cy, t.c[2] / n - cx * cz, t.c[3] / n - cy * cy, t.c[4] / n - cy * cz,
-             t.c[5] / n - cz * cz, lam);
-    st = lam[0] / lam[1] < (double)thr ? NODE_PLANE : NODE_SPLIT;
+    const double a00 = t.c[0] / n - cx * cx, a01 = t.c[1] / n - cx * cy, a02 = t.c[2] / n - cx * cz, a11 = t.c[3] / n - cy * cy,
+                 a12 = t.c[4] / n - cy * cz, a22 = t.c[5] / n - cz * cz;
+    if (!plane) {
+      eigvals3(a00, a01, a02, a11, a12, a22, lam);
+      st = lam[0] / lam[1] < (double)thr ? NODE_PLANE : NODE_SPLIT;
+    } else {
+      double nrm[3];
+      eig3_vec(a00, a01, a02, a11, a12, a22, lam, nrm);
+      const bool ok = lam[0] / lam[1] < (double)thr && (pr.ratio21_max <= 0 || lam[2] / lam[1] < pr.ratio21_max) &&
+                      (pr.lam0_max <= 0 || lam[0] < pr.lam0_max);
+      st = ok ? NODE_PLANE : NODE_SPLIT;
+      double *pl = plane + (size_t)j * 6;
+      pl[0] = nrm[0]; pl[1] = nrm[1]; pl[2] = nrm[2]; pl[3] = cx; pl[4] = cy; pl[5] = cz;
+    }
   }
   status[j] = (unsigned char)st;
 }
 
+// strict mode: a candidate plane with a point farther than max_dis from it is not a plane (BAs_left.hpp:658-674).
+// One lane per point of the level's sorted list; a node is demoted by whichever of its points finds the violation.
+__global__ __launch_bounds__(256) void k_point_plane_dist(const float *__restrict__ xyz, const int *__restrict__ frame,
+                                                          const double *__restrict__ poses, const unsigned int *__restrict__ idx,
+                                                          const unsigned int *__restrict__ segid_incl,
+                                                          const unsigned int *__restrict__ nid_incl, long n,
+                                                          const double *__restrict__ plane, double max_dis,
+                                                          unsigned char *__restrict__ status) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const unsigned int j = nid_incl[segid_incl[i] - 1] - 1;
+  if (status[j] != NODE_PLANE) return;
+  const long p = idx[i];
+  double q[3], po[3];
+  world_point(xyz, poses + 12 * (long)frame[p], p, q, po);
+  const double *pl = plane + (size_t)j * 6;
+  const double d = fabs(pl[0] * (q[0] - pl[3]) + pl[1] * (q[1] - pl[4]) + pl[2] * (q[2] - pl[5]));
+  if (!(d < max_dis)) status[j] = NODE_SPLIT;       // benign race: every writer stores the same value
+}
+
+// node id of every point at this level (for the point -> feature map)
+__global__ void k_point_nodes(const unsigned int *__restrict__ idx, const unsigned int *__restrict__ segid_incl,
+                              const unsigned int *__restrict__ nid_incl, long n, unsigned int *__restrict__ node_of_point) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) node_of_point[idx[i]] = nid_incl[segid_incl[i] - 1] - 1;
+}
+
 // recut's descent (bavoxel.hpp:737-776) + tras_opt / push_voxel (:908-929, :30-37): a node is a feature when
-// every ancestor was split, it is a plane, and at least two scans observe it
+// every ancestor was split, it is a plane with more than min_ps points, the scans that stay hold at least min_ps
+// of them and at least min_observers of those scans observe it
 __global__ void k_feature_flags(int level, long NN, const NodeTot *__restrict__ tot, const unsigned char *__restrict__ st0,
                                 const unsigned char *__restrict__ st1, const unsigned char *__restrict__ st2,
                                 const unsigned int *__restrict__ parent1, const unsigned int *__restrict__ parent2,
-                                unsigned int *__restrict__ flag) {
+                                VoxParams pr, unsigned int *__restrict__ flag) {
   const long j = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= NN) return;
   bool live;
@@ -354,25 +449,47 @@ __global__ void k_feature_flags(int level, long NN, const NodeTot *__restrict__ 
     const unsigned int p1 = parent2[j];
     live = st2[j] == NODE_PLANE && st1[p1] == NODE_SPLIT && st0[parent1[p1]] == NODE_SPLIT;
   }
-  flag[j] = (live && tot[j].minf != tot[j].maxf) ? 1u : 0u;
+  const NodeTot &t = tot[j];
+  flag[j] = (live && (int)t.nrest >= pr.min_ps && t.nobs >= pr.min_observers && t.nobs >= 1) ? 1u : 0u;
 }
 
-// per-(feature, pose) body clusters = the feature node's own segments (sig_orig), weight = sum_i N_i;
+__global__ void k_point_features(long n, int levels, const unsigned int *__restrict__ node0, const unsigned int *__restrict__ node1,
+                                 const unsigned int *__restrict__ node2, const unsigned int *__restrict__ flag0,
+                                 const unsigned int *__restrict__ flag1, const unsigned int *__restrict__ flag2,
+                                 const unsigned int *__restrict__ fid0, const unsigned int *__restrict__ fid1,
+                                 const unsigned int *__restrict__ fid2, unsigned int base1, unsigned int base2,
+                                 int *__restrict__ feat_of_point) {
+  const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  int f = -1;
+  unsigned int j = node0[p];
+  if (flag0[j]) f = (int)fid0[j];
+  if (f < 0 && levels > 1) { j = node1[p]; if (flag1[j]) f = (int)(base1 + fid1[j]); }
+  if (f < 0 && levels > 2) { j = node2[p]; if (flag2[j]) f = (int)(base2 + fid2[j]); }
+  feat_of_point[p] = f;
+}
+
+// per-(feature, pose) body clusters = the feature node's own segments (sig_orig) of the scans that stay, shifted by
+// the marginalised ones; weight = sum_i N_i over them; fix cluster = the marginalised scans' world cluster.
 // 16 lanes per node, lane c < 10 copies component c
 __global__ __launch_bounds__(256) void k_emit(long NN, const unsigned int *__restrict__ flag,
                                               const unsigned int *__restrict__ fid_excl, unsigned int fid_base,
                                               const unsigned int *__restrict__ node_seg, const unsigned long long *__restrict__ seg_ck,
-                                              const double *__restrict__ seg_body, const NodeTot *__restrict__ tot, int W, int layer,
-                                              double *__restrict__ out, double *__restrict__ coe, int *__restrict__ layer_out) {
+                                              const double *__restrict__ seg_body, const NodeTot *__restrict__ tot, int Wout,
+                                              int fix_frames, int layer, double *__restrict__ out, double *__restrict__ coe,
+                                              double *__restrict__ fixout, int *__restrict__ layer_out) {
   const long j = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
   const int c = threadIdx.x & 15;
   if (j >= NN || !flag[j]) return;
   const size_t f = fid_base + fid_excl[j];
   if (c < 10) {
-    for (unsigned int s = node_seg[j]; s < node_seg[j + 1]; s++)
-      out[(f * W + (size_t)(seg_ck[s] & 511ull)) * 10 + c] = seg_body[(size_t)s * 10 + c];
+    for (unsigned int s = node_seg[j]; s < node_seg[j + 1]; s++) {
+      const int fr = (int)(seg_ck[s] & 511ull) - fix_frames;
+      if (fr >= 0) out[(f * Wout + (size_t)fr) * 10 + c] = seg_body[(size_t)s * 10 + c];
+    }
+    fixout[f * 10 + c] = tot[j].fixc[c];
   } else if (c == 10) {
-    coe[f] = tot[j].c[9];     // VOX_HESS::push_voxel weight = sum_i N_i (bavoxel.hpp:42-44)
+    coe[f] = tot[j].nrest;     // VOX_HESS::push_voxel weight = sum_i N_i (bavoxel.hpp:42-44)
     layer_out[f] = layer;
   }
 }
@@ -437,15 +554,23 @@ struct Level {
 
 }  // namespace
 
-// Device-side association.  d_xyz [n][3], d_frame [n] (0..W-1, points of a frame in scan order), d_poses [W][12].
-// `arena` / `arena_cap`: caller-owned scratch (may be NULL / 0); *arena_need receives the bytes this call wanted.
-// On success *F_out features; *d_out = hipMalloc'ed [F][W][10] (caller frees), *d_coe = [F], *d_layer = [F].
-// Returns 0, or a negative code (-1 allocation / HIP failure, -2 unsupported size).
-int associate_device(hipStream_t s, const float *d_xyz, const int *d_frame, const double *d_poses, long n, int W,
-                     double voxel_size, const float thr[3], int min_ps, void *arena, size_t arena_cap, size_t *arena_need,
-                     int *F_out, double **d_out, double **d_coe, int **d_layer, long *n_roots) {
-  *F_out = 0; *d_out = nullptr; *d_coe = nullptr; *d_layer = nullptr; *n_roots = 0;
-  if (W > 512 || n <= 0 || n >= (1l << 31)) return -2;
+// Device-side association.  d_xyz [n][3], d_frame [n] (0..W-1, points of a frame in scan order), d_poses [W][12],
+// W = scans including the `fix_frames` marginalised ones.  `arena` / `arena_cap`: caller-owned scratch (may be NULL / 0);
+// *arena_need receives the bytes this call wanted.  On success *F_out features; *d_out = hipMalloc'ed
+// [F][W - fix_frames][10] (caller frees), *d_coe = [F], *d_fix = [F][10], *d_layer = [F], and, when want_points,
+// *d_point_feat = [n] feature of every point (-1: none).  Returns 0, or a negative code (-1 allocation / HIP
+// failure, -2 unsupported size).
+int associate_device(hipStream_t s, const float *d_xyz, const int *d_frame, const double *d_poses, long n, const AssocOpts &o,
+                     void *arena, size_t arena_cap, size_t *arena_need, int *F_out, double **d_out, double **d_coe,
+                     double **d_fix, int **d_layer, int **d_point_feat, long *n_roots) {
+  *F_out = 0; *d_out = nullptr; *d_coe = nullptr; *d_fix = nullptr; *d_layer = nullptr; *n_roots = 0;
+  if (d_point_feat) *d_point_feat = nullptr;
+  const int W = o.W;
+  if (W > 512 || n <= 0 || n >= (1l << 31) || o.layer_limit < 0 || o.layer_limit > 2 || o.fix_frames < 0 || o.fix_frames >= W)
+    return -2;
+  const bool strict = o.max_dis > 0 || o.ratio21_max > 0 || o.lam0_max > 0;
+  const bool want_points = d_point_feat != nullptr;
+  const int levels = o.layer_limit + 1;
   Scratch sc(arena, arena_cap);
   struct NeedOut { Scratch &sc; size_t *out; ~NeedOut() { *out = sc.need; } } need_out{sc, arena_need};
   const int B = 256;
@@ -455,12 +580,14 @@ int associate_device(hipStream_t s, const float *d_xyz, const int *d_frame, cons
   auto *flag = sc.get<unsigned int>(n), *rootid = sc.get<unsigned int>(n), *incl = sc.get<unsigned int>(n);
   auto *cks = sc.get<unsigned long long>(n);
   auto *range = sc.get<int>(6 * RANGE_BLOCKS);
+  unsigned int *pnode[3] = {nullptr, nullptr, nullptr};
+  if (want_points) for (int L = 0; L < levels; L++) pnode[L] = sc.get<unsigned int>(n);
   if (!sc.ok) return -1;
 
   // pass A: key range -> digits needed per axis
   const int rblocks = std::min(grid_for(n, B), RANGE_BLOCKS);
   std::vector<int> h_rows((size_t)6 * rblocks);
-  hipLaunchKernelGGL(k_vox_range, dim3(rblocks), dim3(B), 0, s, d_xyz, d_frame, d_poses, n, voxel_size, range);
+  hipLaunchKernelGGL(k_vox_range, dim3(rblocks), dim3(B), 0, s, d_xyz, d_frame, d_poses, n, o.voxel_size, range);
   hipMemcpyAsync(h_rows.data(), range, h_rows.size() * sizeof(int), hipMemcpyDeviceToHost, s);
   if (hipStreamSynchronize(s) != hipSuccess) return -1;
   int h_range[6] = {1 << 30, 1 << 30, 1 << 30, -(1 << 30), -(1 << 30), -(1 << 30)};
@@ -481,7 +608,7 @@ int associate_device(hipStream_t s, const float *d_xyz, const int *d_frame, cons
 
   auto root_keys = [&](auto *ka, auto *kb) {     // 32-bit radix keys whenever the packed key fits
     using K = std::remove_pointer_t<decltype(ka)>;
-    hipLaunchKernelGGL((k_vox_keys<K>), dim3(grid_for(n, B)), dim3(B), 0, s, d_xyz, d_frame, d_poses, n, voxel_size, kp, ka, val);
+    hipLaunchKernelGGL((k_vox_keys<K>), dim3(grid_for(n, B)), dim3(B), 0, s, d_xyz, d_frame, d_poses, n, o.voxel_size, kp, ka, val);
     sort_pairs(sc, s, ka, kb, val, vals, n, key_bits);
     hipLaunchKernelGGL((k_head_flags<K>), dim3(grid_for(n, B)), dim3(B), 0, s, kb, n, 0, flag);
   };
@@ -493,10 +620,11 @@ int associate_device(hipStream_t s, const float *d_xyz, const int *d_frame, cons
   int root_bits = 1;
   while ((1l << root_bits) < NR) root_bits++;
 
-  VoxParams pr{voxel_size, {thr[0], thr[1], thr[2]}, min_ps, W};
+  VoxParams pr{o.voxel_size, {o.thr[0], o.thr[1], o.thr[2]}, o.min_ps, W, o.layer_limit, o.min_observers, o.fix_frames,
+               o.max_dis, o.ratio21_max, o.lam0_max};
   Level lv[3];
   const unsigned long long attr_mask[3] = {0x1ffull, (0x38ull << 9) | 0x1ffull, (0x3full << 9) | 0x1ffull};
-  for (int L = 0; L < 3; L++) {
+  for (int L = 0; L < levels; L++) {
     Level &v = lv[L];
     auto level_keys = [&](auto *ka, auto *kb) {
       using K = std::remove_pointer_t<decltype(ka)>;
@@ -541,48 +669,54 @@ int associate_device(hipStream_t s, const float *d_xyz, const int *d_frame, cons
     v.status = sc.get<unsigned char>(v.NN);
     v.flag = sc.get<unsigned int>(v.NN + 1);
     v.fid = sc.get<unsigned int>(v.NN + 1);
+    double *plane = strict ? sc.get<double>((size_t)v.NN * 6) : nullptr;
     if (!sc.ok) return -1;
     hipLaunchKernelGGL(k_level_heads, dim3(grid_for(v.NS, B)), dim3(B), 0, s, v.seg_ck, nid, pid, v.NS, pshift, v.node_seg,
                        v.node_parent);
     hipLaunchKernelGGL(k_set_u32, dim3(1), dim3(1), 0, s, v.node_seg + v.NN, (unsigned int)v.NS);
-    hipLaunchKernelGGL(k_node_totals, dim3(grid_for(v.NN * 16, B)), dim3(B), 0, s, seg_world, v.seg_ck, v.node_seg, v.NN, v.tot);
-    hipLaunchKernelGGL(k_node_status, dim3(grid_for(v.NN, 128)), dim3(128), 0, s, v.tot, v.NN, pr.thr[L], pr.min_ps, v.status);
+    hipLaunchKernelGGL(k_node_totals, dim3(grid_for(v.NN * 16, B)), dim3(B), 0, s, seg_world, v.seg_ck, v.node_seg, v.NN,
+                       o.fix_frames, v.tot);
+    hipLaunchKernelGGL(k_node_status, dim3(grid_for(v.NN, 128)), dim3(128), 0, s, v.tot, v.NN, pr.thr[L], pr, v.status, plane);
+    if (strict && o.max_dis > 0)
+      hipLaunchKernelGGL(k_point_plane_dist, dim3(grid_for(n, B)), dim3(B), 0, s, d_xyz, d_frame, d_poses, idxL, incl, nid, n, plane,
+                         o.max_dis, v.status);
+    if (want_points) hipLaunchKernelGGL(k_point_nodes, dim3(grid_for(n, B)), dim3(B), 0, s, idxL, incl, nid, n, pnode[L]);
     hipMemsetAsync(v.flag + v.NN, 0, sizeof(unsigned int), s);
   }
   if (lv[0].NN != NR) return -1;
-  unsigned int FL[3];
-  for (int L = 0; L < 3; L++) {
+  unsigned int FL[3] = {0, 0, 0};
+  for (int L = 0; L < levels; L++) {
     hipLaunchKernelGGL(k_feature_flags, dim3(grid_for(lv[L].NN, B)), dim3(B), 0, s, L, lv[L].NN, lv[L].tot, lv[0].status,
-                       lv[1].status, lv[2].status, lv[1].node_parent, lv[2].node_parent, lv[L].flag);
+                       lv[1].status, lv[2].status, lv[1].node_parent, lv[2].node_parent, pr, lv[L].flag);
     scan_excl(sc, s, lv[L].flag, lv[L].fid, lv[L].NN + 1);
   }
   if (!sc.ok) return -1;
-  for (int L = 0; L < 3; L++) FL[L] = last_u32(s, lv[L].fid, lv[L].NN + 1);
+  for (int L = 0; L < levels; L++) FL[L] = last_u32(s, lv[L].fid, lv[L].NN + 1);
   const long F = (long)FL[0] + FL[1] + FL[2];
   *n_roots = NR;
   if (hipGetLastError() != hipSuccess) return -1;
   if (F == 0) return 0;
-  double *out = nullptr, *coe = nullptr;
-  int *lay = nullptr;
-  if (hipMalloc((void **)&out, (size_t)F * W * 10 * sizeof(double)) != hipSuccess ||
+  const int Wout = W - o.fix_frames;
+  double *out = nullptr, *coe = nullptr, *fixo = nullptr;
+  int *lay = nullptr, *pf = nullptr;
+  auto fail = [&]() { if (out) hipFree(out); if (coe) hipFree(coe); if (fixo) hipFree(fixo); if (lay) hipFree(lay); if (pf) hipFree(pf); return -1; };
+  if (hipMalloc((void **)&out, (size_t)F * Wout * 10 * sizeof(double)) != hipSuccess ||
       hipMalloc((void **)&coe, (size_t)F * sizeof(double)) != hipSuccess ||
-      hipMalloc((void **)&lay, (size_t)F * sizeof(int)) != hipSuccess) {
-    if (out) hipFree(out);
-    if (coe) hipFree(coe);
-    return -1;
-  }
-  hipMemsetAsync(out, 0, (size_t)F * W * 10 * sizeof(double), s);
-  unsigned int base = 0;
-  for (int L = 0; L < 3; L++) {
-    hipLaunchKernelGGL(k_emit, dim3(grid_for(lv[L].NN * 16, B)), dim3(B), 0, s, lv[L].NN, lv[L].flag, lv[L].fid, base,
-                       lv[L].node_seg, lv[L].seg_ck, lv[L].seg_body, lv[L].tot, W, L, out, coe, lay);
-    base += FL[L];
-  }
-  if (hipStreamSynchronize(s) != hipSuccess || hipGetLastError() != hipSuccess) {
-    hipFree(out); hipFree(coe); hipFree(lay);
-    return -1;
-  }
-  *F_out = (int)F; *d_out = out; *d_coe = coe; *d_layer = lay;
+      hipMalloc((void **)&fixo, (size_t)F * 10 * sizeof(double)) != hipSuccess ||
+      hipMalloc((void **)&lay, (size_t)F * sizeof(int)) != hipSuccess ||
+      (want_points && hipMalloc((void **)&pf, (size_t)n * sizeof(int)) != hipSuccess))
+    return fail();
+  hipMemsetAsync(out, 0, (size_t)F * Wout * 10 * sizeof(double), s);
+  unsigned int base[3] = {0, FL[0], FL[0] + FL[1]};
+  for (int L = 0; L < levels; L++)
+    hipLaunchKernelGGL(k_emit, dim3(grid_for(lv[L].NN * 16, B)), dim3(B), 0, s, lv[L].NN, lv[L].flag, lv[L].fid, base[L],
+                       lv[L].node_seg, lv[L].seg_ck, lv[L].seg_body, lv[L].tot, Wout, o.fix_frames, L, out, coe, fixo, lay);
+  if (want_points)
+    hipLaunchKernelGGL(k_point_features, dim3(grid_for(n, B)), dim3(B), 0, s, n, levels, pnode[0], pnode[1], pnode[2], lv[0].flag,
+                       lv[1].flag, lv[2].flag, lv[0].fid, lv[1].fid, lv[2].fid, base[1], base[2], pf);
+  if (hipStreamSynchronize(s) != hipSuccess || hipGetLastError() != hipSuccess) return fail();
+  *F_out = (int)F; *d_out = out; *d_coe = coe; *d_fix = fixo; *d_layer = lay;
+  if (want_points) *d_point_feat = pf;
   return 0;
 }
 

@@ -109,12 +109,15 @@ def associate(frames_xyz, poses, voxel_size=2.0, eigen_thresholds=(1.0 / 16, 1.0
     return cl, co, layer
 
 
-def associate_gpu(ctx, frames_xyz, poses, voxel_size=2.0, eigen_thresholds=(1.0 / 16, 1.0 / 16, 1.0 / 9), min_ps=15,
-                  want_features=True):
-    """Same contract as `associate`, on the device through balm_associate; the features are installed in `ctx`."""
+def associate_gpu(ctx, frames_xyz, poses, voxel_size=2.0, eigen_thresholds=(1.0 / 16, 1.0 / 16, 1.0 / 9), layer_limit=2,
+                  min_ps=15, strict=None, fix_frames=0, min_observers=2, want_points=False, want_features=True):
+    """Same contract and rule set as `associate` (e.g. `**SIM_RULES`), on the device through balm_associate; the
+    features are installed in `ctx` (a context for len(frames_xyz) - fix_frames poses).  -> (F, n_root_voxels,
+    feature tuple or None); the point -> feature map refers to the concatenation of the scans."""
     xyz = np.concatenate([np.ascontiguousarray(f, dtype=np.float32).reshape(-1, 3) for f in frames_xyz])
     fid = np.concatenate([np.full(f.shape[0], i, dtype=np.int32) for i, f in enumerate(frames_xyz)])
-    return ctx.associate(xyz, fid, poses, voxel_size, eigen_thresholds, min_ps, want_features)
+    return ctx.associate(xyz, fid, poses, voxel_size, eigen_thresholds, min_ps, want_features, layer_limit, min_observers,
+                         fix_frames, strict, want_points)
 
 
 def canonical_order(clusters, coeffs):

@@ -114,24 +114,45 @@ int balm_build_clusters(balm_ctx *ctx, int F, const float *xyz, const int *feat_
 
 /* Replaces the caller's association stage: cut_voxel over every scan, OCTO_TREE_NODE::recut and
  * ::tras_opt over every root voxel (bavoxel.hpp:1170-1223, 654-776, 908-929;
- * benchmark_realworld.cpp:183-200).  Points are body-frame floats with the index (0..W-1) of the
- * scan they belong to, in scan order; `poses` are the W initial poses.  Every voxel-membership and
+ * benchmark_realworld.cpp:183-200).  Points are body-frame floats with the index of the scan they
+ * belong to, in scan order; `poses` are the initial poses of all scans.  Every voxel-membership and
  * plane decision uses the reference's float/double types and operation order, so the feature set
- * (and every N) equals the reference's.  The features (body-frame clusters, weight = sum_i N_i,
- * empty fix clusters) are installed like balm_set_features; their order is (layer, voxel key),
- * not the reference's hash-map order -- the optimizer does not depend on it.  layer_limit is the
- * reference's 2 (bavoxel.hpp:11).  *F_out = 0 (and BALM_OK) when no plane was found. */
+ * (and every N) equals the reference's.  The features (body-frame clusters, weight = sum_i N_i) are
+ * installed like balm_set_features; their order is (layer, voxel key), not the reference's hash-map
+ * order -- the optimizer does not depend on it.  *F_out = 0 (and BALM_OK) when no plane was found.
+ *
+ * The globals of the reference's association are fields here.  balm_voxel_defaults() fills the
+ * benchmark drivers' values (bavoxel.hpp:8-15, launch/benchmark_realworld.launch).  The consistency
+ * driver's copy of the state machine (src/simulation/BAs_left.hpp:18-23, 647-815; consistency.cpp:
+ * 96-150) is the same code with layer_limit 0, thresholds 1/64, min_ps 10, min_observers 0, the
+ * stricter plane test (max_plane_dist 1e-3, max_lambda21 25, max_lambda0 1e-10) and fix_frames 1:
+ * the window's first scan(s) are marginalised into world-frame fix clusters (to_margi,
+ * bavoxel.hpp:778-816, batch form).  With fix_frames = m the context's win_size counts the scans
+ * that stay: frame_id runs over 0..win_size+m-1 and `poses` holds win_size+m poses. */
 typedef struct balm_voxel_opts {
-  double voxel_size;        /* benchmark_realworld.cpp:150 -> 1.0 in the shipped launch file    */
-  float eigen_thr[3];       /* per layer; bavoxel.hpp:11 / launch file: 1/16, 1/16, 1/9         */
-  int min_ps;               /* bavoxel.hpp:12: 15                                               */
+  double voxel_size;        /* benchmark_realworld.cpp:150 -> launch file                        */
+  float eigen_thr[3];       /* per layer; bavoxel.hpp:11 / launch file: 1/16, 1/16, 1/9          */
+  int min_ps;               /* bavoxel.hpp:12: 15                                                */
+  int layer_limit;          /* bavoxel.hpp:8: 2 (0..2 supported)                                 */
+  int min_observers;        /* VOX_HESS::push_voxel, bavoxel.hpp:32-37: 2                        */
+  int fix_frames;           /* 0 for the benchmark drivers                                       */
+  double max_plane_dist;    /* 0 = off; BAs_left.hpp:674                                         */
+  double max_lambda21;      /* 0 = off                                                           */
+  double max_lambda0;       /* 0 = off                                                           */
+  int want_point_features;  /* keep the point -> feature map for balm_get_association            */
 } balm_voxel_opts;
+void balm_voxel_defaults(balm_voxel_opts *opts);
 int balm_associate(balm_ctx *ctx, const balm_voxel_opts *opts, const float *xyz, const int *frame_id,
                    long n_pts, const double *poses, int *F_out, long *n_root_voxels);
 
 /* Host copies of the feature table installed by the last balm_associate: clusters F*W*10, coeffs F,
  * layer F (octree depth of the feature's voxel).  Any pointer may be NULL. */
 int balm_get_features(balm_ctx *ctx, double *clusters, double *coeffs, int *layer);
+
+/* ... and its fix clusters (F*10, zero without fix_frames) and, if want_point_features was set, the
+ * feature index of every input point (n_pts ints, -1 = the point belongs to no feature): what
+ * OCTO_TREE_NODE::corrupt / a re-build of the clusters (balm_build_clusters) needs. */
+int balm_get_association(balm_ctx *ctx, double *fix, int *point_feature);
 
 /* Replaces the covariance tail of the consistency experiment's BALM2::damping_iter
  * (src/simulation/BAs_left.hpp:1089-1096): Hess at `poses` (left form), VOX_HESS::left_jacobian_point summed

@@ -65,14 +65,14 @@ class BALM2_HIP {
   // Replaces the association block of the reference's drivers (benchmark_realworld.cpp:183-200: cut_voxel per
   // scan into the surf_map, OCTO_TREE_ROOT::recut, ::tras_opt -> VOX_HESS::push_voxel) with one device call.
   // Reads the same globals the reference's code reads: win_size, voxel_size, eigen_value_array, min_ps
-  // (bavoxel.hpp:11-17); layer_limit must be the reference's 2.  `Cloud` is pcl::PointCloud<PointType>::Ptr (any
+  // (bavoxel.hpp:8-17; layer_limit 0..2).  `Cloud` is pcl::PointCloud<PointType>::Ptr (any
   // pointer to a container of points with float x, y, z).  Returns the number of plane features, which are
   // installed on the device: follow with damping_iter(x_stats).
   template <class CloudPtr>
   int associate(const std::vector<CloudPtr> &pl_fulls, const std::vector<IMUST> &x_buf) {
     ensure_ctx();
-    if (layer_limit != 2 || (int)pl_fulls.size() != win_size || (int)x_buf.size() != win_size) {
-      fprintf(stderr, "balm_hip: associate needs layer_limit == 2 and win_size scans and poses\n");
+    if (layer_limit < 0 || layer_limit > 2 || (int)pl_fulls.size() != win_size || (int)x_buf.size() != win_size) {
+      fprintf(stderr, "balm_hip: associate needs layer_limit in 0..2 and win_size scans and poses\n");
       abort();
     }
     size_t n = 0;
@@ -87,9 +87,11 @@ class BALM2_HIP {
       }
     std::vector<double> poses = flatten_poses(x_buf);
     balm_voxel_opts o;
+    balm_voxel_defaults(&o);
     o.voxel_size = voxel_size;
     for (int l = 0; l < 3; l++) o.eigen_thr[l] = eigen_value_array[l];
     o.min_ps = min_ps;
+    o.layer_limit = layer_limit;
     int F = 0;
     long roots = 0;
     check(balm_associate(ctx_, &o, xyz.data(), frame.data(), (long)n, poses.data(), &F, &roots));

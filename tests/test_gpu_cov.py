@@ -161,7 +161,7 @@ def test_cpp_shim_dropin_for_the_consistency_driver():
 
 def test_consistency_experiment_on_shipped_scans():
     """src/simulation/consistency.cpp end to end on its own shipped data (datas/consistency: 101 simulated scans):
-    association with that driver's rules (host), per run noise -> device cluster build -> device LM -> device
+    association with that driver's rules (on the device; once more on the host), per run noise -> device cluster build -> device LM -> device
     covariance -> NEES.  The reference prints "The expected NEES is 6*100 = 600"."""
     path = os.path.join(ROOT, "oracle", "_ref", "consistency_scans.npz")
     if not os.path.exists(path):
@@ -169,7 +169,9 @@ def test_consistency_experiment_on_shipped_scans():
     d = np.load(path)
     frames = np.split(d["xyz"], np.cumsum(d["counts"])[:-1])
     c = capi.Context(100)
-    vals, F = consistency.monte_carlo(c, frames, d["poses"], pnoise=0.02, runs=4, seed=7)
+    vals, F = consistency.monte_carlo(c, frames, d["poses"], pnoise=0.02, runs=4, seed=7)          # association on the GPU too
+    vals_h, F_h = consistency.monte_carlo(c, frames, d["poses"], pnoise=0.02, runs=1, seed=7, gpu_assoc=False)
+    assert F_h == F and abs(vals_h[0] - 600) < 6 * np.sqrt(1200)         # same features; the noise lands on the points in another order
     c.close()
     vals = np.array(vals)
     print("consistency experiment: %d features, NEES %s (expected 600 +- 35)" % (F, np.round(vals, 1)))

@@ -45,7 +45,7 @@ def cluttered_window(seed, W, n_planes, pts_per_plane, n_clutter):
 
 def check_same_features(ctx, frames, poses, voxel, thr=(1.0 / 16, 1.0 / 16, 1.0 / 9), min_ps=15):
     cl_h, co_h, layer_h = rw.associate(frames, poses, voxel, thr, 2, min_ps)
-    F, nroots, feats = rw.associate_gpu(ctx, frames, poses, voxel, thr, min_ps)
+    F, nroots, feats = rw.associate_gpu(ctx, frames, poses, voxel, thr, min_ps=min_ps)
     assert F == cl_h.shape[0]
     if F == 0:
         return cl_h, layer_h
@@ -176,4 +176,53 @@ def test_device_association_wide_keys():
     c = capi.Context(W)
     cl, layer = check_same_features(c, frames, poses, 0.01)
     assert cl.shape[0] >= 1
+    c.close()
+
+
+def _canon_with_fix(cl, fix):
+    both = np.concatenate([cl.reshape(cl.shape[0], -1), fix], axis=1)
+    return both[np.lexsort(both[:, ::-1].T)]
+
+
+@pytest.mark.parametrize("layer_limit,min_observers,fix_frames", [(0, 2, 0), (1, 1, 0), (2, 0, 2), (1, 2, 1)])
+def test_device_association_rule_options(layer_limit, min_observers, fix_frames):
+    """the association's globals as options: layer_limit (bavoxel.hpp:8), push_voxel's observer minimum (:32-37),
+    marginalisation of the first scans into world-frame fix clusters (to_margi :778-816, batch form) -- against the
+    host association with the same rules; and the point -> feature map against the clusters it must rebuild"""
+    W = 10
+    poses, frames = cluttered_window(9, W + fix_frames, 50, 100, 2500)
+    kw = dict(voxel_size=1.0, layer_limit=layer_limit, min_observers=min_observers, fix_frames=fix_frames)
+    cl_h, co_h, lay_h, fix_h, _ = rw.associate(frames, poses, want_points=True, **kw)
+    c = capi.Context(W)
+    F, nroots, (cl, co, layer, fix, pf) = rw.associate_gpu(c, frames, poses, want_points=True, **kw)
+    assert F == cl_h.shape[0] and F > 5 and cl.shape == (F, W, 10)
+    assert np.array_equal(_canon_with_fix(cl, fix), _canon_with_fix(cl_h, fix_h))
+    assert layer.max() <= layer_limit and np.array_equal(np.bincount(layer, minlength=3), np.bincount(lay_h, minlength=3))
+    assert (fix[:, 9] > 0).any() == (fix_frames > 0)
+    # point -> feature map: counting the mapped points per (feature, scan) gives back every N
+    scan = np.concatenate([np.full(f.shape[0], i) for i, f in enumerate(frames)]) - fix_frames
+    keep = (pf >= 0) & (scan >= 0)
+    N = np.zeros((F, W))
+    np.add.at(N, (pf[keep], scan[keep]), 1)
+    assert np.array_equal(N, cl[..., 9])
+    # the features (fix clusters included) are installed: optimiser runs
+    out, lg = c.damping_iter(poses[fix_frames:], form=0, u0=0.01, max_iter=3)
+    assert np.isfinite(out).all()
+    c.close()
+
+
+def test_device_association_consistency_rules():
+    """the consistency driver's rule set (strict plane test on exact planes, layer_limit 0, first scan marginalised,
+    no observer minimum) against the host association, which tests/test_association.py pins to the reference's
+    compiled copy"""
+    from test_association import exact_plane_scans
+    poses, frames = exact_plane_scans(4, 9, 40, 60)
+    cl_h, co_h, lay_h, fix_h, _ = rw.associate(frames, poses, **rw.SIM_RULES)
+    c = capi.Context(8)
+    F, nroots, (cl, co, layer, fix, pf) = rw.associate_gpu(c, frames, poses, want_points=True, **rw.SIM_RULES)
+    assert F == cl_h.shape[0] >= 10
+    assert np.array_equal(_canon_with_fix(cl, fix), _canon_with_fix(cl_h, fix_h))
+    # without the strict test the clutter-contaminated voxels would pass the eigen-ratio test too
+    loose = dict(rw.SIM_RULES, strict=None)
+    assert rw.associate_gpu(c, frames, poses, **loose)[0] >= F
     c.close()
