@@ -80,14 +80,20 @@ class DeviceAllReduce:
         self.zero_copy = True
         self._stage = None
         self._hip = None
+        self._views = {}          # (ptr, n) -> tensor view: the library reuses its payload buffers
 
     def __call__(self, ptr, n):
         torch, dist = self.torch, self.dist
         if self.zero_copy:
             try:
-                t = torch.as_tensor(_DevMem(ptr, n), device="cuda")
-                if t.data_ptr() != ptr:
-                    raise RuntimeError("as_tensor copied")
+                t = self._views.get((ptr, n))
+                if t is None:
+                    t = torch.as_tensor(_DevMem(ptr, n), device="cuda")
+                    if t.data_ptr() != ptr:
+                        raise RuntimeError("as_tensor copied")
+                    if len(self._views) > 64:
+                        self._views.clear()
+                    self._views[(ptr, n)] = t
                 dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
                 torch.cuda.synchronize()
                 return
