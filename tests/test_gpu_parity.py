@@ -243,6 +243,46 @@ def test_full_width_window_properties(W, F):
     c.close()
 
 
+def test_bench_size_properties():
+    """BASELINE configs[2] at FULL size (W=200 poses, 50 000 features: the bench workload) through properties that
+    do not need the oracle at that size: feature sub-ranges add up, symmetry, weight linearity, translation-gauge
+    orthogonality of the gradient, the oracle on a random sample of the features through the sub-range entry, and
+    an LM run that must reach the ground truth."""
+    W, F = 200, 50000
+    sc = scene.generate(123, W, F, 6, mode=1)
+    c = capi.Context(W)
+    c.set_features(sc.clusters, None, sc.coeffs)
+    H, g, r = c.evaluate(0, sc.poses_init)
+    assert np.array_equal(H, H.T) and np.isfinite(H).all()
+    # (1) sub-ranges add up (the reference's thread split, bavoxel.hpp:1044-1056)
+    cut = 17321
+    H1, g1, r1 = c.evaluate(0, sc.poses_init, 0, cut)
+    H2, g2, r2 = c.evaluate(0, sc.poses_init, cut, F)
+    assert rel_err(H1 + H2, H) < 1e-12 and rel_err(g1 + g2, g) < 1e-12 and abs(r1 + r2 - r) / r < 1e-13
+    # (2) gauge: a common left translation leaves the residual unchanged
+    assert np.abs(g.reshape(W, 6)[:, 3:].sum(0)).max() < 1e-9 * np.abs(g).max()
+    # (3) the oracle on 48 consecutive features somewhere in the middle, via the sub-range entry
+    lo = 31007
+    Hs, gs, rs = c.evaluate(0, sc.poses_init, lo, lo + 48)
+    Ho, go, ro = orc.evaluate_threads(0, sc.clusters[lo:lo + 48], None, sc.coeffs[lo:lo + 48], sc.poses_init, 8)
+    assert abs(rs - ro) / ro < 1e-12 and rel_err(gs, go) < HTOL and rel_err(Hs, Ho) < HTOL
+    # (4) residual-only == the evaluator's residual
+    assert abs(c.only_residual(sc.poses_init) - r) / r < 1e-13
+    # (5) weights enter linearly
+    c2 = capi.Context(W)
+    c2.set_features(sc.clusters, None, 3.0 * sc.coeffs)
+    H3, g3, r3 = c2.evaluate(0, sc.poses_init)
+    assert rel_err(H3, 3.0 * H) < 1e-13 and abs(r3 - 3.0 * r) / r < 1e-13
+    c2.close()
+    # (6) the LM loop reaches the ground truth of the scene (RSME as benchmark_virtual.cpp:48-61 reports it)
+    out, lg = c.damping_iter(sc.poses_init, form=0, u0=0.1, max_iter=20)
+    assert lg[-1, 1] < 0.05 * lg[0, 0]
+    rot, tr = orc.rsme(orc.reanchor(sc.poses_gt), out)
+    print("W=200 F=50000: %d LM iterations, residual %.4g -> %.4g, RSME %.2e rad %.2e m" % (len(lg), lg[0, 0], lg[-1, 1], rot, tr))
+    assert rot < 1e-4 and tr < 1e-3
+    c.close()
+
+
 # ---- golden fixtures: outputs of the reference's own source (tests/golden/make_golden.py) ------------
 import glob as _glob
 import os as _os
