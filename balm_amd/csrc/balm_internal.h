@@ -117,7 +117,7 @@ void launch_solve(balm_ctx *c, double u, bool new_hessian);      // (H + u diag 
 void launch_update_poses(hipStream_t s, int form, int W, const double *poses, const double *dx, double *out);
 void launch_reanchor(hipStream_t s, int W, double *poses);
 
-// launchers (kernels_build.hip)
+// kernels_voxel.hip
 struct AssocOpts {
   int W;                    // scans, the marginalised ones included
   double voxel_size;
@@ -128,6 +128,7 @@ struct AssocOpts {
 int associate_device(hipStream_t s, const float *d_xyz, const int *d_frame, const double *d_poses, long n, const AssocOpts &o,
                      void *arena, size_t arena_cap, size_t *arena_need, int *F_out, double **d_out, double **d_coe,
                      double **d_fix, int **d_layer, int **d_point_feat, long *n_roots);
+
 // launchers (kernels_cov.hip)
 int cov_factors_grid(int W, int F);
 void launch_cov_factors(hipStream_t s, const double *cl, const double *ccov, double sigma2, const double *poses,
@@ -137,6 +138,8 @@ void launch_cov_reduce_dacc(hipStream_t s, const double *dpart, int nblk, int W,
 void launch_cov_assemble(hipStream_t s, const double *redx, const double *redy, const double *sdiag, const int *tileIJ,
                          int ntiles, int W, double *Rout);
 void launch_congruence_inverse(balm_ctx *c, const double *Rraw, double *Z, double *tmp, double *Rcov);
+
+// launchers (kernels_build.hip)
 void launch_build_clusters(hipStream_t s, const float *xyz, const int *feat_id, const int *pose_id, long n_pts,
                            int F, int W, double *soa);
 void launch_soa_to_aos(hipStream_t s, const double *soa, double *aos, int F, int W);
