@@ -658,7 +658,7 @@ int balm_work_model(balm_ctx *ctx, double *out4) {
   out4[2] = 108.0 * F * W * (W + 1.0);            // 108 FMA = 216 flop per unordered pair incl. diagonal -> x2/2
   SyrkPlan p = plan_syrk(ctx->ntiles, 3L * ctx->F);
   const double noff = ctx->ntiles - ctx->T, ndiag = ctx->T;
-  out4[3] = (noff * 25.0 + ndiag * 15.0) * 2048.0 * ((double)p.Kpad / 4.0);   // every k-step of every tile
+  out4[3] = (noff + ndiag) * 25.0 * 2048.0 * ((double)p.Kpad / 4.0);   // every k-step of every tile (diagonal tiles run full sweeps)
   return BALM_OK;
 }
 
