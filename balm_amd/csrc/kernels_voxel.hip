@@ -130,27 +130,32 @@ __global__ void k_head_flags(const T *__restrict__ key, long n, int shift, unsig
   if (i < n) flag[i] = (i == 0 || (key[i] >> shift) != (key[i - 1] >> shift)) ? 1u : 0u;
 }
 
-// composite key of level L: (root id, octant prefix, frame); oct_mask = 0, 0x38, 0x3f for L = 0, 1, 2
+// composite key of level L: (root id, octant prefix of 3 L bits, frame of fb bits) -- as few radix digits as the
+// window needs; the canonical form (root << 15 | octants << 9 | frame) is restored per segment in k_seg_heads
 template <class K>
 __global__ void k_make_ck(const unsigned int *__restrict__ rootid_incl, const unsigned long long *__restrict__ val, long n,
-                          unsigned long long attr_mask, K *__restrict__ ck, unsigned int *__restrict__ idx) {
+                          int level, int fb, K *__restrict__ ck, unsigned int *__restrict__ idx) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const unsigned long long v = val[i];
-  ck[i] = (K)(((unsigned long long)(rootid_incl[i] - 1) << 15) | (v & attr_mask));
+  const unsigned long long oct = ((v >> 9) & 0x3full) >> (6 - 3 * level);       // o1 for level 1, (o1, o2) for level 2
+  ck[i] = (K)(((((unsigned long long)(rootid_incl[i] - 1) << (3 * level)) | oct) << fb) | (v & 0x1ffull));
   idx[i] = (unsigned int)(v >> 15);
 }
 
-// segment s = run of equal composite keys: its first position and key
+// segment s = run of equal composite keys: its first position and its key in canonical form
 template <class K>
-__global__ void k_seg_heads(const K *__restrict__ cks, const unsigned int *__restrict__ segid_incl,
-                            long n, unsigned int *__restrict__ seg_start, unsigned long long *__restrict__ seg_ck) {
+__global__ void k_seg_heads(const K *__restrict__ cks, const unsigned int *__restrict__ segid_incl, long n, int level, int fb,
+                            unsigned int *__restrict__ seg_start, unsigned long long *__restrict__ seg_ck) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   if (i == 0 || cks[i] != cks[i - 1]) {
     const unsigned int s = segid_incl[i] - 1;
+    const unsigned long long k = cks[i];
+    const unsigned long long frame = k & ((1ull << fb) - 1), rest = k >> fb;
+    const unsigned long long oct = (rest & ((1ull << (3 * level)) - 1)) << (6 - 3 * level), root = rest >> (3 * level);
     seg_start[s] = (unsigned int)i;
-    seg_ck[s] = cks[i];
+    seg_ck[s] = (root << 15) | (oct << 9) | frame;
   }
 }
 
@@ -293,6 +298,26 @@ __global__ __launch_bounds__(256) void k_node_totals(const double *__restrict__ 
   const int c = threadIdx.x & 15;
   if (j >= NN) return;
   const unsigned int s0 = node_seg[j], s1 = node_seg[j + 1];
+  if (fix_frames == 0) {                 // the benchmark drivers' case: nothing is marginalised
+    if (c < 10) {
+      double t = 0.0;
+      unsigned int s = s0;
+      for (; s + 8 <= s1; s += 8) {             // loads of eight scans in flight, the sum stays in scan order
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = seg_world[(size_t)(s + u) * 10 + c];
+#pragma unroll
+        for (int u = 0; u < 8; u++) t = __dadd_rn(t, v[u]);
+      }
+      for (; s < s1; s++) t = __dadd_rn(t, seg_world[(size_t)s * 10 + c]);
+      tot[j].c[c] = t;
+      tot[j].fixc[c] = 0.0;
+      if (c == 9) tot[j].nrest = t;
+    } else if (c == 10) {
+      tot[j].nobs = (int)(s1 - s0);
+    }
+    return;
+  }
   if (c < 10) {
     double t = 0.0, fx = 0.0;
     for (unsigned int s = s0; s < s1; s++) {
@@ -470,28 +495,36 @@ __global__ void k_point_features(long n, int levels, const unsigned int *__restr
 }
 
 // per-(feature, pose) body clusters = the feature node's own segments (sig_orig) of the scans that stay, shifted by
-// the marginalised ones; weight = sum_i N_i over them; fix cluster = the marginalised scans' world cluster.
-// 16 lanes per node, lane c < 10 copies component c
-__global__ __launch_bounds__(256) void k_emit(long NN, const unsigned int *__restrict__ flag,
-                                              const unsigned int *__restrict__ fid_excl, unsigned int fid_base,
-                                              const unsigned int *__restrict__ node_seg, const unsigned long long *__restrict__ seg_ck,
-                                              const double *__restrict__ seg_body, const NodeTot *__restrict__ tot, int Wout,
-                                              int fix_frames, int layer, double *__restrict__ out, double *__restrict__ coe,
-                                              double *__restrict__ fixout, int *__restrict__ layer_out) {
+// the marginalised ones: one lane per (segment, component)
+__global__ __launch_bounds__(256) void k_emit_segments(long NS, const unsigned int *__restrict__ nid_incl,
+                                                       const unsigned int *__restrict__ flag, const unsigned int *__restrict__ fid_excl,
+                                                       unsigned int fid_base, const unsigned long long *__restrict__ seg_ck,
+                                                       const double *__restrict__ seg_body, int Wout, int fix_frames,
+                                                       double *__restrict__ out) {
+  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long s = t >> 4;
+  const int c = (int)(t & 15);
+  if (s >= NS || c >= 10) return;
+  const unsigned int j = nid_incl[s] - 1;
+  if (!flag[j]) return;
+  const int fr = (int)(seg_ck[s] & 511ull) - fix_frames;
+  if (fr < 0) return;
+  const size_t f = fid_base + fid_excl[j];
+  out[(f * Wout + (size_t)fr) * 10 + c] = seg_body[(size_t)s * 10 + c];
+}
+
+// per feature: weight = sum_i N_i over the scans that stay (VOX_HESS::push_voxel, bavoxel.hpp:42-44), fix cluster =
+// the marginalised scans' world cluster, octree layer
+__global__ __launch_bounds__(256) void k_emit_nodes(long NN, const unsigned int *__restrict__ flag,
+                                                    const unsigned int *__restrict__ fid_excl, unsigned int fid_base,
+                                                    const NodeTot *__restrict__ tot, int layer, double *__restrict__ coe,
+                                                    double *__restrict__ fixout, int *__restrict__ layer_out) {
   const long j = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
   const int c = threadIdx.x & 15;
   if (j >= NN || !flag[j]) return;
   const size_t f = fid_base + fid_excl[j];
-  if (c < 10) {
-    for (unsigned int s = node_seg[j]; s < node_seg[j + 1]; s++) {
-      const int fr = (int)(seg_ck[s] & 511ull) - fix_frames;
-      if (fr >= 0) out[(f * Wout + (size_t)fr) * 10 + c] = seg_body[(size_t)s * 10 + c];
-    }
-    fixout[f * 10 + c] = tot[j].fixc[c];
-  } else if (c == 10) {
-    coe[f] = tot[j].nrest;     // VOX_HESS::push_voxel weight = sum_i N_i (bavoxel.hpp:42-44)
-    layer_out[f] = layer;
-  }
+  if (c < 10) fixout[f * 10 + c] = tot[j].fixc[c];
+  else if (c == 10) { coe[f] = tot[j].nrest; layer_out[f] = layer; }
 }
 
 // bump allocator over a caller-owned arena; whatever does not fit falls back to hipMalloc for this call and
@@ -547,7 +580,7 @@ struct Level {
   long NS = 0, NN = 0;
   unsigned long long *seg_ck = nullptr;
   double *seg_body = nullptr;
-  unsigned int *node_seg = nullptr, *node_parent = nullptr, *flag = nullptr, *fid = nullptr;
+  unsigned int *node_seg = nullptr, *node_parent = nullptr, *flag = nullptr, *fid = nullptr, *seg_node = nullptr;
   unsigned char *status = nullptr;
   NodeTot *tot = nullptr;
 };
@@ -623,16 +656,18 @@ int associate_device(hipStream_t s, const float *d_xyz, const int *d_frame, cons
   VoxParams pr{o.voxel_size, {o.thr[0], o.thr[1], o.thr[2]}, o.min_ps, W, o.layer_limit, o.min_observers, o.fix_frames,
                o.max_dis, o.ratio21_max, o.lam0_max};
   Level lv[3];
-  const unsigned long long attr_mask[3] = {0x1ffull, (0x38ull << 9) | 0x1ffull, (0x3full << 9) | 0x1ffull};
+  int fb = 1;                                     // bits of a scan index
+  while ((1 << fb) < W) fb++;
   for (int L = 0; L < levels; L++) {
     Level &v = lv[L];
+    const int key_bits_L = root_bits + 3 * L + fb;
     auto level_keys = [&](auto *ka, auto *kb) {
       using K = std::remove_pointer_t<decltype(ka)>;
-      hipLaunchKernelGGL((k_make_ck<K>), dim3(grid_for(n, B)), dim3(B), 0, s, rootid, vals, n, attr_mask[L], ka, idx1);
-      sort_pairs(sc, s, ka, kb, idx1, idxL, n, 15 + root_bits);
+      hipLaunchKernelGGL((k_make_ck<K>), dim3(grid_for(n, B)), dim3(B), 0, s, rootid, vals, n, L, fb, ka, idx1);
+      sort_pairs(sc, s, ka, kb, idx1, idxL, n, key_bits_L);
       hipLaunchKernelGGL((k_head_flags<K>), dim3(grid_for(n, B)), dim3(B), 0, s, kb, n, 0, flag);
     };
-    const bool narrow = 15 + root_bits <= 32;
+    const bool narrow = key_bits_L <= 32;
     if (narrow) level_keys((unsigned int *)k0, (unsigned int *)cks);
     else level_keys(k0, cks);
     scan_incl(sc, s, flag, incl, n);
@@ -643,12 +678,13 @@ int associate_device(hipStream_t s, const float *d_xyz, const int *d_frame, cons
     v.seg_body = sc.get<double>((size_t)v.NS * 10);
     auto *seg_world = sc.get<double>((size_t)v.NS * 10);
     auto *sf = sc.get<unsigned int>(v.NS), *nid = sc.get<unsigned int>(v.NS), *pid = sc.get<unsigned int>(v.NS);
+    v.seg_node = nid;
     if (!sc.ok) return -1;
     if (narrow)
-      hipLaunchKernelGGL((k_seg_heads<unsigned int>), dim3(grid_for(n, B)), dim3(B), 0, s, (const unsigned int *)cks, incl, n,
-                         seg_start, v.seg_ck);
+      hipLaunchKernelGGL((k_seg_heads<unsigned int>), dim3(grid_for(n, B)), dim3(B), 0, s, (const unsigned int *)cks, incl, n, L,
+                         fb, seg_start, v.seg_ck);
     else
-      hipLaunchKernelGGL((k_seg_heads<unsigned long long>), dim3(grid_for(n, B)), dim3(B), 0, s, cks, incl, n, seg_start, v.seg_ck);
+      hipLaunchKernelGGL((k_seg_heads<unsigned long long>), dim3(grid_for(n, B)), dim3(B), 0, s, cks, incl, n, L, fb, seg_start, v.seg_ck);
     hipLaunchKernelGGL(k_set_u32, dim3(1), dim3(1), 0, s, seg_start + v.NS, (unsigned int)n);
     hipLaunchKernelGGL(k_seg_clusters_short, dim3(grid_for(v.NS, B)), dim3(B), 0, s, d_xyz, d_poses, idxL, seg_start, v.seg_ck,
                        v.NS, v.seg_body, seg_world);
@@ -708,9 +744,12 @@ int associate_device(hipStream_t s, const float *d_xyz, const int *d_frame, cons
     return fail();
   hipMemsetAsync(out, 0, (size_t)F * Wout * 10 * sizeof(double), s);
   unsigned int base[3] = {0, FL[0], FL[0] + FL[1]};
-  for (int L = 0; L < levels; L++)
-    hipLaunchKernelGGL(k_emit, dim3(grid_for(lv[L].NN * 16, B)), dim3(B), 0, s, lv[L].NN, lv[L].flag, lv[L].fid, base[L],
-                       lv[L].node_seg, lv[L].seg_ck, lv[L].seg_body, lv[L].tot, Wout, o.fix_frames, L, out, coe, fixo, lay);
+  for (int L = 0; L < levels; L++) {
+    hipLaunchKernelGGL(k_emit_segments, dim3(grid_for(lv[L].NS * 16, B)), dim3(B), 0, s, lv[L].NS, lv[L].seg_node, lv[L].flag,
+                       lv[L].fid, base[L], lv[L].seg_ck, lv[L].seg_body, Wout, o.fix_frames, out);
+    hipLaunchKernelGGL(k_emit_nodes, dim3(grid_for(lv[L].NN * 16, B)), dim3(B), 0, s, lv[L].NN, lv[L].flag, lv[L].fid, base[L],
+                       lv[L].tot, L, coe, fixo, lay);
+  }
   if (want_points)
     hipLaunchKernelGGL(k_point_features, dim3(grid_for(n, B)), dim3(B), 0, s, n, levels, pnode[0], pnode[1], pnode[2], lv[0].flag,
                        lv[1].flag, lv[2].flag, lv[0].fid, lv[1].fid, lv[2].fid, base[1], base[2], pf);
