@@ -12,7 +12,7 @@
 //   k_cov_factors   one workgroup per feature, one lane per pose: X and Y columns, S partials
 //   k_hessian_syrk  (kernels_accum.hip) on X, then on Y
 //   k_cov_assemble  Rcov_raw = XX^T - YY^T + blockdiag(S)
-//   k_trsm_*        H^-1 B for n right-hand sides through the LDL^T factor of kernels_solve.hip (applied twice)
+//   k_trsm_panel    H^-1 B for n right-hand sides through the LDL^T factor of kernels_solve.hip (applied twice)
 #include <cfloat>
 
 #include "balm_internal.h"
@@ -403,8 +403,8 @@ __global__ __launch_bounds__(256) void k_cov_assemble(const double *__restrict__
 // ------------------------------------------------------------------------------------------------
 // H^-1 B for m right-hand sides through the factor P H P^T = L D L^T left in c->d_A / d_dvec / d_perm by
 // launch_solve: Z = P B, L Z' = Z (forward, panel by panel), Z'' = D^+ Z', L^T Z''' = Z'' (backward), out = P^T Z'''.
-// B is nA x m column-major with leading dimension nA.  Straightforward FP64 FMA kernels (this stage is
-// O(n^3) with n = 6W <= 2880, microseconds next to the SYRKs).
+// B is nA x m column-major with leading dimension nA.  Straightforward FP64 FMA kernels, one launch per panel and
+// direction (this stage is O(n^3) with n = 6W <= 2880, small next to the SYRKs).
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_rows_permute(const double *__restrict__ B, int n, int nA, int m,
                                                       const int *__restrict__ perm, int inverse, double *__restrict__ out) {
@@ -436,57 +436,98 @@ __global__ __launch_bounds__(256) void k_transpose_sq(const double *__restrict__
   if (by + tx < n && bx + ty < n) At[(size_t)(bx + ty) * n + by + tx] = tile[tx][ty];
 }
 
-// the NB x NB unit-triangular diagonal block against the panel's rows of every right-hand side: one lane per column
-template <int BACKWARD>
-__global__ __launch_bounds__(64) void k_trsm_diag(const double *__restrict__ A, int ldA, int c0, double *__restrict__ Z,
-                                                  int nA, int m) {
+// inverses of the NB x NB unit-lower-triangular diagonal blocks of L, once per factorisation: column j of the
+// inverse by forward substitution, one lane per column.  Linv[p][c][r] = (L_pp^-1)(r, c), column-major.
+__global__ __launch_bounds__(64) void k_invert_diag_blocks(const double *__restrict__ A, int ldA, double *__restrict__ Linv) {
   __shared__ double Ls[NB][NB + 1];
+  const int c0 = blockIdx.x * NB;
   for (int t = threadIdx.x; t < NB * NB; t += 64) {
     const int r = t % NB, c = t / NB;
     Ls[r][c] = r > c ? A[(size_t)(c0 + c) * ldA + c0 + r] : 0.0;
   }
   __syncthreads();
-  const int col = blockIdx.x * 64 + threadIdx.x;
-  if (col >= m) return;
-  double *z = Z + (size_t)col * nA + c0;
+  const int j = threadIdx.x;
+  if (j >= NB) return;
   double x[NB];
 #pragma unroll
-  for (int k = 0; k < NB; k++) x[k] = z[k];
-  if (!BACKWARD) {
+  for (int k = 0; k < NB; k++) x[k] = k == j ? 1.0 : 0.0;
 #pragma unroll
-    for (int k = 0; k < NB; k++)
+  for (int k = 0; k < NB; k++)
 #pragma unroll
-      for (int i = k + 1; i < NB; i++) x[i] = __builtin_fma(-Ls[i][k], x[k], x[i]);
-  } else {
+    for (int i = k + 1; i < NB; i++) x[i] = __builtin_fma(-Ls[i][k], x[k], x[i]);
+  double *dst = Linv + ((size_t)blockIdx.x * NB + j) * NB;
 #pragma unroll
-    for (int k = NB - 1; k >= 0; k--)
-#pragma unroll
-      for (int i = 0; i < k; i++) x[i] = __builtin_fma(-Ls[k][i], x[k], x[i]);
-  }
-#pragma unroll
-  for (int k = 0; k < NB; k++) z[k] = x[k];
+  for (int k = 0; k < NB; k++) dst[k] = x[k];
 }
 
-// rank-NB update of the remaining rows: forward  Z[r][:] -= L[r][c0..c0+NB) Z[c0..][:]  for r >= c0 + NB,
-//                                       backward Z[r][:] -= L[c0..c0+NB)[r]^T Z[c0..][:] for r <  c0.
-// 64 x 64 output tile per workgroup, 4 x 4 per lane.
+// One launch per panel: every workgroup (64 right-hand sides x one 64-row tile of the rows still to update) first
+// solves the NB x NB unit-triangular diagonal block against its 64 columns of the panel rows -- redundantly per
+// row tile, as a product with the block's precomputed inverse (no serial substitution chain on the critical
+// path) -- then applies the rank-NB update to its tile:
+//   forward   Z[r][:] -= L[r][c0..c0+NB) X      for r >= c0 + NB        (L Z' = Z)
+//   backward  Z[r][:] -= L[c0..c0+NB)[r]^T X    for r <  c0             (L^T Z' = Z)
+// The solved panel rows X go to a second buffer S (written by the workgroups of row tile 0), so nobody reads rows
+// another workgroup is overwriting.  4 x 4 outputs per lane.
 template <int BACKWARD>
-__global__ __launch_bounds__(256) void k_trsm_update(const double *__restrict__ A, int ldA, int c0, double *__restrict__ Z,
-                                                     int nA, int m, int r_begin, int r_end) {
-  __shared__ double Lt[NB][64 + 1];      // [k][row]
-  __shared__ double Xt[NB][64 + 1];      // [k][rhs]
-  const int r0 = r_begin + blockIdx.y * 64, cb = blockIdx.x * 64;
-  for (int t = threadIdx.x; t < NB * 64; t += 256) {
-    int k, rl;
-    if (!BACKWARD) { rl = t & 63; k = t >> 6; } else { k = t % NB; rl = t / NB; }
-    const int r = r0 + rl;
-    double v = 0.0;
-    if (r < r_end) v = BACKWARD ? A[(size_t)r * ldA + c0 + k] : A[(size_t)(c0 + k) * ldA + r];
-    Lt[k][rl] = v;
+__global__ __launch_bounds__(256) void k_trsm_panel(const double *__restrict__ A, const double *__restrict__ Linv, int ldA, int c0,
+                                                    double *__restrict__ Z, double *__restrict__ S, int nA, int m, int r_begin,
+                                                    int r_end) {
+  __shared__ double LL[NB][64 + 1];      // first the diagonal block (strictly lower part), then [k][row] multipliers of the tile
+  __shared__ double Xt[NB][64 + 1];      // [k][rhs]  panel rows of these right-hand sides
+  const int cb = blockIdx.x * 64, r0 = r_begin + blockIdx.y * 64;
+  {
+    const double *li = Linv + (size_t)(c0 / NB) * NB * NB;
+    for (int t = threadIdx.x; t < NB * NB; t += 256) {
+      const int r = t % NB, c = t / NB;           // (L_pp^-1)(r, c); the backward pass needs its transpose
+      if (!BACKWARD) LL[r][c] = li[t]; else LL[c][r] = li[t];
+    }
   }
   for (int t = threadIdx.x; t < NB * 64; t += 256) {
     const int k = t % NB, cl = t / NB;
     Xt[k][cl] = cb + cl < m ? Z[(size_t)(cb + cl) * nA + c0 + k] : 0.0;
+  }
+  const bool has_rows = r0 < r_end;
+  double lpre[NB * 64 / 256];              // this lane's multipliers, in flight during the solve
+  if (has_rows) {
+#pragma unroll
+    for (int q = 0; q < NB * 64 / 256; q++) {
+      const int t = threadIdx.x + 256 * q;
+      int k, rl;
+      if (!BACKWARD) { rl = t & 63; k = t >> 6; } else { k = t % NB; rl = t / NB; }
+      const int r = r0 + rl;
+      lpre[q] = 0.0;
+      if (r < r_end) lpre[q] = BACKWARD ? A[(size_t)r * ldA + c0 + k] : A[(size_t)(c0 + k) * ldA + r];
+    }
+  }
+  __syncthreads();
+  {
+    // X = M Xt with M = L_pp^-1 (lower) or its transpose (upper): 48 x 64 outputs, 12 per lane
+    const int cl = threadIdx.x & 63, kq = threadIdx.x >> 6;          // rows kq, kq + 4, ...
+    double xo[NB / 4];
+#pragma unroll
+    for (int q = 0; q < NB / 4; q++) {
+      const int r = kq + 4 * q;
+      double acc = 0.0;
+      if (!BACKWARD) { for (int k = 0; k <= r; k++) acc = __builtin_fma(LL[r][k], Xt[k][cl], acc); }
+      else { for (int k = r; k < NB; k++) acc = __builtin_fma(LL[r][k], Xt[k][cl], acc); }
+      xo[q] = acc;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < NB / 4; q++) {
+      const int r = kq + 4 * q;
+      Xt[r][cl] = xo[q];
+      if (blockIdx.y == 0 && cb + cl < m) S[(size_t)(cb + cl) * nA + c0 + r] = xo[q];
+    }
+  }
+  if (!has_rows) return;
+  __syncthreads();                         // the diagonal block is no longer needed
+#pragma unroll
+  for (int q = 0; q < NB * 64 / 256; q++) {
+    const int t = threadIdx.x + 256 * q;
+    int k, rl;
+    if (!BACKWARD) { rl = t & 63; k = t >> 6; } else { k = t % NB; rl = t / NB; }
+    LL[k][rl] = lpre[q];
   }
   __syncthreads();
   const int tr = (threadIdx.x & 15) * 4, tc = (threadIdx.x >> 4) * 4;
@@ -495,7 +536,7 @@ __global__ __launch_bounds__(256) void k_trsm_update(const double *__restrict__ 
   for (int k = 0; k < NB; k++) {
     double l[4], x[4];
 #pragma unroll
-    for (int u = 0; u < 4; u++) { l[u] = Lt[k][tr + u]; x[u] = Xt[k][tc + u]; }
+    for (int u = 0; u < 4; u++) { l[u] = LL[k][tr + u]; x[u] = Xt[k][tc + u]; }
 #pragma unroll
     for (int u = 0; u < 4; u++)
 #pragma unroll
@@ -515,25 +556,22 @@ inline int grid1(long total, int bs, int cap) {
   return (int)(g > cap ? cap : (g < 1 ? 1 : g));
 }
 
-// out (n x m, ld n) = H^-1 B (n x m, ld n), Z = nA x m scratch
-void solve_multi(balm_ctx *c, const double *B, int m, double *Z, double *out) {
+// out (n x m, ld n) = H^-1 B (n x m, ld n); Z, S = nA x m scratch each
+void solve_multi(balm_ctx *c, const double *Linv, const double *B, int m, double *Z, double *S, double *out) {
   hipStream_t s = c->stream;
   const int n = c->n, nA = c->nA, ldA = nA + NB, P = nA / NB;
+  const unsigned gx = (unsigned)((m + 63) / 64);
   hipLaunchKernelGGL(k_rows_permute, dim3(grid1((long)nA * m, 256, 4096)), dim3(256), 0, s, B, n, nA, m, c->d_perm, 0, Z);
-  for (int p = 0; p < P; p++) {
-    const int c0 = p * NB;
-    hipLaunchKernelGGL(k_trsm_diag<0>, dim3((m + 63) / 64), dim3(64), 0, s, c->d_A, ldA, c0, Z, nA, m);
-    const int rows = nA - c0 - NB;
-    if (rows > 0)
-      hipLaunchKernelGGL(k_trsm_update<0>, dim3((m + 63) / 64, (rows + 63) / 64), dim3(256), 0, s, c->d_A, ldA, c0, Z, nA, m,
-                         c0 + NB, nA);
+  for (int p = 0; p < P; p++) {                 // forward: work in Z, solved rows into S
+    const int c0 = p * NB, rows = nA - c0 - NB;
+    hipLaunchKernelGGL(k_trsm_panel<0>, dim3(gx, rows > 0 ? (rows + 63) / 64 : 1), dim3(256), 0, s, c->d_A, Linv, ldA, c0, Z, S, nA, m,
+                       c0 + NB, nA);
   }
-  hipLaunchKernelGGL(k_rows_scale, dim3(grid1((long)nA * m, 256, 4096)), dim3(256), 0, s, Z, nA, m, c->d_dvec);
-  for (int p = P - 1; p >= 0; p--) {
+  hipLaunchKernelGGL(k_rows_scale, dim3(grid1((long)nA * m, 256, 4096)), dim3(256), 0, s, S, nA, m, c->d_dvec);
+  for (int p = P - 1; p >= 0; p--) {            // backward: work in S, solved rows into Z
     const int c0 = p * NB;
-    hipLaunchKernelGGL(k_trsm_diag<1>, dim3((m + 63) / 64), dim3(64), 0, s, c->d_A, ldA, c0, Z, nA, m);
-    if (c0 > 0)
-      hipLaunchKernelGGL(k_trsm_update<1>, dim3((m + 63) / 64, (c0 + 63) / 64), dim3(256), 0, s, c->d_A, ldA, c0, Z, nA, m, 0, c0);
+    hipLaunchKernelGGL(k_trsm_panel<1>, dim3(gx, c0 > 0 ? (c0 + 63) / 64 : 1), dim3(256), 0, s, c->d_A, Linv, ldA, c0, S, Z, nA, m, 0,
+                       c0);
   }
   hipLaunchKernelGGL(k_rows_permute, dim3(grid1((long)nA * m, 256, 4096)), dim3(256), 0, s, Z, n, nA, m, c->d_perm, 1, out);
 }
@@ -578,12 +616,14 @@ void launch_cov_assemble(hipStream_t s, const double *redx, const double *redy, 
                      tileIJ, ntiles, W, Rout);
 }
 
-// Rcov (n x n) = H^-1 Rraw H^-T, H factored in the context by launch_solve; Z (nA x n) and tmp (n x n) scratch
-void launch_congruence_inverse(balm_ctx *c, const double *Rraw, double *Z, double *tmp, double *Rcov) {
-  const int n = c->n;
-  solve_multi(c, Rraw, n, Z, tmp);                       // M1 = H^-1 Rraw
+// Rcov (n x n) = H^-1 Rraw H^-T, H factored in the context by launch_solve; Z, S (nA x n each), tmp (n x n) and
+// Linv (nA x NB) scratch
+void launch_congruence_inverse(balm_ctx *c, const double *Rraw, double *Z, double *S, double *tmp, double *Linv, double *Rcov) {
+  const int n = c->n, nA = c->nA;
+  hipLaunchKernelGGL(k_invert_diag_blocks, dim3(nA / NB), dim3(64), 0, c->stream, c->d_A, nA + NB, Linv);
+  solve_multi(c, Linv, Rraw, n, Z, S, tmp);              // M1 = H^-1 Rraw
   hipLaunchKernelGGL(k_transpose_sq, dim3((n + 15) / 16, (n + 15) / 16), dim3(256), 0, c->stream, tmp, n, Rcov);
-  solve_multi(c, Rcov, n, Z, tmp);                       // H^-1 M1^T = H^-1 Rraw H^-T  (symmetric)
+  solve_multi(c, Linv, Rcov, n, Z, S, tmp);              // H^-1 M1^T = H^-1 Rraw H^-T  (symmetric)
   hipMemcpyAsync(Rcov, tmp, (size_t)n * n * sizeof(double), hipMemcpyDeviceToDevice, c->stream);
 }
 
