@@ -164,7 +164,7 @@ const char *balm_version(void) { return "balm_hip 0.1.0 (gfx950)"; }
 const char *balm_last_error(balm_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 
 balm_ctx *balm_create(int win_size, int device, int flags) {
-  if (win_size < 1 || win_size > MAX_W_LDS) return nullptr;
+  if (win_size < 1 || win_size > MAX_W) return nullptr;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1 || device < 0 || device >= ndev) return nullptr;
   if (hipSetDevice(device) != hipSuccess) return nullptr;
@@ -445,6 +445,7 @@ int balm_pose_covariance(balm_ctx *ctx, const double *poses, const double *clust
   if (!ctx) return BALM_ERR_ARG;
   if (ctx->F < 1) { ctx->err = "balm_pose_covariance: no features installed"; return BALM_ERR_STATE; }
   if (!poses || (!cluster_cov && !(point_sigma > 0))) { ctx->err = "balm_pose_covariance: bad argument"; return BALM_ERR_ARG; }
+  if (ctx->W > MAX_W_LDS) { ctx->err = "balm_pose_covariance: windows above 480 poses are not supported"; return BALM_ERR_ARG; }
   HIP_TRY(hipSetDevice(ctx->device));
   const int W = ctx->W, n = ctx->n, nA = ctx->nA, F = ctx->F;
   hipStream_t s = ctx->stream;

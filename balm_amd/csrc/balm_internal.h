@@ -19,7 +19,8 @@ constexpr int DACC_LEFT = 27;       // per-pose accumulators: 6 gradient + 21 (s
 constexpr int DACC_RIGHT = 30;      // 6 gradient + 9 (TL) + 9 (TR) + 6 (BR symmetric)
 constexpr int DACC_MAX = 30;
 constexpr int NB = 48;              // LDL^T panel width
-constexpr int MAX_W_LDS = 480;      // feature_factors keeps (12 + DACC) * W doubles in LDS
+constexpr int MAX_W_LDS = 480;      // feature_factors keeps (12 + DACC) * W doubles in LDS up to here, pose chunks beyond
+constexpr int MAX_W = 1024;         // window limit of a context (n = 6144 unknowns)
 
 // feat record layout
 enum { FT_NN = 0, FT_VBAR = 1, FT_LAM = 4, FT_U0 = 7, FT_U1 = 10, FT_U2 = 13, FT_C0 = 16, FT_C1 = 17,

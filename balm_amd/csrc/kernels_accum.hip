@@ -137,6 +137,11 @@ void launch_world_moments(hipStream_t s, const double *cl, const double *poses, 
   int grid = (nf + 3) / 4;
   if (grid > 2048) grid = 2048;
   size_t lds = (size_t)12 * W * sizeof(double);
+  static bool attr_set = false;
+  if (!attr_set) {   // windows above ~680 poses need more than the default 64 KiB of dynamic LDS
+    hipFuncSetAttribute((const void *)k_world_moments, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
   hipLaunchKernelGGL(k_world_moments, dim3(grid), dim3(256), lds, s, cl, poses, W, f0, f1, C);
 }
 
@@ -282,18 +287,20 @@ __device__ __forceinline__ void store6(double *dst, const double x[6]) {
 template <int FORM>
 __global__ __launch_bounds__(256) void k_feature_factors(const double *__restrict__ cl,
                                                          const double *__restrict__ poses,
-                                                         const double *__restrict__ feat, int W, int npad, int f0,
+                                                         const double *__restrict__ feat, int W, int Wc, int npad, int f0,
                                                          int f1, double *__restrict__ Gt,
                                                          double *__restrict__ dpart) {
   constexpr int DACC = FORM == 0 ? DACC_LEFT : DACC_RIGHT;
   extern __shared__ __attribute__((aligned(16))) double sm[];
-  double *sp = sm;                 // [12][W] poses
-  double *sacc = sm + 12 * W;      // [DACC][W]
-  for (int t = threadIdx.x; t < 12 * W; t += blockDim.x) {
-    int i = t / 12, c = t - 12 * i;
-    sp[c * W + i] = poses[t];
+  // blockIdx.y = chunk of Wc poses (one chunk = the whole window up to MAX_W_LDS poses)
+  const int p0 = blockIdx.y * Wc, wc = min(Wc, W - p0);
+  double *sp = sm;                 // [12][Wc] poses of the chunk
+  double *sacc = sm + 12 * Wc;     // [DACC][Wc]
+  for (int t = threadIdx.x; t < 12 * wc; t += blockDim.x) {
+    int il = t / 12, c = t - 12 * il;
+    sp[c * Wc + il] = poses[12 * p0 + t];
   }
-  for (int t = threadIdx.x; t < DACC * W; t += blockDim.x) sacc[t] = 0.0;
+  for (int t = threadIdx.x; t < DACC * Wc; t += blockDim.x) sacc[t] = 0.0;
   __syncthreads();
 
   // cluster of (feature a, pose i): ten coalesced streams, loaded one feature ahead of its use
@@ -303,7 +310,7 @@ __global__ __launch_bounds__(256) void k_feature_factors(const double *__restric
 #pragma unroll
     for (int c = 0; c < 10; c++) nxt[c] = ca[(size_t)c * W];
   };
-  const int i_first = threadIdx.x < (unsigned)W ? threadIdx.x : 0;
+  const int i_first = p0 + (threadIdx.x < (unsigned)wc ? (int)threadIdx.x : 0);
   if (f0 + (int)blockIdx.x < f1) fetch(f0 + blockIdx.x, i_first);
 
   for (int a = f0 + blockIdx.x; a < f1; a += gridDim.x) {
@@ -318,10 +325,11 @@ __global__ __launch_bounds__(256) void k_feature_factors(const double *__restric
     const double *ca = cl + (size_t)a * 10 * W;
     double *g0 = Gt + (size_t)(3 * (a - f0)) * npad;
 
-    for (int i = threadIdx.x; i < W; i += blockDim.x) {
+    for (int il = threadIdx.x; il < wc; il += blockDim.x) {
+      const int i = p0 + il;
       double col0[6], col1[6], col2[6];
       double P[6], v[3];
-      if (i == (int)threadIdx.x) {          // first pose slot of this lane: prefetched
+      if (il == (int)threadIdx.x) {         // first pose slot of this lane: prefetched
 #pragma unroll
         for (int c = 0; c < 6; c++) P[c] = nxt[c];
 #pragma unroll
@@ -332,14 +340,14 @@ __global__ __launch_bounds__(256) void k_feature_factors(const double *__restric
 #pragma unroll
         for (int c = 0; c < 3; c++) v[c] = ca[(size_t)(6 + c) * W + i];
       }
-      const double N = i == (int)threadIdx.x ? nxt[9] : ca[(size_t)9 * W + i];
-      if (i == (int)threadIdx.x && a + (int)gridDim.x < f1) fetch(a + gridDim.x, i_first);
+      const double N = il == (int)threadIdx.x ? nxt[9] : ca[(size_t)9 * W + i];
+      if (il == (int)threadIdx.x && a + (int)gridDim.x < f1) fetch(a + gridDim.x, i_first);
       if ((int)N > 0) {
         double R[9], p[3];
 #pragma unroll
-        for (int c = 0; c < 9; c++) R[c] = sp[c * W + i];
+        for (int c = 0; c < 9; c++) R[c] = sp[c * Wc + il];
 #pragma unroll
-        for (int c = 0; c < 3; c++) p[c] = sp[(9 + c) * W + i];
+        for (int c = 0; c < 3; c++) p[c] = sp[(9 + c) * Wc + il];
 
         if (FORM == 0) {
           // ---- LEFT form, bavoxel.hpp:365-402 -------------------------------------------------
@@ -411,9 +419,9 @@ __global__ __launch_bounds__(256) void k_feature_factors(const double *__restric
 #pragma unroll
             for (int c = r; c < 3; c++) bd[q++] = k2 * N * u0[r] * u0[c];   // BR, symmetric
 #pragma unroll
-          for (int k = 0; k < 6; k++) sacc[k * W + i] += grad[k];
+          for (int k = 0; k < 6; k++) sacc[k * Wc + il] += grad[k];
 #pragma unroll
-          for (int k = 0; k < 21; k++) sacc[(6 + k) * W + i] += bd[k];
+          for (int k = 0; k < 21; k++) sacc[(6 + k) * Wc + il] += bd[k];
         } else {
           // ---- RIGHT form, bavoxel.hpp:93-130 ("Right update.pdf") ----------------------------
           const double Pf[3][3] = {{P[0], P[1], P[2]}, {P[1], P[3], P[4]}, {P[2], P[4], P[5]}};
@@ -505,9 +513,9 @@ __global__ __launch_bounds__(256) void k_feature_factors(const double *__restric
 #pragma unroll
             for (int c = r; c < 3; c++) bd[q++] = k2 * N * u0[r] * u0[c];
 #pragma unroll
-          for (int k = 0; k < 6; k++) sacc[k * W + i] += coe * jjt[k];
+          for (int k = 0; k < 6; k++) sacc[k * Wc + il] += coe * jjt[k];
 #pragma unroll
-          for (int k = 0; k < 24; k++) sacc[(6 + k) * W + i] += bd[k];
+          for (int k = 0; k < 24; k++) sacc[(6 + k) * Wc + il] += bd[k];
         }
       } else {
 #pragma unroll
@@ -519,13 +527,19 @@ __global__ __launch_bounds__(256) void k_feature_factors(const double *__restric
     }
   }
   __syncthreads();
-  double *dp = dpart + (size_t)blockIdx.x * DACC * W;
-  for (int t = threadIdx.x; t < DACC * W; t += blockDim.x) dp[t] = sacc[t];
+  double *dp = dpart + (size_t)blockIdx.x * DACC * W + p0;
+  for (int t = threadIdx.x; t < DACC * wc; t += blockDim.x) {
+    const int k = t / wc, il = t - k * wc;
+    dp[(size_t)k * W + il] = sacc[k * Wc + il];
+  }
 }
+
+// poses per workgroup of the factor kernel: the whole window while its accumulators fit in LDS, else chunks
+int factors_chunk(int W) { return W <= MAX_W_LDS ? W : 256; }
 
 int factors_grid(int W, int nfeat, int form) {
   int dacc = form == 0 ? DACC_LEFT : DACC_RIGHT;
-  size_t lds = (size_t)(12 + dacc) * W * sizeof(double);
+  size_t lds = (size_t)(12 + dacc) * factors_chunk(W) * sizeof(double);
   int per_cu = (int)(160 * 1024 / lds);
   if (per_cu < 1) per_cu = 1;
   if (per_cu > 4) per_cu = 4;
@@ -538,7 +552,8 @@ int factors_grid(int W, int nfeat, int form) {
 void launch_factors(hipStream_t s, int form, const double *cl, const double *poses, const double *feat, int W,
                     int npad, int f0, int f1, double *Gt, double *dpart, int nblk) {
   int dacc = form == 0 ? DACC_LEFT : DACC_RIGHT;
-  size_t lds = (size_t)(12 + dacc) * W * sizeof(double);
+  const int Wc = factors_chunk(W), chunks = (W + Wc - 1) / Wc;
+  size_t lds = (size_t)(12 + dacc) * Wc * sizeof(double);
   int bs = W <= 64 ? 64 : (W <= 128 ? 128 : 256);
   static bool attr_set = false;
   if (!attr_set) {   // windows above ~200 poses need more than the default 64 KiB of dynamic LDS
@@ -547,9 +562,9 @@ void launch_factors(hipStream_t s, int form, const double *cl, const double *pos
     attr_set = true;
   }
   if (form == 0)
-    hipLaunchKernelGGL(k_feature_factors<0>, dim3(nblk), dim3(bs), lds, s, cl, poses, feat, W, npad, f0, f1, Gt, dpart);
+    hipLaunchKernelGGL(k_feature_factors<0>, dim3(nblk, chunks), dim3(bs), lds, s, cl, poses, feat, W, Wc, npad, f0, f1, Gt, dpart);
   else
-    hipLaunchKernelGGL(k_feature_factors<1>, dim3(nblk), dim3(bs), lds, s, cl, poses, feat, W, npad, f0, f1, Gt, dpart);
+    hipLaunchKernelGGL(k_feature_factors<1>, dim3(nblk, chunks), dim3(bs), lds, s, cl, poses, feat, W, Wc, npad, f0, f1, Gt, dpart);
 }
 
 // ------------------------------------------------------------------------------------------------

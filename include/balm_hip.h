@@ -67,7 +67,8 @@ typedef struct balm_lm_opts {
 } balm_lm_opts;
 
 /* Replaces the global `int win_size` (bavoxel.hpp:17) + object construction.  `device` is the
- * HIP device ordinal this context owns (one process per GPU sets it to LOCAL_RANK). */
+ * HIP device ordinal this context owns (one process per GPU sets it to LOCAL_RANK).  1 <= win_size <= 1024
+ * (balm_pose_covariance: <= 480); NULL on failure. */
 balm_ctx *balm_create(int win_size, int device, int flags);
 void balm_destroy(balm_ctx *ctx);
 

@@ -53,9 +53,11 @@ def test_evaluate_matches_oracle(case, form):
     c.close()
 
 
-@pytest.mark.parametrize("W,F,form", [(177, 60, 0), (230, 40, 0), (230, 40, 1), (320, 30, 0), (480, 24, 0), (480, 24, 1)])
+@pytest.mark.parametrize("W,F,form", [(177, 60, 0), (230, 40, 0), (230, 40, 1), (320, 30, 0), (480, 24, 0), (480, 24, 1),
+                                      (500, 16, 0), (700, 10, 1), (1024, 6, 0)])
 def test_wide_windows(W, F, form):
-    """windows beyond one LDS default (W > 210), the shipped data's W=177 and the W=480 ceiling;
+    """windows beyond one LDS default (W > 210), the shipped data's W=177, W=480 (the last window whose per-pose
+    accumulators fit one workgroup's LDS) and pose-chunked windows up to the context limit of 1024 poses;
     evaluate + one damped solve against the oracle"""
     sc, _ = make_scene(90 + W, W, F, 4, drop=0.3, mode=1)
     c = ctx_for(sc)
