@@ -613,7 +613,10 @@ int balm_damping_iter(balm_ctx *ctx, const balm_lm_opts *o, double *poses, balm_
     if (log) { log[it].r1 = r1; log[it].r2 = r2; log[it].u = u; log[it].v = v; log[it].q = q; log[it].q1 = q1;
                log[it].accepted = q > 0; log[it].hess_evaluated = evaluated; }
     if (o->verbose)   // the reference's progress line, bavoxel.hpp:1132
+    {
       printf("iter%d: (%lf %lf) u: %lf v: %.1lf q: %.3lf %lf %lf\n", it, r1, r2, u, v, q / q1, q1, q);
+      fflush(stdout);       // progress lines interleave correctly with a host language's own output
+    }
     if (q > 0) {      // bavoxel.hpp:1134-1143
       double *t = ctx->d_poses; ctx->d_poses = ctx->d_poses_tmp; ctx->d_poses_tmp = t;
       // the trial poses become current: so do their eigen records and residual partials

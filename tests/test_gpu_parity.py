@@ -484,3 +484,14 @@ def test_edge_cases_single_feature_two_observers_and_blind_pose():
         if F == 6:                                                   # F = 1 leaves the system rank deficient everywhere
             assert rel_err(dx[live], dxo[live]) < 1e-6
         c.close()
+
+
+def test_virtual_driver_prints_the_reference_lines(capfd):
+    """python -m balm_amd.virtual: the benchmark_virtual flow (generate, perturb, cluster build on the device, LM with
+    that driver's constants) with the launch file's default sizes; RSME as the reference reports it"""
+    from balm_amd import virtual
+    assert virtual.main(["--seed", "5"]) == 0
+    out = capfd.readouterr().out
+    assert "winSize: 20" in out and "RSME:" in out and "iter0:" in out
+    deg, m = [float(x.rstrip("degm,")) for x in out.split("RSME:")[1].split()[:2]]
+    assert deg < 0.5 and m < 0.02           # 5 cm point noise: the reference lands in the same range
