@@ -344,8 +344,6 @@ int balm_associate(balm_ctx *ctx, const balm_voxel_opts *opts, const float *xyz,
   }
   const int W = ctx->W, WT = W + opts->fix_frames;
   if (WT > 512) { ctx->err = "balm_associate: more than 512 scans not supported"; return BALM_ERR_ARG; }
-  for (long k = 0; k < n_pts; k++)
-    if (frame_id[k] < 0 || frame_id[k] >= WT) { ctx->err = "balm_associate: frame_id out of range"; return BALM_ERR_ARG; }
   HIP_TRY(hipSetDevice(ctx->device));
   *F_out = 0;
   ctx->F = 0;
@@ -383,6 +381,7 @@ int balm_associate(balm_ctx *ctx, const balm_voxel_opts *opts, const float *xyz,
   if (d_f) hipFree(d_f);
   if (d_pos) hipFree(d_pos);
   HIP_TRY(e);
+  if (arc == -3) { ctx->err = "balm_associate: frame_id out of range or non-finite point"; return BALM_ERR_ARG; }
   if (arc) { ctx->err = arc == -2 ? "balm_associate: unsupported size" : "balm_associate: device failure"; return BALM_ERR_HIP; }
   if (n_root_voxels) *n_root_voxels = nroots;
   if (F == 0) return BALM_OK;

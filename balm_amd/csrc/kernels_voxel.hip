@@ -59,16 +59,22 @@ __device__ __forceinline__ long long voxel_key(double q, double vs) {
 
 // pass A: range of the voxel keys per axis (to pack them into as few radix digits as possible); keys are
 // saturated to +-2^30 here -- anything beyond 2^21 voxels per axis is rejected by the host anyway.
-// One row of {min[3], max[3]} per block; the host folds the rows.
+// One row of {min[3], max[3], bad} per block; the host folds the rows.  bad != 0: a scan index outside [0, W) or a
+// non-finite coordinate (input validation rides along instead of a host pass over the points).
 constexpr int RANGE_BLOCKS = 1024;
+constexpr int RANGE_ROW = 7;
 __global__ __launch_bounds__(256) void k_vox_range(const float *__restrict__ xyz, const int *__restrict__ frame,
-                                                   const double *__restrict__ poses, long n, double vs,
-                                                   int *__restrict__ range /* [gridDim.x][6] */) {
-  __shared__ int red[4][6];
+                                                   const double *__restrict__ poses, long n, int W, double vs,
+                                                   int *__restrict__ range /* [gridDim.x][RANGE_ROW] */) {
+  __shared__ int red[4][RANGE_ROW];
   int lo[3] = {1 << 30, 1 << 30, 1 << 30}, hi[3] = {-(1 << 30), -(1 << 30), -(1 << 30)};
+  int bad = 0;
   for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (long)gridDim.x * blockDim.x) {
     double q[3], po[3];
-    world_point(xyz, poses + 12 * (long)frame[p], p, q, po);
+    const int fr = frame[p];
+    if (fr < 0 || fr >= W) { bad = 1; continue; }
+    world_point(xyz, poses + 12 * (long)fr, p, q, po);
+    if (!(isfinite(q[0]) && isfinite(q[1]) && isfinite(q[2]))) { bad = 1; continue; }
 #pragma unroll
     for (int j = 0; j < 3; j++) {
       const long long k = voxel_key(q[j], vs);
@@ -82,14 +88,17 @@ __global__ __launch_bounds__(256) void k_vox_range(const float *__restrict__ xyz
       lo[j] = min(lo[j], __shfl_xor(lo[j], d, 64));
       hi[j] = max(hi[j], __shfl_xor(hi[j], d, 64));
     }
-  if ((threadIdx.x & 63) == 0)
+  for (int d = 32; d >= 1; d >>= 1) bad |= __shfl_xor(bad, d, 64);
+  if ((threadIdx.x & 63) == 0) {
 #pragma unroll
     for (int j = 0; j < 3; j++) { red[threadIdx.x >> 6][j] = lo[j]; red[threadIdx.x >> 6][3 + j] = hi[j]; }
+    red[threadIdx.x >> 6][6] = bad;
+  }
   __syncthreads();
-  if (threadIdx.x < 6) {
+  if (threadIdx.x < RANGE_ROW) {
     int v = red[0][threadIdx.x];
     for (int w = 1; w < 4; w++) v = threadIdx.x < 3 ? min(v, red[w][threadIdx.x]) : max(v, red[w][threadIdx.x]);
-    range[blockIdx.x * 6 + threadIdx.x] = v;
+    range[blockIdx.x * RANGE_ROW + threadIdx.x] = v;
   }
 }
 
@@ -592,7 +601,7 @@ struct Level {
 // *arena_need receives the bytes this call wanted.  On success *F_out features; *d_out = hipMalloc'ed
 // [F][W - fix_frames][10] (caller frees), *d_coe = [F], *d_fix = [F][10], *d_layer = [F], and, when want_points,
 // *d_point_feat = [n] feature of every point (-1: none).  Returns 0, or a negative code (-1 allocation / HIP
-// failure, -2 unsupported size).
+// failure, -2 unsupported size, -3 a scan index outside [0, W) or a non-finite point).
 int associate_device(hipStream_t s, const float *d_xyz, const int *d_frame, const double *d_poses, long n, const AssocOpts &o,
                      void *arena, size_t arena_cap, size_t *arena_need, int *F_out, double **d_out, double **d_coe,
                      double **d_fix, int **d_layer, int **d_point_feat, long *n_roots) {
@@ -612,23 +621,25 @@ int associate_device(hipStream_t s, const float *d_xyz, const int *d_frame, cons
   auto *idx1 = sc.get<unsigned int>(n), *idxL = sc.get<unsigned int>(n);
   auto *flag = sc.get<unsigned int>(n), *rootid = sc.get<unsigned int>(n), *incl = sc.get<unsigned int>(n);
   auto *cks = sc.get<unsigned long long>(n);
-  auto *range = sc.get<int>(6 * RANGE_BLOCKS);
+  auto *range = sc.get<int>(RANGE_ROW * RANGE_BLOCKS);
   unsigned int *pnode[3] = {nullptr, nullptr, nullptr};
   if (want_points) for (int L = 0; L < levels; L++) pnode[L] = sc.get<unsigned int>(n);
   if (!sc.ok) return -1;
 
   // pass A: key range -> digits needed per axis
   const int rblocks = std::min(grid_for(n, B), RANGE_BLOCKS);
-  std::vector<int> h_rows((size_t)6 * rblocks);
-  hipLaunchKernelGGL(k_vox_range, dim3(rblocks), dim3(B), 0, s, d_xyz, d_frame, d_poses, n, o.voxel_size, range);
+  std::vector<int> h_rows((size_t)RANGE_ROW * rblocks);
+  hipLaunchKernelGGL(k_vox_range, dim3(rblocks), dim3(B), 0, s, d_xyz, d_frame, d_poses, n, W, o.voxel_size, range);
   hipMemcpyAsync(h_rows.data(), range, h_rows.size() * sizeof(int), hipMemcpyDeviceToHost, s);
   if (hipStreamSynchronize(s) != hipSuccess) return -1;
   int h_range[6] = {1 << 30, 1 << 30, 1 << 30, -(1 << 30), -(1 << 30), -(1 << 30)};
-  for (int b = 0; b < rblocks; b++)
+  for (int b = 0; b < rblocks; b++) {
+    if (h_rows[(size_t)RANGE_ROW * b + 6]) return -3;           // scan index out of range / non-finite point
     for (int j = 0; j < 3; j++) {
-      h_range[j] = std::min(h_range[j], h_rows[(size_t)6 * b + j]);
-      h_range[3 + j] = std::max(h_range[3 + j], h_rows[(size_t)6 * b + 3 + j]);
+      h_range[j] = std::min(h_range[j], h_rows[(size_t)RANGE_ROW * b + j]);
+      h_range[3 + j] = std::max(h_range[3 + j], h_rows[(size_t)RANGE_ROW * b + 3 + j]);
     }
+  }
   KeyPack kp;
   int key_bits = 0;
   for (int j = 0; j < 3; j++) {

@@ -105,6 +105,11 @@ def test_device_association_edge_cases():
     assert c.F >= 1
     with pytest.raises(capi.BalmError):                                    # frame id out of range
         c.associate(plane.astype(np.float32), np.full(200, 4, np.int32), poses, 1.0)
+    bad = plane.astype(np.float32).copy()
+    bad[17, 1] = np.nan
+    with pytest.raises(capi.BalmError):                                    # non-finite point: rejected, not hashed
+        c.associate(bad, np.zeros(200, np.int32), poses, 1.0)
+    check_same_features(c, frames, poses, 1.0)                             # the context survives both
     c.close()
 
 
