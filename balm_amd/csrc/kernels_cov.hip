@@ -194,30 +194,23 @@ __global__ __launch_bounds__(256) void k_cov_factors(const double *__restrict__ 
             gm[2][c] = c >= 6 ? r3[c - 6] : 0.0;
           }
         }
-        // D = (2/NN) U_0 T_j g1([r3; (p - vbar).u0])  (6x9)                                            (:449-450)
-        //   top  = hat(-u0) (R g1t[:3] + p (x) [0..0 r3]),  bottom = u0 (x) [0..0 r3]
-        double D[6][9];
+        // D = (2/NN) U_0 Y (6x9),  Y = T_j g1([r3; (p - vbar).u0]) (4x9), U_0 = [[hat(-u0), 0], [0, u0]]    (:449-450)
+        //   Y[:3] = R g1t[:3] + p (x) [0..0 r3],  Y[3] = [0 0 0 0 0 0 r3]
+        // everything downstream is done on the 4-row Y and lifted through U_0 at the end
+        double Y[3][9];
         {
           const double st = pu - vu0;
           const double wt[4] = {r3[0], r3[1], r3[2], st};
           double g1t[3][9];
           g1_top(wt, g1t);
 #pragma unroll
-          for (int c = 0; c < 9; c++) {
-            double y[3];
+          for (int c = 0; c < 9; c++)
 #pragma unroll
             for (int r = 0; r < 3; r++) {
-              y[r] = R[r] * g1t[0][c] + R[3 + r] * g1t[1][c] + R[6 + r] * g1t[2][c];
-              if (c >= 6) y[r] += p[r] * r3[c - 6];
+              double y = R[r] * g1t[0][c] + R[3 + r] * g1t[1][c] + R[6 + r] * g1t[2][c];
+              if (c >= 6) y += p[r] * r3[c - 6];
+              Y[r][c] = y;
             }
-            double yx[3];
-            cross3(y, u0, yx);                 // hat(-u0) y = y x u0
-#pragma unroll
-            for (int r = 0; r < 3; r++) {
-              D[r][c] = c2 * yx[r];
-              D[3 + r][c] = c >= 6 ? c2 * u0[r] * r3[c - 6] : 0.0;
-            }
-          }
         }
         // the cluster's 9x9 noise covariance
         double cc[9][9];
@@ -230,16 +223,18 @@ __global__ __launch_bounds__(256) void k_cov_factors(const double *__restrict__ 
         } else {
           noise_cov_isotropic(P, v, N, sigma2, cc);
         }
-        double sg[9][3];                       // c_cov Gm^T
+        double sg[9][3];                       // c_cov Gm^T  (Gm row 2 = [0 0 0 0 0 0 r3])
 #pragma unroll
-        for (int r = 0; r < 9; r++)
+        for (int r = 0; r < 9; r++) {
 #pragma unroll
-          for (int k = 0; k < 3; k++) {
+          for (int k = 0; k < 2; k++) {
             double s = 0.0;
 #pragma unroll
             for (int c = 0; c < 9; c++) s += cc[r][c] * gm[k][c];
             sg[r][k] = s;
           }
+          sg[r][2] = cc[r][6] * r3[0] + cc[r][7] * r3[1] + cc[r][8] * r3[2];
+        }
         {
           int t = 0;
 #pragma unroll
@@ -248,40 +243,89 @@ __global__ __launch_bounds__(256) void k_cov_factors(const double *__restrict__ 
             for (int k = r; k < 3; k++) {
               double s = 0.0;
 #pragma unroll
-              for (int c = 0; c < 9; c++) s += gm[r][c] * sg[c][k];
+              for (int c = (r == 2 ? 6 : 0); c < 9; c++) s += gm[r][c] * sg[c][k];
               q[t++] += s;
             }
         }
+        // Rr = D c_cov Gm^T = c2 U_0 (Y sg):  rows 0..2 = (Y[:3] sg) x u0 per column, rows 3..5 = u0 (Y[3] sg)
 #pragma unroll
-        for (int r = 0; r < 6; r++)
+        for (int k = 0; k < 3; k++) {
+          double ys[3];
 #pragma unroll
-          for (int k = 0; k < 3; k++) {
+          for (int r = 0; r < 3; r++) {
             double s = 0.0;
 #pragma unroll
-            for (int c = 0; c < 9; c++) s += D[r][c] * sg[c][k];
-            rr[r][k] = s;
+            for (int c = 0; c < 9; c++) s += Y[r][c] * sg[c][k];
+            ys[r] = s;
           }
-        {
-          const double w2 = coe * coe;
-          int t = 0;
+          const double y3 = r3[0] * sg[6][k] + r3[1] * sg[7][k] + r3[2] * sg[8][k];
+          double yx[3];
+          cross3(ys, u0, yx);                  // hat(-u0) y = y x u0
 #pragma unroll
-          for (int r = 0; r < 6; r++) {
-            double e[9];                       // row r of D c_cov
+          for (int r = 0; r < 3; r++) { rr[r][k] = c2 * yx[r]; rr[3 + r][k] = c2 * u0[r] * y3; }
+        }
+        // S_j = D c_cov D^T = c2^2 U_0 M U_0^T,  M = Y4 c_cov Y4^T (4x4 symmetric)
+        {
+          double M[4][4];
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            double e[9];                       // row r of Y4 c_cov
 #pragma unroll
             for (int c = 0; c < 9; c++) {
-              double s = 0.0;
+              double sacc_ = 0.0;
+              if (r < 3) {
 #pragma unroll
-              for (int k = 0; k < 9; k++) s += D[r][k] * cc[k][c];
-              e[c] = s;
+                for (int k = 0; k < 9; k++) sacc_ += Y[r][k] * cc[k][c];
+              } else {
+                sacc_ = r3[0] * cc[6][c] + r3[1] * cc[7][c] + r3[2] * cc[8][c];
+              }
+              e[c] = sacc_;
             }
 #pragma unroll
-            for (int k = r; k < 6; k++) {
-              double s = 0.0;
+            for (int k = r; k < 4; k++) {
+              double m = 0.0;
+              if (k < 3) {
 #pragma unroll
-              for (int c = 0; c < 9; c++) s += e[c] * D[k][c];
-              sacc[(t++) * W + i] += w2 * s;
+                for (int c = 0; c < 9; c++) m += e[c] * Y[k][c];
+              } else {
+                m = e[6] * r3[0] + e[7] * r3[1] + e[8] * r3[2];
+              }
+              M[r][k] = M[k][r] = m;
             }
           }
+          // top-left: K M33 K^T with K = hat(-u0) (K y = y x u0); top-right: (K M[:3][3]) u0^T; bottom-right: M33' = M[3][3] u0 u0^T
+          double KM[3][3];                     // column c of K M33: M33[:, c] x u0
+#pragma unroll
+          for (int c = 0; c < 3; c++) {
+            const double col[3] = {M[0][c], M[1][c], M[2][c]};
+            double x[3];
+            cross3(col, u0, x);
+            KM[0][c] = x[0]; KM[1][c] = x[1]; KM[2][c] = x[2];
+          }
+          double S6[6][6];
+#pragma unroll
+          for (int r = 0; r < 3; r++) {
+            const double row[3] = {KM[r][0], KM[r][1], KM[r][2]};     // (K M33)[r, :] -> times K^T: row x u0
+            double x[3];
+            cross3(row, u0, x);
+#pragma unroll
+            for (int c = 0; c < 3; c++) S6[r][c] = x[c];
+          }
+          {
+            const double m3[3] = {M[0][3], M[1][3], M[2][3]};
+            double km3[3];
+            cross3(m3, u0, km3);
+#pragma unroll
+            for (int r = 0; r < 3; r++)
+#pragma unroll
+              for (int c = 0; c < 3; c++) { S6[r][3 + c] = km3[r] * u0[c]; S6[3 + r][3 + c] = M[3][3] * u0[r] * u0[c]; }
+          }
+          const double w2 = coe * coe * c2 * c2;
+          int t = 0;
+#pragma unroll
+          for (int r = 0; r < 6; r++)
+#pragma unroll
+            for (int k = r; k < 6; k++) sacc[(t++) * W + i] += w2 * S6[r][k];
         }
       }
 #pragma unroll
