@@ -166,3 +166,25 @@ def test_consistency_rules_on_shipped_scans():
     clr, fxr = ref_sim.associate(frames, d["poses"], 1, 1.0)
     assert cl.shape == clr.shape == (1096, 100, 10)
     assert np.array_equal(_canon_with_fix(cl, fix), _canon_with_fix(clr, fxr))
+
+
+# ---- committed golden vectors from both compiled copies of the reference's state machine (make_golden_assoc.py) ----
+def _golden(name):
+    from conftest import ROOT
+    d = dict(np.load(os.path.join(ROOT, "tests", "golden", name)))
+    d["frames"] = np.split(d["xyz"], np.cumsum(d["counts"])[:-1])
+    return d
+
+
+def test_host_association_matches_golden_benchmark_rules():
+    g = _golden("assoc_bench_w8.npz")
+    cl, co, layer = rw.associate(g["frames"], g["poses"], 1.0)
+    assert cl.shape == g["clusters"].shape and np.array_equal(canon(cl), canon(g["clusters"]))
+    assert np.array_equal(np.sort(co), np.sort(g["coeffs"])) and len(set(layer.tolist())) == 3
+
+
+def test_host_association_matches_golden_consistency_rules():
+    g = _golden("assoc_sim_w8.npz")
+    cl, co, layer, fix, _ = rw.associate(g["frames"], g["poses"], **rw.SIM_RULES)
+    assert cl.shape == g["clusters"].shape
+    assert np.array_equal(_canon_with_fix(cl, fix), _canon_with_fix(g["clusters"], g["fix"]))

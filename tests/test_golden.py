@@ -12,7 +12,7 @@ from oracle import orc, ref
 from util import make_scene, pose_errors, rel_err
 
 GOLD = sorted(g for g in glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz"))
-              if not os.path.basename(g).startswith("cov_"))      # covariance fixtures: tests/test_cov_oracle.py
+              if not os.path.basename(g).startswith(("cov_", "assoc_")))      # covariance fixtures: tests/test_cov_oracle.py
 
 
 def load(path):

@@ -231,3 +231,18 @@ def test_device_association_consistency_rules():
     loose = dict(rw.SIM_RULES, strict=None)
     assert rw.associate_gpu(c, frames, poses, **loose)[0] >= F
     c.close()
+
+
+def test_device_association_matches_reference_golden_vectors():
+    """committed golden vectors made by both compiled copies of the reference's association (tests/golden/
+    make_golden_assoc.py): benchmark rules (all three layers) and the consistency driver's rules (fix clusters)"""
+    from test_association import _golden
+    g = _golden("assoc_bench_w8.npz")
+    c = capi.Context(8)
+    F, _, (cl, co, layer) = rw.associate_gpu(c, g["frames"], g["poses"], 1.0)
+    assert cl.shape == g["clusters"].shape and np.array_equal(canon(cl), canon(g["clusters"]))
+    assert np.array_equal(np.sort(co), np.sort(g["coeffs"]))
+    g = _golden("assoc_sim_w8.npz")
+    F, _, (cl, co, layer, fix, _) = rw.associate_gpu(c, g["frames"], g["poses"], **rw.SIM_RULES)
+    assert np.array_equal(_canon_with_fix(cl, fix), _canon_with_fix(g["clusters"], g["fix"]))
+    c.close()
