@@ -409,11 +409,22 @@ __global__ __launch_bounds__(256) void k_cov_reduce_tiles(const double *__restri
 
 __global__ __launch_bounds__(256) void k_cov_reduce_dacc(const double *__restrict__ dpart, int nblk, int len,
                                                          double *__restrict__ out) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= len) return;
-  double s = 0.0;
-  for (int b = 0; b < nblk; b++) s += dpart[(size_t)b * len + t];
-  out[t] = s;
+  // 64 outputs per workgroup, the block range split over its four waves, eight loads in flight; fixed order
+  __shared__ double sq[256];
+  const int jl = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int j = blockIdx.x * 64 + jl;
+  const int chunk = (nblk + 3) / 4, b0 = q * chunk, b1 = min(nblk, b0 + chunk);
+  double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (j < len) {
+    int b = b0;
+    for (; b + 8 <= b1; b += 8)
+#pragma unroll
+      for (int k = 0; k < 8; k++) a[k] += dpart[(size_t)(b + k) * len + j];
+    for (; b < b1; b++) a[0] += dpart[(size_t)b * len + j];
+  }
+  sq[threadIdx.x] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+  __syncthreads();
+  if (q == 0 && j < len) out[j] = (sq[jl] + sq[64 + jl]) + (sq[128 + jl] + sq[192 + jl]);
 }
 
 // Rcov_raw = XX^T - YY^T + blockdiag(S), both triangles.  MFMA f64 16x16x4 C/D layout of the tile sets:
@@ -651,7 +662,7 @@ void launch_cov_reduce_tiles(hipStream_t s, const double *part, int SG, long til
 }
 
 void launch_cov_reduce_dacc(hipStream_t s, const double *dpart, int nblk, int W, double *out) {
-  hipLaunchKernelGGL(k_cov_reduce_dacc, dim3((COV_DACC * W + 255) / 256), dim3(256), 0, s, dpart, nblk, COV_DACC * W, out);
+  hipLaunchKernelGGL(k_cov_reduce_dacc, dim3((COV_DACC * W + 63) / 64), dim3(256), 0, s, dpart, nblk, COV_DACC * W, out);
 }
 
 void launch_cov_assemble(hipStream_t s, const double *redx, const double *redy, const double *sdiag, const int *tileIJ,
