@@ -2,6 +2,7 @@
 // (per-feature SoA clusters, poses, Hessian), sequences the HIP kernels on one stream, and runs the
 // Levenberg-Marquardt loop of BALM2::damping_iter (src/benchmark/bavoxel.hpp:1069-1166) with every
 // matrix device-resident; only four scalars cross PCIe per iteration.
+#include <array>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -132,7 +133,7 @@ int evaluate_device(balm_ctx *ctx, int form, const double *d_poses, int f0, int 
   }
   {
     Span sp(ctx, BALM_T_SYRK);
-    launch_syrk(s, ctx->d_Gt, ctx->npad, ctx->ntiles, ctx->d_tileIJ, plan, ctx->d_part);
+    launch_syrk(s, ctx->d_Gt, ctx->npad, ctx->ntiles, ctx->d_jobs, plan, ctx->d_part);
   }
   {
     Span sp(ctx, BALM_T_ASSEMBLE);
@@ -143,7 +144,7 @@ int evaluate_device(balm_ctx *ctx, int form, const double *d_poses, int f0, int 
   if ((rc = hook_allreduce(ctx, ctx->d_red, (long)ctx->red_len))) return rc;
   {
     Span sp(ctx, BALM_T_ASSEMBLE);
-    launch_assemble(s, form, ctx->d_red, red_dacc_off(ctx), ctx->d_tileIJ, ctx->ntiles, W, ctx->d_H, ctx->d_g);
+    launch_assemble(s, form, ctx->d_red, red_dacc_off(ctx), ctx->d_sub, ctx->ntiles, W, ctx->d_H, ctx->d_g);
     HIP_TRY(hipMemcpyAsync(ctx->d_scal + slot, ctx->d_red + red_r_off(ctx), sizeof(double),
                            hipMemcpyDeviceToDevice, s));
   }
@@ -173,17 +174,56 @@ balm_ctx *balm_create(int win_size, int device, int flags) {
   ctx->n = 6 * win_size;
   ctx->npad = (ctx->n + TILE - 1) / TILE * TILE;
   ctx->T = ctx->npad / TILE;
-  ctx->ntiles = ctx->T * (ctx->T + 1) / 2;
   ctx->nA = (ctx->n + NB - 1) / NB * NB;
   ctx->device = device;
   ctx->flags = flags;
   ctx->timer.on = (flags & BALM_FLAG_TIMING) != 0;
   auto fail = [&]() -> balm_ctx * { balm_destroy(ctx); return nullptr; };
+  // The SYRK's jobs per k-slice, each 25 accumulator sub-tiles (16x16) = one wavefront:
+  //   the off-diagonal 80x80 tiles (I < J), in shells of growing J: a prefix of the list touches few row blocks.
+  //     An XCD has 128 wave slots for the jobs of a k-slice, so every "generation" of waves holds the tail of one
+  //     slice and the head of the next; the head's rows are fetched for it alone, and a compact head needs fewer
+  //     of them (2.29 GB vs 2.63 GB fetched per launch with an I-major order);
+  //   the diagonal blocks: five consecutive ones have 5 x 15 = 75 upper sub-tiles = three "mixed" jobs of 25
+  //     (csrc/gen/gen_syrk_asm.py), placed after the shell of their last block; blocks left over (T mod 5) run as
+  //     full tiles whose lower half is ignored.
+  // jobs[4 j] = {type 0 | 1..3, I or first block of the group, J, 0}; sub[25 j + t] = (R << 16) | C, the global
+  // 16-row sub-tile coordinates of accumulator tile t (what the assemble kernels need).
+  std::vector<int> jobs, sub;
+  {
+    const int T = ctx->T, ngroups = T / 5;
+    std::vector<std::array<int, 3>> mixed[4];           // (block offset, r, c) lists, as the generator builds them
+    std::vector<std::array<int, 2>> pairs;
+    for (int r = 0; r < TM; r++) for (int c = r; c < TM; c++) pairs.push_back({r, c});
+    for (int k = 0; k < 15; k++) mixed[1].push_back({0, pairs[k][0], pairs[k][1]});
+    for (int k = 0; k < 10; k++) mixed[1].push_back({1, pairs[k][0], pairs[k][1]});
+    for (int k = 10; k < 15; k++) mixed[2].push_back({1, pairs[k][0], pairs[k][1]});
+    for (int k = 0; k < 15; k++) mixed[2].push_back({2, pairs[k][0], pairs[k][1]});
+    for (int k = 0; k < 5; k++) mixed[2].push_back({3, pairs[k][0], pairs[k][1]});
+    for (int k = 5; k < 15; k++) mixed[3].push_back({3, pairs[k][0], pairs[k][1]});
+    for (int k = 0; k < 15; k++) mixed[3].push_back({4, pairs[k][0], pairs[k][1]});
+    auto regular = [&](int I, int J) {
+      jobs.insert(jobs.end(), {0, I, J, 0});
+      for (int t = 0; t < 25; t++) sub.push_back(((TM * I + t / TM) << 16) | (TM * J + t % TM));
+    };
+    for (int m = 0; m < T; m++) {
+      for (int i = 0; i < m; i++) regular(i, m);
+      if (m >= TM * ngroups) regular(m, m);
+      else if (m % TM == TM - 1) {
+        const int b = m - (TM - 1);
+        for (int v = 1; v <= 3; v++) {
+          jobs.insert(jobs.end(), {v, b, b, 0});
+          for (const auto &e : mixed[v]) sub.push_back(((TM * (b + e[0]) + e[1]) << 16) | (TM * (b + e[0]) + e[2]));
+        }
+      }
+    }
+  }
+  ctx->ntiles = (int)(jobs.size() / 4);
   if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) return fail();
   const int W = ctx->W, n = ctx->n, nA = ctx->nA;
   ctx->red_len = (size_t)ctx->ntiles * TILE_ELEMS + (size_t)DACC_MAX * W + 2;
   if (dalloc(ctx, &ctx->d_poses, (size_t)12 * W) || dalloc(ctx, &ctx->d_poses_tmp, (size_t)12 * W) ||
-      dalloc(ctx, &ctx->d_red, ctx->red_len) || dalloc(ctx, &ctx->d_tileIJ, (size_t)2 * ctx->ntiles) ||
+      dalloc(ctx, &ctx->d_red, ctx->red_len) || dalloc(ctx, &ctx->d_jobs, jobs.size()) || dalloc(ctx, &ctx->d_sub, sub.size()) ||
       dalloc(ctx, &ctx->d_H, (size_t)n * n) || dalloc(ctx, &ctx->d_g, (size_t)n) ||
       dalloc(ctx, &ctx->d_A, (size_t)(nA + NB) * nA) || dalloc(ctx, &ctx->d_Wp, (size_t)NB * (nA + NB)) ||
       dalloc(ctx, &ctx->d_dvec, (size_t)nA) || dalloc(ctx, &ctx->d_z, (size_t)nA) || dalloc(ctx, &ctx->d_x, (size_t)nA) ||
@@ -191,14 +231,9 @@ balm_ctx *balm_create(int win_size, int device, int flags) {
       dalloc(ctx, &ctx->d_scal, (size_t)16))
     return fail();
   if (hipHostMalloc((void **)&ctx->h_scal, 16 * sizeof(double)) != hipSuccess) return fail();
-  // tile order = shells of growing max(I, J): a prefix of the list touches few row blocks.  An XCD has 128 wave
-  // slots for the 120 tiles of a k-slice, so every "generation" of waves holds the tail of one slice and the head
-  // of the next; the head's rows are fetched for it alone, and a compact head needs fewer of them
-  // (2.29 GB vs 2.63 GB fetched per launch with the I-major order).
-  std::vector<int> ij;
-  for (int m = 0; m < ctx->T; m++)
-    for (int i = 0; i <= m; i++) { ij.push_back(i); ij.push_back(m); }
-  if (hipMemcpy(ctx->d_tileIJ, ij.data(), ij.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) return fail();
+  if (hipMemcpy(ctx->d_jobs, jobs.data(), jobs.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(ctx->d_sub, sub.data(), sub.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess)
+    return fail();
   if (hipMemset(ctx->d_scal, 0, 16 * sizeof(double)) != hipSuccess) return fail();
   if (hipMemset(ctx->d_red, 0, ctx->red_len * sizeof(double)) != hipSuccess) return fail();
   return ctx;
@@ -209,7 +244,7 @@ void balm_destroy(balm_ctx *ctx) {
   hipSetDevice(ctx->device);
   if (ctx->stream) hipStreamSynchronize(ctx->stream);
   void *ptrs[] = {ctx->d_cl, ctx->d_fix, ctx->d_coe, ctx->d_poses, ctx->d_poses_tmp, ctx->d_C, ctx->d_feat,
-                  ctx->d_Gt, ctx->d_part, ctx->d_dpart, ctx->d_rpart, ctx->d_feat_tmp, ctx->d_rpart_tmp, ctx->d_red, ctx->d_tileIJ, ctx->d_H,
+                  ctx->d_Gt, ctx->d_part, ctx->d_dpart, ctx->d_rpart, ctx->d_feat_tmp, ctx->d_rpart_tmp, ctx->d_red, ctx->d_jobs, ctx->d_sub, ctx->d_H,
                   ctx->d_g, ctx->d_A, ctx->d_Wp, ctx->d_dvec, ctx->d_z, ctx->d_x, ctx->d_perm, ctx->d_dx, ctx->d_scal, ctx->d_arena};
   for (void *p : ptrs) if (p) hipFree(p);
   if (ctx->h_scal) hipHostFree(ctx->h_scal);
@@ -478,16 +513,16 @@ int balm_pose_covariance(balm_ctx *ctx, const double *poses, const double *clust
     hipMemsetAsync(Gy + k0 * ctx->npad, 0, (gcols - k0) * ctx->npad * sizeof(double), s);
     launch_cov_factors(s, ctx->d_cl, d_cc, point_sigma * point_sigma, ctx->d_poses, ctx->d_feat, W, ctx->npad, F, Gx, Gy,
                        ctx->d_dpart, nblk);
-    launch_syrk(s, Gx, ctx->npad, ctx->ntiles, ctx->d_tileIJ, plan, ctx->d_part);
+    launch_syrk(s, Gx, ctx->npad, ctx->ntiles, ctx->d_jobs, plan, ctx->d_part);
     launch_cov_reduce_tiles(s, ctx->d_part, plan.SG, (long)tiles, redx);
-    launch_syrk(s, Gy, ctx->npad, ctx->ntiles, ctx->d_tileIJ, plan, ctx->d_part);
+    launch_syrk(s, Gy, ctx->npad, ctx->ntiles, ctx->d_jobs, plan, ctx->d_part);
     launch_cov_reduce_tiles(s, ctx->d_part, plan.SG, (long)tiles, redy);
     launch_cov_reduce_dacc(s, ctx->d_dpart, nblk, W, sdiag);
   }
   if (e == hipSuccess) rc = hook_allreduce(ctx, buf, (long)pay);
   if (e == hipSuccess && !rc) {
     Span sp(ctx, BALM_T_COV);
-    launch_cov_assemble(s, redx, redy, sdiag, ctx->d_tileIJ, ctx->ntiles, W, Rraw);
+    launch_cov_assemble(s, redx, redy, sdiag, ctx->d_sub, ctx->ntiles, W, Rraw);
     hipMemsetAsync(ctx->d_g, 0, (size_t)n * sizeof(double), s);
     launch_solve(ctx, 0.0, true);                        // P H P^T = L D L^T stays in d_A / d_dvec / d_perm
     launch_congruence_inverse(ctx, Rraw, Z, Zs, tmp, Linv, Rc);
@@ -663,8 +698,7 @@ int balm_work_model(balm_ctx *ctx, double *out4) {
   out4[1] = ctx->work_B;
   out4[2] = 108.0 * F * W * (W + 1.0);            // 108 FMA = 216 flop per unordered pair incl. diagonal -> x2/2
   SyrkPlan p = plan_syrk(ctx->ntiles, 3L * ctx->F);
-  const double noff = ctx->ntiles - ctx->T, ndiag = ctx->T;
-  out4[3] = (noff + ndiag) * 25.0 * 2048.0 * ((double)p.Kpad / 4.0);   // every k-step of every tile (diagonal tiles run full sweeps)
+  out4[3] = (double)ctx->ntiles * 25.0 * 2048.0 * ((double)p.Kpad / 4.0);   // 25 MFMAs per k-step of every job
   return BALM_OK;
 }
 

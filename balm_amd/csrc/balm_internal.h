@@ -67,7 +67,8 @@ struct balm_ctx {
   double *d_rpart = nullptr;        // residual partials at the current poses
   double *d_red = nullptr;          // [ntiles*6400 | DACC_MAX*W | r | pad]   all-reduce payload
   size_t red_len = 0;
-  int *d_tileIJ = nullptr;          // [ntiles][2]
+  int *d_jobs = nullptr;            // [ntiles][4]  SYRK jobs per k-slice: type, block I (or first block of a group), block J
+  int *d_sub = nullptr;             // [ntiles][25] (R << 16) | C: global 16-row sub-tile coordinates of each accumulator tile
   double *d_H = nullptr;            // [n][n] column-major
   double *d_g = nullptr;            // [n]
   // solver

@@ -611,28 +611,59 @@ __device__ __forceinline__ void syrk_sweep(const double *__restrict__ pa, const 
   }
 }
 
-__global__ __launch_bounds__(64) void k_hessian_syrk(const double *__restrict__ Gt, int npad, int ntiles,
-                                                     const int *__restrict__ tileIJ, int nsteps, long nblocks,
+// A "mixed" wave: 25 upper sub-tile pairs of up to three consecutive diagonal blocks (syrk_mfma_asm.inc, gen/).
+#define BALM_DEFINE_MIXED_SWEEP(V)                                                                                  \
+  __device__ __forceinline__ void syrk_sweep_mixed##V(const double *__restrict__ p, size_t step, int nsteps) {    \
+    double x[SYRK_NBUF][BALM_SYRK_MIX##V##_NLOAD];                                                                  \
+    _Pragma("unroll") for (int i = 0; i < SYRK_NBUF - 1; i++) {                                                    \
+      const double *q = p + i * step;                                                                               \
+      BALM_SYRK_MIX##V##_LOAD(q, x[i])                                                                              \
+    }                                                                                                               \
+    p += (SYRK_NBUF - 1) * step;                                                                                    \
+    for (int s = 0; s < nsteps; s += SYRK_NBUF) {                                                                   \
+      _Pragma("unroll") for (int j = 0; j < SYRK_NBUF; j++) {                                                      \
+        const int nb = (j + SYRK_NBUF - 1) % SYRK_NBUF;                                                             \
+        BALM_SYRK_MIX##V##_LOAD(p, x[nb])                                                                           \
+        p += step;                                                                                                  \
+        BALM_SYRK_MIX##V##_MFMA(x[j])                                                                               \
+      }                                                                                                             \
+    }                                                                                                               \
+  }
+BALM_DEFINE_MIXED_SWEEP(1)
+BALM_DEFINE_MIXED_SWEEP(2)
+BALM_DEFINE_MIXED_SWEEP(3)
+#undef BALM_DEFINE_MIXED_SWEEP
+
+__global__ __launch_bounds__(64) void k_hessian_syrk(const double *__restrict__ Gt, int npad, int njobs,
+                                                     const int *__restrict__ jobs, int nsteps, long nblocks,
                                                      double *__restrict__ part) {
-  // One wavefront per (tile, k-slice).  XCD-aware remap: hardware places workgroup b on XCD b % 8;
-  // every XCD gets a contiguous run of logical workgroups = ALL tiles of one k-slice after the other.
-  // An XCD holds 128 of these one-wave workgroups (4 per CU), i.e. the 120 tiles of a slice run side
-  // by side and sweep k in lockstep (they are all MFMA-paced), so each 128-byte line of Gt is pulled
-  // into that XCD's L2 once and serves the ~15 tiles that need it.
+  // One wavefront per (job, k-slice); a job = an off-diagonal 80x80 tile or 25 upper sub-tiles of the diagonal
+  // blocks (jobs[4 j] = type, block I or base block, block J).  XCD-aware remap: hardware places workgroup b on XCD
+  // b % 8; every XCD gets a contiguous run of logical workgroups = ALL jobs of one k-slice after the other.
+  // An XCD holds 128 of these one-wave workgroups (4 per CU), i.e. the jobs of a slice run side by side and sweep
+  // k in lockstep (they are all MFMA-paced, 25 MFMAs per k-step each), so each 128-byte line of Gt is pulled into
+  // that XCD's L2 once and serves the ~15 jobs that need it.
   long bid = blockIdx.x;
-  if ((nblocks & 7) == 0) bid = (bid & 7) * (nblocks >> 3) + (bid >> 3);
-  const int tile = (int)(bid % ntiles);
-  const int sg = (int)(bid / ntiles);
-  const int I = tileIJ[2 * tile], J = tileIJ[2 * tile + 1];
+  {
+    const long q = nblocks >> 3, r = nblocks & 7, x = bid & 7;       // XCD x runs q (+1 if x < r) logical workgroups
+    bid = x * q + (x < r ? x : r) + (bid >> 3);
+  }
+  const int tile = (int)(bid % njobs);
+  const int sg = (int)(bid / njobs);
+  const int type = jobs[4 * tile], I = jobs[4 * tile + 1], J = jobs[4 * tile + 2];
   const int lane = threadIdx.x;
   const size_t k_begin = (size_t)sg * nsteps * 4;
   const double *base = Gt + (k_begin + (lane >> 4)) * (size_t)npad + (lane & 15);
   const double *pa = base + I * TILE;
   const double *pb = base + J * TILE;
   const size_t step = (size_t)4 * npad;
+  const int ntiles = njobs;
 
   BALM_SYRK_ZERO_ACC();
-  syrk_sweep(pa, pb, step, nsteps);
+  if (type == 0) syrk_sweep(pa, pb, step, nsteps);
+  else if (type == 1) syrk_sweep_mixed1(pa, step, nsteps);
+  else if (type == 2) syrk_sweep_mixed2(pa, step, nsteps);
+  else syrk_sweep_mixed3(pa, step, nsteps);
   // MFMA (16 passes) -> v_accvgpr_read needs wait states the assembler will not insert for asm
   asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
 
@@ -654,7 +685,8 @@ SyrkPlan plan_syrk(int ntiles, long K) {
   long max_sg = steps / 64;                         // keep >= 256 columns per wave
   if (max_sg < 1) max_sg = 1;
   // ~4 resident rounds of the 1024 wave slots (128 per XCD): pick the slice count in that
-  // neighbourhood whose last round is fullest
+  // neighbourhood whose last round is fullest (measured with 114 jobs per slice: 35 / 44 / 53 slices = 4 / 5 / 6
+  // rounds are within 0.7 % of each other, the extra partial tiles of the larger counts cost it back in the reduce)
   long base = (4096 + ntiles - 1) / ntiles, sg = base;
   double best = -1.0;
   for (long c = (base > 6 ? base - 6 : 1); c <= base + 6; c++) {
@@ -789,11 +821,10 @@ __global__ __launch_bounds__(256) void k_assemble(const double *__restrict__ red
     const int e = (int)(t - (long)tile * TILE_ELEMS);
     const int lane = e & 63, slot = e >> 6;
     const int reg = slot & 3, mt = slot >> 2;
-    const int mr = mt / TM, mc = mt - mr * TM;
-    const int I = tileIJ[2 * tile], J = tileIJ[2 * tile + 1];
-    const int row = I * TILE + mr * 16 + (lane >> 4) + 4 * reg;
-    const int col = J * TILE + mc * 16 + (lane & 15);
-    if (row >= n || col >= n || row > col) continue;   // diagonal tiles: only r <= c was computed
+    const int rc = tileIJ[tile * 25 + mt];              // global 16-row sub-tile coordinates of accumulator tile mt
+    const int row = (rc >> 16) * 16 + (lane >> 4) + 4 * reg;
+    const int col = (rc & 0xffff) * 16 + (lane & 15);
+    if (row >= n || col >= n || row > col) continue;   // diagonal sub-tiles: only r <= c is used
     double val = -red[t];
     const int pi = row / 6, pj = col / 6;
     if (pi == pj) {

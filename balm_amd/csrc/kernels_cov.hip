@@ -439,10 +439,9 @@ __global__ __launch_bounds__(256) void k_cov_assemble(const double *__restrict__
     const int e = (int)(t - (long)tile * TILE_ELEMS);
     const int lane = e & 63, slot = e >> 6;
     const int reg = slot & 3, mt = slot >> 2;
-    const int mr = mt / TM, mc = mt - mr * TM;
-    const int I = tileIJ[2 * tile], J = tileIJ[2 * tile + 1];
-    const int row = I * TILE + mr * 16 + (lane >> 4) + 4 * reg;
-    const int col = J * TILE + mc * 16 + (lane & 15);
+    const int rc = tileIJ[tile * 25 + mt];
+    const int row = (rc >> 16) * 16 + (lane >> 4) + 4 * reg;
+    const int col = (rc & 0xffff) * 16 + (lane & 15);
     if (row >= n || col >= n || row > col) continue;
     double val = redx[t] - redy[t];
     const int pi = row / 6, pj = col / 6;
