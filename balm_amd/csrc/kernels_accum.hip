@@ -8,7 +8,8 @@
 //   K1  world_moments   one wavefront per feature, coalesced SoA reads, shuffle reduction
 //   K1b feature_eigen   one lane per feature: 3x3 Jacobi, residual partials
 //   K2  feature_factors one lane per (feature, pose): Gt columns + gradient + B_i partials
-//   K3  hessian_syrk    80x80 tiles per wavefront on v_mfma_f64_16x16x4_f64, split-K
+//   K3  hessian_syrk    25 MFMA sub-tiles (an 80x80 tile, or 25 upper sub-tiles of the diagonal blocks) per
+//                       wavefront on v_mfma_f64_16x16x4_f64, split-K
 //   K4  reduce / assemble
 #include "balm_internal.h"
 
@@ -568,9 +569,10 @@ void launch_factors(hipStream_t s, int form, const double *cl, const double *pos
 }
 
 // ------------------------------------------------------------------------------------------------
-// K3: hessian_syrk.  part[sg][tile] = Gt[I-rows, kslice] * Gt[J-rows, kslice]^T for the upper
-// triangle of 80x80 tiles.  One wavefront owns a full 80x80 accumulator (25 v_mfma_f64_16x16x4_f64
-// tiles = 200 accumulator AGPRs, one wave per SIMD) over one k-slice; no LDS, no barriers.
+// K3: hessian_syrk.  part[sg][job] = Gt[I-rows, kslice] * Gt[J-rows, kslice]^T for the off-diagonal
+// 80x80 tiles of the upper triangle, and the upper 16x16 sub-tiles of the diagonal blocks packed 25 to a
+// job.  One wavefront owns 25 v_mfma_f64_16x16x4_f64 accumulator tiles (200 AGPRs, one wave per SIMD) over
+// one k-slice; no LDS, no barriers.
 // Operands come straight from L2: lane l of an MFMA operand is Gt[k0 + (l>>4)][row0 + (l&15)] --
 // four 128-byte row segments per instruction.
 // ------------------------------------------------------------------------------------------------
