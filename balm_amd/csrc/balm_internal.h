@@ -72,11 +72,11 @@ struct balm_ctx {
   double *d_H = nullptr;            // [n][n] column-major
   double *d_g = nullptr;            // [n]
   // solver
-  double *d_A = nullptr;            // [nA cols][nA+NB rows] permuted damped matrix + RHS row tile -> L in place
-  double *d_Wp = nullptr;           // [NB][nA+NB]  W21 = L21 * D11 of the current panel
+  double *d_A = nullptr;            // [nA cols][2 nA + NB rows] permuted damped matrix + RHS row tile + identity -> L, z, L^-T D^+
+  double *d_Wp = nullptr;           // [NB][2 nA + NB]  W21 = L21 * D11 of the current panel
   double *d_dvec = nullptr;         // [nA] pivots D
   double *d_z = nullptr;            // [nA] z = D^+ L^-1 P b, then scratch of the backward sweep
-  double *d_x = nullptr;            // [nA] solution in permuted order
+  double *d_x = nullptr;            // [16][nA] column-chunk partials of the solution in permuted order
   int *d_perm = nullptr;            // [nA] position -> original index
   double *d_dx = nullptr;           // [n]
   double *d_scal = nullptr;         // [16] device scalars: 0 r1, 1 r2, 2 q1, 3 flags

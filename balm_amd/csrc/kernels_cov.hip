@@ -613,7 +613,7 @@ inline int grid1(long total, int bs, int cap) {
 // out (n x m, ld n) = H^-1 B (n x m, ld n); Z, S = nA x m scratch each
 void solve_multi(balm_ctx *c, const double *Linv, const double *B, int m, double *Z, double *S, double *out) {
   hipStream_t s = c->stream;
-  const int n = c->n, nA = c->nA, ldA = nA + NB, P = nA / NB;
+  const int n = c->n, nA = c->nA, ldA = 2 * nA + NB, P = nA / NB;
   const unsigned gx = (unsigned)((m + 63) / 64);
   hipLaunchKernelGGL(k_rows_permute, dim3(grid1((long)nA * m, 256, 4096)), dim3(256), 0, s, B, n, nA, m, c->d_perm, 0, Z);
   for (int p = 0; p < P; p++) {                 // forward: work in Z, solved rows into S
@@ -674,7 +674,7 @@ void launch_cov_assemble(hipStream_t s, const double *redx, const double *redy, 
 // Linv (nA x NB) scratch
 void launch_congruence_inverse(balm_ctx *c, const double *Rraw, double *Z, double *S, double *tmp, double *Linv, double *Rcov) {
   const int n = c->n, nA = c->nA;
-  hipLaunchKernelGGL(k_invert_diag_blocks, dim3(nA / NB), dim3(64), 0, c->stream, c->d_A, nA + NB, Linv);
+  hipLaunchKernelGGL(k_invert_diag_blocks, dim3(nA / NB), dim3(64), 0, c->stream, c->d_A, 2 * nA + NB, Linv);
   solve_multi(c, Linv, Rraw, n, Z, S, tmp);              // M1 = H^-1 Rraw
   hipLaunchKernelGGL(k_transpose_sq, dim3((n + 15) / 16, (n + 15) / 16), dim3(256), 0, c->stream, tmp, n, Rcov);
   solve_multi(c, Linv, Rcov, n, Z, S, tmp);              // H^-1 M1^T = H^-1 Rraw H^-T  (symmetric)

@@ -9,9 +9,12 @@
 //   per panel of NB=48 columns:  ldl_panel (rank-4 steps on f64 MFMA) L11, D11 (redundantly per workgroup),
 //                                                                     W21 = L21 D11, L21
 //                                ldl_trail (f64 MFMA, 48x16 tiles)    A22 -= L21 W21^T
-//   The right-hand side rides along as one extra row below the matrix (row nA of the ldA = nA+NB
-//   row storage): the panel / trail kernels then produce z = D^+ L^-1 P b for free, and only the
-//   backward solve  L^T x = z  (+ un-permute, q1) is left for one workgroup in 16-column sub-panels.
+//   Two things ride along as extra rows below the matrix (ldA = 2 nA + NB rows of storage):
+//     row nA          the right-hand side: the panel / trail kernels produce z = D^+ L^-1 P b for free;
+//     rows nA+NB ..   the identity: its rows come out as M = L^-T D^+ (upper triangular; tile t is only touched
+//                     from panel t on, so the factorisation carries ~25 % more trail tiles and no extra
+//                     launches), which turns the backward solve  L^T x = z  -- a chain of one launch per panel
+//                     -- into ONE matrix-vector product  x = M (D z)  (k_ldl_apply).
 // Pose update kernels (bavoxel.hpp:1116-1126, 1159-1164) live here too.
 #include <cfloat>
 
@@ -55,7 +58,7 @@ __global__ __launch_bounds__(256) void k_rank_diag(const double *__restrict__ H,
 __global__ __launch_bounds__(256) void k_build_A(const double *__restrict__ H, const double *__restrict__ g, int n,
                                                  int nA, const int *__restrict__ perm, double u,
                                                  double *__restrict__ A) {
-  const int ldA = nA + NB;
+  const int ldA = 2 * nA + NB;
   const long total = (long)ldA * nA;
   for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
     const int c = (int)(t / ldA), r = (int)(t - (long)c * ldA);
@@ -69,8 +72,10 @@ __global__ __launch_bounds__(256) void k_build_A(const double *__restrict__ H, c
       } else {
         v = (r == c) ? 1.0 : 0.0;
       }
-    } else {
+    } else if (r < nA + NB) {
       v = (r == nA && pc < n) ? -g[pc] : 0.0;     // right-hand side row: P (-JacT)
+    } else {
+      v = (r - (nA + NB) == c) ? 1.0 : 0.0;       // identity rows -> L^-T D^+
     }
     A[t] = v;
   }
@@ -108,13 +113,13 @@ __device__ __forceinline__ double rcp_nr(double d) {        // 1/d: v_rcp_f64 + 
   return (fabs(d) > DBL_MIN) ? x : 0.0;                      // Eigen's D^+ rule for a vanished pivot
 }
 
-__global__ __launch_bounds__(256) void k_ldl_panel(double *__restrict__ A, int nA, int c0,
+__global__ __launch_bounds__(256) void k_ldl_panel(double *__restrict__ A, int nA, int c0, int nR,
                                                    double *__restrict__ dvec, double *__restrict__ Wp,
                                                    double *__restrict__ zvec) {
   __shared__ double cur[4][PANEL_LR];     // the four current columns, all local rows
   __shared__ double Wop[4][PANEL_LR];     // -W (B operand), k-major
   __shared__ double Lop[4][PANEL_LR];     //  L (A operand; only local rows < NB are read)
-  const int ldA = nA + NB, nR = nA + NB;
+  const int ldA = 2 * nA + NB;           // nR = live rows: matrix, right-hand side tile, identity tiles <= this panel
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int l15 = lane & 15, l4 = lane >> 4;
   const int rbase = c0 + NB + blockIdx.x * PANEL_ROWS;        // first own row
@@ -228,7 +233,7 @@ __global__ __launch_bounds__(256) void k_ldl_panel(double *__restrict__ A, int n
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_ldl_trail(double *__restrict__ A, int nA, int c0,
                                                    const double *__restrict__ Wp, int mt) {
-  const int ldA = nA + NB;
+  const int ldA = 2 * nA + NB;
   const int lane = threadIdx.x & 63;
   const int ti = blockIdx.y;                                  // 48-row tile; ti == mt: right-hand side tile
   const int tj = blockIdx.x * 4 + (threadIdx.x >> 6);         // 16-col tile
@@ -266,52 +271,33 @@ __global__ __launch_bounds__(256) void k_ldl_trail(double *__restrict__ A, int n
 }
 
 // ------------------------------------------------------------------------------------------------
-// backward solve  L^T x = z, right-looking, one launch per panel (descending).  Every workgroup
-// solves the NB x NB unit-triangular block redundantly (wave 0: lane = column, v_readlane
-// substitution) while all its lanes already hold -- prefetched -- the NB multipliers
-// L[c0..c0+NB)[r] of their own row r < c0 (384 contiguous bytes), then applies the rank-NB update
-// z_r -= L[.,r] . x_p.  Workgroup 0 publishes x_p.
+// backward solve  L^T x = z  as one product with the factor's own by-product: the identity rows appended to the
+// matrix came out of the factorisation as M = L^-T D^+ (row r, columns c >= r), so x = M (D z).
+// 64 rows per workgroup, the column range split over its four waves; lanes of a wave read 512 contiguous bytes.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_ldl_back_panel(const double *__restrict__ A, int nA, int c0,
-                                                        double *__restrict__ z, double *__restrict__ xout) {
-  __shared__ double xs[NB];
-  const int ldA = nA + NB;
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int r = blockIdx.x * 256 + tid;
-  const bool has_row = r < c0;
-  double l[NB];
-  {
-    const double *src = A + (size_t)(has_row ? r : 0) * ldA + c0;
+constexpr int APPLY_CHUNKS = 16;        // column chunks of the product; k_ldl_finish adds the partials in order
+__global__ __launch_bounds__(256) void k_ldl_apply(const double *__restrict__ A, int nA, const double *__restrict__ dvec,
+                                                   const double *__restrict__ z, double *__restrict__ xpart) {
+  __shared__ double sq[256];
+  const int ldA = 2 * nA + NB;
+  const int rl = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int r0 = blockIdx.x * 64, r = r0 + rl;
+  // this workgroup: rows r0..r0+63 x column chunk blockIdx.y (multiples of 16 columns; only columns >= r0 matter)
+  const int span = ((nA - r0) / 16 + APPLY_CHUNKS - 1) / APPLY_CHUNKS * 16;
+  const int cbeg = r0 + blockIdx.y * span, cend = min(nA, cbeg + span);
+  double acc0 = 0.0, acc1 = 0.0;
+  const double *Mr = A + (size_t)(nA + NB) + min(r, nA - 1);
+  for (int cb = cbeg + 16 * q; cb < cend; cb += 64) {
 #pragma unroll
-    for (int k = 0; k < NB; k++) l[k] = src[k];
-  }
-  if (wv == 0) {
-    const int j = lane < NB ? lane : 0;
-    const double *col = A + (size_t)(c0 + j) * ldA + c0;       // column j of the block: rows k > j
-    double Lb[NB];
-#pragma unroll
-    for (int k = 0; k < NB; k++) Lb[k] = col[k];
-    double v = z[c0 + j];
-#pragma unroll
-    for (int k = NB - 1; k >= 1; k--) {
-      const double xk = bcast(v, k);
-      if (lane < k) v = __builtin_fma(-Lb[k], xk, v);
-    }
-    if (lane < NB) {
-      xs[lane] = v;
-      if (blockIdx.x == 0) xout[c0 + lane] = v;
+    for (int k = 0; k < 16; k += 2) {
+      const int c = cb + k;
+      acc0 = __builtin_fma(Mr[(size_t)c * ldA], dvec[c] * z[c], acc0);
+      acc1 = __builtin_fma(Mr[(size_t)(c + 1) * ldA], dvec[c + 1] * z[c + 1], acc1);
     }
   }
+  sq[threadIdx.x] = acc0 + acc1;
   __syncthreads();
-  if (has_row) {
-    double s0 = 0.0, s1 = 0.0;
-#pragma unroll
-    for (int k = 0; k < NB; k += 2) {
-      s0 = __builtin_fma(l[k], xs[k], s0);
-      s1 = __builtin_fma(l[k + 1], xs[k + 1], s1);
-    }
-    z[r] -= s0 + s1;
-  }
+  if (q == 0 && r < nA) xpart[(size_t)blockIdx.y * nA + r] = (sq[rl] + sq[64 + rl]) + (sq[128 + rl] + sq[192 + rl]);
 }
 
 // un-permute, q1 = 0.5 dx.(u D dx - g)    (bavoxel.hpp:1127)
@@ -325,7 +311,9 @@ __global__ __launch_bounds__(1024) void k_ldl_finish(const double *__restrict__ 
   for (int r = tid; r < nA; r += 1024) {
     const int p = perm[r];
     if (p < n) {
-      const double xv = x[r];
+      double xv = 0.0;
+#pragma unroll
+      for (int k = 0; k < APPLY_CHUNKS; k++) xv += x[(size_t)k * nA + r];       // partial products of k_ldl_apply
       dx[p] = xv;
       q += xv * (u * H[(size_t)p * n + p] * xv - g[p]);
     }
@@ -346,7 +334,7 @@ void launch_solve(balm_ctx *c, double u, bool new_hessian) {
     hipLaunchKernelGGL(k_rank_diag, dim3((nA + 63) / 64), dim3(256), (size_t)nA * sizeof(double) + 256 * sizeof(int),
                        s, c->d_H, n, nA, c->d_perm);
   {
-    long total = (long)(nA + NB) * nA;
+    long total = (long)(2 * nA + NB) * nA;
     int grid = (int)((total + 255) / 256);
     if (grid > 4096) grid = 4096;
     hipLaunchKernelGGL(k_build_A, dim3(grid), dim3(256), 0, s, c->d_H, c->d_g, n, nA, c->d_perm, u, c->d_A);
@@ -355,19 +343,16 @@ void launch_solve(balm_ctx *c, double u, bool new_hessian) {
   for (int p = 0; p < P; p++) {
     const int c0 = p * NB;
     const int m = nA - c0 - NB;                 // square part still to factor
-    const int rows = m + NB;                    // + right-hand side tile
-    hipLaunchKernelGGL(k_ldl_panel, dim3((rows + PANEL_ROWS - 1) / PANEL_ROWS), dim3(256), 0, s, c->d_A, nA, c0,
+    const int nR = nA + NB + NB * (p + 1);      // live rows: + right-hand side tile + identity tiles 0..p
+    const int rows = nR - (c0 + NB);
+    hipLaunchKernelGGL(k_ldl_panel, dim3((rows + PANEL_ROWS - 1) / PANEL_ROWS), dim3(256), 0, s, c->d_A, nA, c0, nR,
                        c->d_dvec, c->d_Wp, c->d_z);
     if (m > 0) {
       const int mt = m / NB;
-      hipLaunchKernelGGL(k_ldl_trail, dim3((3 * mt + 3) / 4, mt + 1), dim3(256), 0, s, c->d_A, nA, c0, c->d_Wp, mt);
+      hipLaunchKernelGGL(k_ldl_trail, dim3((3 * mt + 3) / 4, mt + 1 + (p + 1)), dim3(256), 0, s, c->d_A, nA, c0, c->d_Wp, mt);
     }
   }
-  for (int p = P - 1; p >= 0; p--) {
-    const int c0 = p * NB;
-    hipLaunchKernelGGL(k_ldl_back_panel, dim3(c0 > 0 ? (c0 + 255) / 256 : 1), dim3(256), 0, s, c->d_A, nA, c0, c->d_z,
-                       c->d_x);
-  }
+  hipLaunchKernelGGL(k_ldl_apply, dim3((nA + 63) / 64, APPLY_CHUNKS), dim3(256), 0, s, c->d_A, nA, c->d_dvec, c->d_z, c->d_x);
   hipLaunchKernelGGL(k_ldl_finish, dim3(1), dim3(1024), 0, s, c->d_x, nA, n, c->d_perm, c->d_H, c->d_g, u, c->d_dx,
                      c->d_scal);
 }
