@@ -494,12 +494,12 @@ int balm_pose_covariance(balm_ctx *ctx, const double *poses, const double *clust
   if ((rc = ensure(ctx, &ctx->d_part, &ctx->cap_part, (size_t)plan.SG * tiles))) return rc;
   const int nblk = cov_factors_grid(W, F);
   if ((rc = ensure(ctx, &ctx->d_dpart, &ctx->cap_dpart, (size_t)nblk * DACC_MAX * W))) return rc;
-  // scratch: [redX | redY | S (21 W)] (one all-reduce payload) | Rraw | tmp | Rcov | Z, Zs (nA x n each) | Linv (nA x NB)
+  // scratch: [redX | redY | S (21 W)] (one all-reduce payload) | Rraw | Rcov | T0, T1 (nA x nA each)
   const size_t pay = 2 * tiles + (size_t)21 * W, nn = (size_t)n * n;
   double *buf = nullptr, *d_cc = nullptr;
-  HIP_TRY(hipMalloc((void **)&buf, (pay + 3 * nn + 2 * (size_t)nA * n + (size_t)nA * NB) * sizeof(double)));
-  double *redx = buf, *redy = buf + tiles, *sdiag = buf + 2 * tiles, *Rraw = buf + pay, *tmp = Rraw + nn, *Rc = tmp + nn,
-         *Z = Rc + nn, *Zs = Z + (size_t)nA * n, *Linv = Zs + (size_t)nA * n;
+  HIP_TRY(hipMalloc((void **)&buf, (pay + 2 * nn + 2 * (size_t)nA * nA) * sizeof(double)));
+  double *redx = buf, *redy = buf + tiles, *sdiag = buf + 2 * tiles, *Rraw = buf + pay, *Rc = Rraw + nn,
+         *T0 = Rc + nn, *T1 = T0 + (size_t)nA * nA;
   hipError_t e = hipSuccess;
   if (cluster_cov) {
     e = hipMalloc((void **)&d_cc, (size_t)F * W * 81 * sizeof(double));
@@ -525,7 +525,7 @@ int balm_pose_covariance(balm_ctx *ctx, const double *poses, const double *clust
     launch_cov_assemble(s, redx, redy, sdiag, ctx->d_sub, ctx->ntiles, W, Rraw);
     hipMemsetAsync(ctx->d_g, 0, (size_t)n * sizeof(double), s);
     launch_solve(ctx, 0.0, true);                        // P H P^T = L D L^T stays in d_A / d_dvec / d_perm
-    launch_congruence_inverse(ctx, Rraw, Z, Zs, tmp, Linv, Rc);
+    launch_congruence_inverse(ctx, Rraw, T0, T1, Rc);
     if (Rcov) e = hipMemcpyAsync(Rcov, Rc, nn * sizeof(double), hipMemcpyDeviceToHost, s);
     if (e == hipSuccess && Rcov_raw) e = hipMemcpyAsync(Rcov_raw, Rraw, nn * sizeof(double), hipMemcpyDeviceToHost, s);
   }

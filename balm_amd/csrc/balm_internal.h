@@ -139,8 +139,7 @@ void launch_cov_reduce_tiles(hipStream_t s, const double *part, int SG, long til
 void launch_cov_reduce_dacc(hipStream_t s, const double *dpart, int nblk, int W, double *out);
 void launch_cov_assemble(hipStream_t s, const double *redx, const double *redy, const double *sdiag, const int *tileIJ,
                          int ntiles, int W, double *Rout);
-void launch_congruence_inverse(balm_ctx *c, const double *Rraw, double *Z, double *S, double *tmp, double *Linv,
-                               double *Rcov);
+void launch_congruence_inverse(balm_ctx *c, const double *Rraw, double *T0, double *T1, double *Rcov);
 
 // launchers (kernels_build.hip)
 void launch_build_clusters(hipStream_t s, const float *xyz, const int *feat_id, const int *pose_id, long n_pts,

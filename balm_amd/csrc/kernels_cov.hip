@@ -12,7 +12,7 @@
 //   k_cov_factors   one workgroup per feature, one lane per pose: X and Y columns, S partials
 //   k_hessian_syrk  (kernels_accum.hip) on X, then on Y
 //   k_cov_assemble  Rcov_raw = XX^T - YY^T + blockdiag(S)
-//   k_trsm_panel    H^-1 B for n right-hand sides through the LDL^T factor of kernels_solve.hip (applied twice)
+//   k_tri_gemm      H^-1 Rraw H^-T = M D (M^T Rraw M) D M^T with the factorisation's by-product M = L^-T D^+
 #include <cfloat>
 
 #include "balm_internal.h"
@@ -455,179 +455,77 @@ __global__ __launch_bounds__(256) void k_cov_assemble(const double *__restrict__
 }
 
 // ------------------------------------------------------------------------------------------------
-// H^-1 B for m right-hand sides through the factor P H P^T = L D L^T left in c->d_A / d_dvec / d_perm by
-// launch_solve: Z = P B, L Z' = Z (forward, panel by panel), Z'' = D^+ Z', L^T Z''' = Z'' (backward), out = P^T Z'''.
-// B is nA x m column-major with leading dimension nA.  Straightforward FP64 FMA kernels, one launch per panel and
-// direction (this stage is O(n^3) with n = 6W <= 2880, small next to the SYRKs).
+// Rcov = H^-1 Rraw H^-T without a single triangular solve: launch_solve leaves, next to L and D, the matrix
+// M = L^-T D^+ (the identity rows that ride through the factorisation, kernels_solve.hip), and
+//     (P H P^T)^-1 = L^-T D^-1 L^-1 = M D M^T ,
+// so with Rp = P Rraw P^T:   Rcov_p = M D (M^T Rp M) D M^T  -- four products with the triangular M on the
+// FP64 matrix cores (k_tri_gemm: 48 x 48 tiles, one wavefront per 16 x 48 strip, the k range cut to M's non-zero
+// part), no panel chain.  All matrices nA x nA, column-major, padded rows/columns are the identity's.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_rows_permute(const double *__restrict__ B, int n, int nA, int m,
-                                                      const int *__restrict__ perm, int inverse, double *__restrict__ out) {
-  // inverse == 0: out[r][c] = B[perm[r]][c] (B n x m, ld n; out nA x m, ld nA; padded rows zero)
-  // inverse == 1: out[perm[r]][c] = B[r][c] (B nA x m; out n x m)
-  const long total = (long)nA * m;
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+// Rp[r][c] = R[perm[r]][perm[c]] (zero where a padded index is involved); inverse: R[perm[r]][perm[c]] = Rp[r][c]
+__global__ __launch_bounds__(256) void k_sym_permute(const double *__restrict__ src, int n, int nA, const int *__restrict__ perm,
+                                                     int inverse, double *__restrict__ dst) {
+  const long total = (long)nA * nA;
   for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
     const int c = (int)(t / nA), r = (int)(t - (long)c * nA);
-    const int p = perm[r];
-    if (!inverse) out[t] = p < n ? B[(size_t)c * n + p] : 0.0;
-    else if (p < n) out[(size_t)c * n + p] = B[t];
+    const int pr = perm[r], pc = perm[c];
+    if (!inverse) dst[t] = (pr < n && pc < n) ? src[(size_t)pc * n + pr] : 0.0;
+    else if (pr < n && pc < n) dst[(size_t)pc * n + pr] = src[t];
   }
 }
 
-__global__ __launch_bounds__(256) void k_rows_scale(double *__restrict__ Z, int nA, int m, const double *__restrict__ dvec) {
-  const long total = (long)nA * m;
+__global__ __launch_bounds__(256) void k_sym_scale(double *__restrict__ T, int nA, const double *__restrict__ dvec) {
+  const long total = (long)nA * nA;
   for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
-    const int r = (int)(t % nA);
-    const double d = dvec[r];
-    Z[t] = fabs(d) > DBL_MIN ? Z[t] / d : 0.0;          // Eigen's D^+ rule (as in k_ldl_panel)
+    const int c = (int)(t / nA), r = (int)(t - (long)c * nA);
+    T[t] *= dvec[r] * dvec[c];
   }
 }
 
-__global__ __launch_bounds__(256) void k_transpose_sq(const double *__restrict__ A, int n, double *__restrict__ At) {
-  __shared__ double tile[16][17];
-  const int bx = blockIdx.x * 16, by = blockIdx.y * 16, tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-  if (bx + tx < n && by + ty < n) tile[ty][tx] = A[(size_t)(by + ty) * n + bx + tx];
-  __syncthreads();
-  if (by + tx < n && bx + ty < n) At[(size_t)(bx + ty) * n + by + tx] = tile[tx][ty];
-}
-
-// inverses of the NB x NB unit-lower-triangular diagonal blocks of L, once per factorisation: column j of the
-// inverse by forward substitution, one lane per column.  Linv[p][c][r] = (L_pp^-1)(r, c), column-major.
-__global__ __launch_bounds__(64) void k_invert_diag_blocks(const double *__restrict__ A, int ldA, double *__restrict__ Linv) {
-  __shared__ double Ls[NB][NB + 1];
-  const int c0 = blockIdx.x * NB;
-  for (int t = threadIdx.x; t < NB * NB; t += 64) {
-    const int r = t % NB, c = t / NB;
-    Ls[r][c] = r > c ? A[(size_t)(c0 + c) * ldA + c0 + r] : 0.0;
-  }
-  __syncthreads();
-  const int j = threadIdx.x;
-  if (j >= NB) return;
-  double x[NB];
+// C (nA x nA, ld nA) = A B with A(i,k) = a[i sai + k sak], B(k,j) = b[k sbk + j sbj]; one of the operands is the
+// triangular M or its transpose: tri = 1: A non-zero for k <= i, 2: B non-zero for k <= j, 3: A non-zero for
+// k >= i, 4: B non-zero for k >= j.  Workgroup = 3 waves = a 48 x 48 tile of C, wave w = rows 16 w .. 16 w + 15.
+// MFMA f64 16x16x4: A operand lane l = A(row l & 15, k + (l >> 4)), B operand lane l = B(k + (l >> 4), col l & 15),
+// C/D: col = l & 15, row = (l >> 4) + 4 reg.
+__global__ __launch_bounds__(192) void k_tri_gemm(const double *__restrict__ a, long sai, long sak, const double *__restrict__ b,
+                                                  long sbk, long sbj, int nA, int tri, double *__restrict__ C) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int i0 = blockIdx.x * NB + 16 * wv, j0 = blockIdx.y * NB;
+  int k0 = 0, k1 = nA;
+  if (tri == 1) k1 = min(nA, blockIdx.x * NB + NB);
+  else if (tri == 2) k1 = min(nA, j0 + NB);
+  else if (tri == 3) k0 = blockIdx.x * NB;
+  else if (tri == 4) k0 = j0;
+  const double *pa = a + (size_t)(i0 + (lane & 15)) * sai + (size_t)(lane >> 4) * sak;
+  const double *pb = b + (size_t)(lane >> 4) * sbk + (size_t)(j0 + (lane & 15)) * sbj;
+  d4 acc[3];
 #pragma unroll
-  for (int k = 0; k < NB; k++) x[k] = k == j ? 1.0 : 0.0;
+  for (int y = 0; y < 3; y++) acc[y] = (d4){0.0, 0.0, 0.0, 0.0};
+  for (int k = k0; k < k1; k += 16) {           // k ranges are multiples of 48: four k-steps per trip, loads first
+    double av[4], bv[4][3];
 #pragma unroll
-  for (int k = 0; k < NB; k++)
+    for (int u = 0; u < 4; u++) {
+      av[u] = pa[(size_t)(k + 4 * u) * sak];
 #pragma unroll
-    for (int i = k + 1; i < NB; i++) x[i] = __builtin_fma(-Ls[i][k], x[k], x[i]);
-  double *dst = Linv + ((size_t)blockIdx.x * NB + j) * NB;
-#pragma unroll
-  for (int k = 0; k < NB; k++) dst[k] = x[k];
-}
-
-// One launch per panel: every workgroup (64 right-hand sides x one 64-row tile of the rows still to update) first
-// solves the NB x NB unit-triangular diagonal block against its 64 columns of the panel rows -- redundantly per
-// row tile, as a product with the block's precomputed inverse (no serial substitution chain on the critical
-// path) -- then applies the rank-NB update to its tile:
-//   forward   Z[r][:] -= L[r][c0..c0+NB) X      for r >= c0 + NB        (L Z' = Z)
-//   backward  Z[r][:] -= L[c0..c0+NB)[r]^T X    for r <  c0             (L^T Z' = Z)
-// The solved panel rows X go to a second buffer S (written by the workgroups of row tile 0), so nobody reads rows
-// another workgroup is overwriting.  4 x 4 outputs per lane.
-template <int BACKWARD>
-__global__ __launch_bounds__(256) void k_trsm_panel(const double *__restrict__ A, const double *__restrict__ Linv, int ldA, int c0,
-                                                    double *__restrict__ Z, double *__restrict__ S, int nA, int m, int r_begin,
-                                                    int r_end) {
-  __shared__ double LL[NB][64 + 1];      // first the diagonal block (strictly lower part), then [k][row] multipliers of the tile
-  __shared__ double Xt[NB][64 + 1];      // [k][rhs]  panel rows of these right-hand sides
-  const int cb = blockIdx.x * 64, r0 = r_begin + blockIdx.y * 64;
-  {
-    const double *li = Linv + (size_t)(c0 / NB) * NB * NB;
-    for (int t = threadIdx.x; t < NB * NB; t += 256) {
-      const int r = t % NB, c = t / NB;           // (L_pp^-1)(r, c); the backward pass needs its transpose
-      if (!BACKWARD) LL[r][c] = li[t]; else LL[c][r] = li[t];
+      for (int y = 0; y < 3; y++) bv[u][y] = pb[(size_t)(k + 4 * u) * sbk + (size_t)(16 * y) * sbj];
     }
-  }
-  for (int t = threadIdx.x; t < NB * 64; t += 256) {
-    const int k = t % NB, cl = t / NB;
-    Xt[k][cl] = cb + cl < m ? Z[(size_t)(cb + cl) * nA + c0 + k] : 0.0;
-  }
-  const bool has_rows = r0 < r_end;
-  double lpre[NB * 64 / 256];              // this lane's multipliers, in flight during the solve
-  if (has_rows) {
-#pragma unroll
-    for (int q = 0; q < NB * 64 / 256; q++) {
-      const int t = threadIdx.x + 256 * q;
-      int k, rl;
-      if (!BACKWARD) { rl = t & 63; k = t >> 6; } else { k = t % NB; rl = t / NB; }
-      const int r = r0 + rl;
-      lpre[q] = 0.0;
-      if (r < r_end) lpre[q] = BACKWARD ? A[(size_t)r * ldA + c0 + k] : A[(size_t)(c0 + k) * ldA + r];
-    }
-  }
-  __syncthreads();
-  {
-    // X = M Xt with M = L_pp^-1 (lower) or its transpose (upper): 48 x 64 outputs, 12 per lane
-    const int cl = threadIdx.x & 63, kq = threadIdx.x >> 6;          // rows kq, kq + 4, ...
-    double xo[NB / 4];
-#pragma unroll
-    for (int q = 0; q < NB / 4; q++) {
-      const int r = kq + 4 * q;
-      double acc = 0.0;
-      if (!BACKWARD) { for (int k = 0; k <= r; k++) acc = __builtin_fma(LL[r][k], Xt[k][cl], acc); }
-      else { for (int k = r; k < NB; k++) acc = __builtin_fma(LL[r][k], Xt[k][cl], acc); }
-      xo[q] = acc;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int q = 0; q < NB / 4; q++) {
-      const int r = kq + 4 * q;
-      Xt[r][cl] = xo[q];
-      if (blockIdx.y == 0 && cb + cl < m) S[(size_t)(cb + cl) * nA + c0 + r] = xo[q];
-    }
-  }
-  if (!has_rows) return;
-  __syncthreads();                         // the diagonal block is no longer needed
-#pragma unroll
-  for (int q = 0; q < NB * 64 / 256; q++) {
-    const int t = threadIdx.x + 256 * q;
-    int k, rl;
-    if (!BACKWARD) { rl = t & 63; k = t >> 6; } else { k = t % NB; rl = t / NB; }
-    LL[k][rl] = lpre[q];
-  }
-  __syncthreads();
-  const int tr = (threadIdx.x & 15) * 4, tc = (threadIdx.x >> 4) * 4;
-  double acc[4][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
-#pragma unroll 4
-  for (int k = 0; k < NB; k++) {
-    double l[4], x[4];
-#pragma unroll
-    for (int u = 0; u < 4; u++) { l[u] = LL[k][tr + u]; x[u] = Xt[k][tc + u]; }
 #pragma unroll
     for (int u = 0; u < 4; u++)
 #pragma unroll
-      for (int w = 0; w < 4; w++) acc[u][w] = __builtin_fma(l[u], x[w], acc[u][w]);
+      for (int y = 0; y < 3; y++) acc[y] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u][y], acc[y], 0, 0, 0);
   }
 #pragma unroll
-  for (int w = 0; w < 4; w++)
+  for (int y = 0; y < 3; y++)
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
-      const int r = r0 + tr + u, c = cb + tc + w;
-      if (r < r_end && c < m) Z[(size_t)c * nA + r] -= acc[u][w];
-    }
+    for (int e = 0; e < 4; e++)
+      C[(size_t)(j0 + 16 * y + (lane & 15)) * nA + i0 + (lane >> 4) + 4 * e] = acc[y][e];
 }
 
 inline int grid1(long total, int bs, int cap) {
   long g = (total + bs - 1) / bs;
   return (int)(g > cap ? cap : (g < 1 ? 1 : g));
-}
-
-// out (n x m, ld n) = H^-1 B (n x m, ld n); Z, S = nA x m scratch each
-void solve_multi(balm_ctx *c, const double *Linv, const double *B, int m, double *Z, double *S, double *out) {
-  hipStream_t s = c->stream;
-  const int n = c->n, nA = c->nA, ldA = 2 * nA + NB, P = nA / NB;
-  const unsigned gx = (unsigned)((m + 63) / 64);
-  hipLaunchKernelGGL(k_rows_permute, dim3(grid1((long)nA * m, 256, 4096)), dim3(256), 0, s, B, n, nA, m, c->d_perm, 0, Z);
-  for (int p = 0; p < P; p++) {                 // forward: work in Z, solved rows into S
-    const int c0 = p * NB, rows = nA - c0 - NB;
-    hipLaunchKernelGGL(k_trsm_panel<0>, dim3(gx, rows > 0 ? (rows + 63) / 64 : 1), dim3(256), 0, s, c->d_A, Linv, ldA, c0, Z, S, nA, m,
-                       c0 + NB, nA);
-  }
-  hipLaunchKernelGGL(k_rows_scale, dim3(grid1((long)nA * m, 256, 4096)), dim3(256), 0, s, S, nA, m, c->d_dvec);
-  for (int p = P - 1; p >= 0; p--) {            // backward: work in S, solved rows into Z
-    const int c0 = p * NB;
-    hipLaunchKernelGGL(k_trsm_panel<1>, dim3(gx, c0 > 0 ? (c0 + 63) / 64 : 1), dim3(256), 0, s, c->d_A, Linv, ldA, c0, S, Z, nA, m, 0,
-                       c0);
-  }
-  hipLaunchKernelGGL(k_rows_permute, dim3(grid1((long)nA * m, 256, 4096)), dim3(256), 0, s, Z, n, nA, m, c->d_perm, 1, out);
 }
 
 }  // namespace
@@ -670,15 +568,22 @@ void launch_cov_assemble(hipStream_t s, const double *redx, const double *redy, 
                      tileIJ, ntiles, W, Rout);
 }
 
-// Rcov (n x n) = H^-1 Rraw H^-T, H factored in the context by launch_solve; Z, S (nA x n each), tmp (n x n) and
-// Linv (nA x NB) scratch
-void launch_congruence_inverse(balm_ctx *c, const double *Rraw, double *Z, double *S, double *tmp, double *Linv, double *Rcov) {
+// Rcov (n x n) = H^-1 Rraw H^-T, H factored in the context by launch_solve (L, D and M = L^-T D^+ in d_A / d_dvec);
+// T0, T1 = nA x nA scratch each
+void launch_congruence_inverse(balm_ctx *c, const double *Rraw, double *T0, double *T1, double *Rcov) {
+  hipStream_t s = c->stream;
   const int n = c->n, nA = c->nA;
-  hipLaunchKernelGGL(k_invert_diag_blocks, dim3(nA / NB), dim3(64), 0, c->stream, c->d_A, 2 * nA + NB, Linv);
-  solve_multi(c, Linv, Rraw, n, Z, S, tmp);              // M1 = H^-1 Rraw
-  hipLaunchKernelGGL(k_transpose_sq, dim3((n + 15) / 16, (n + 15) / 16), dim3(256), 0, c->stream, tmp, n, Rcov);
-  solve_multi(c, Linv, Rcov, n, Z, S, tmp);              // H^-1 M1^T = H^-1 Rraw H^-T  (symmetric)
-  hipMemcpyAsync(Rcov, tmp, (size_t)n * n * sizeof(double), hipMemcpyDeviceToDevice, c->stream);
+  const long ldA = 2L * nA + NB;
+  const double *M = c->d_A + (size_t)(nA + NB);           // M(r, c) = M[r + c ldA]
+  const dim3 grid(nA / NB, nA / NB), blk(192);
+  const int g1 = grid1((long)nA * nA, 256, 4096);
+  hipLaunchKernelGGL(k_sym_permute, dim3(g1), dim3(256), 0, s, Rraw, n, nA, c->d_perm, 0, T0);                    // Rp
+  hipLaunchKernelGGL(k_tri_gemm, grid, blk, 0, s, M, ldA, 1L, T0, 1L, (long)nA, nA, 1, T1);                       // M^T Rp
+  hipLaunchKernelGGL(k_tri_gemm, grid, blk, 0, s, T1, 1L, (long)nA, M, 1L, ldA, nA, 2, T0);                       // (M^T Rp) M
+  hipLaunchKernelGGL(k_sym_scale, dim3(g1), dim3(256), 0, s, T0, nA, c->d_dvec);                                  // D . D
+  hipLaunchKernelGGL(k_tri_gemm, grid, blk, 0, s, M, 1L, ldA, T0, 1L, (long)nA, nA, 3, T1);                       // M (.)
+  hipLaunchKernelGGL(k_tri_gemm, grid, blk, 0, s, T1, 1L, (long)nA, M, ldA, 1L, nA, 4, T0);                       // (.) M^T
+  hipLaunchKernelGGL(k_sym_permute, dim3(g1), dim3(256), 0, s, T0, n, nA, c->d_perm, 1, Rcov);
 }
 
 }  // namespace balm
