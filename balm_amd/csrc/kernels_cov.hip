@@ -41,24 +41,20 @@ __device__ __forceinline__ void g1_top(const double w[4], double g[3][9]) {
   g[2][2] = w[0]; g[2][4] = w[1]; g[2][5] = w[2]; g[2][8] = w[3];
 }
 
-// c_cov of PointCluster::push with p_cov = sigma^2 I (toolss.hpp:321-345) from the cluster's own moments:
-// sum_k Bf Bf^T is linear in (P, v, N)
-__device__ __forceinline__ void noise_cov_isotropic(const double P[6], const double v[3], double N, double s2,
-                                                    double c[9][9]) {
-#pragma unroll
-  for (int r = 0; r < 9; r++)
-#pragma unroll
-    for (int k = 0; k < 9; k++) c[r][k] = 0.0;
-  const double xx = P[0], xy = P[1], xz = P[2], yy = P[3], yz = P[4], zz = P[5], x = v[0], y = v[1], z = v[2];
-#define BALM_SET(r, k, val) c[r][k] = c[k][r] = s2 * (val)
-  BALM_SET(0, 0, 4 * xx); BALM_SET(0, 1, 2 * xy); BALM_SET(0, 2, 2 * xz); BALM_SET(0, 6, 2 * x);
-  BALM_SET(1, 1, yy + xx); BALM_SET(1, 2, yz); BALM_SET(1, 3, 2 * xy); BALM_SET(1, 4, xz); BALM_SET(1, 6, y); BALM_SET(1, 7, x);
-  BALM_SET(2, 2, zz + xx); BALM_SET(2, 4, xy); BALM_SET(2, 5, 2 * xz); BALM_SET(2, 6, z); BALM_SET(2, 8, x);
-  BALM_SET(3, 3, 4 * yy); BALM_SET(3, 4, 2 * yz); BALM_SET(3, 7, 2 * y);
-  BALM_SET(4, 4, zz + yy); BALM_SET(4, 5, 2 * yz); BALM_SET(4, 7, z); BALM_SET(4, 8, y);
-  BALM_SET(5, 5, 4 * zz); BALM_SET(5, 8, 2 * z);
-  BALM_SET(6, 6, N); BALM_SET(7, 7, N); BALM_SET(8, 8, N);
-#undef BALM_SET
+// y = c_cov x for the c_cov that PointCluster::push accumulates with p_cov = sigma^2 I (toolss.hpp:321-345):
+// sum_k Bf Bf^T is linear in the cluster's own moments (P, v, N) and has 45 non-zeros -- no 9x9 matrix is formed
+__device__ __forceinline__ void iso_cov_mv(const double P[6], const double v[3], double N, double s2, const double x[9],
+                                           double y[9]) {
+  const double xx = P[0], xy = P[1], xz = P[2], yy = P[3], yz = P[4], zz = P[5], vx = v[0], vy = v[1], vz = v[2];
+  y[0] = s2 * (4 * xx * x[0] + 2 * xy * x[1] + 2 * xz * x[2] + 2 * vx * x[6]);
+  y[1] = s2 * (2 * xy * x[0] + (yy + xx) * x[1] + yz * x[2] + 2 * xy * x[3] + xz * x[4] + vy * x[6] + vx * x[7]);
+  y[2] = s2 * (2 * xz * x[0] + yz * x[1] + (zz + xx) * x[2] + xy * x[4] + 2 * xz * x[5] + vz * x[6] + vx * x[8]);
+  y[3] = s2 * (2 * xy * x[1] + 4 * yy * x[3] + 2 * yz * x[4] + 2 * vy * x[7]);
+  y[4] = s2 * (xz * x[1] + xy * x[2] + 2 * yz * x[3] + (zz + yy) * x[4] + 2 * yz * x[5] + vz * x[7] + vy * x[8]);
+  y[5] = s2 * (2 * xz * x[2] + 2 * yz * x[4] + 4 * zz * x[5] + 2 * vz * x[8]);
+  y[6] = s2 * (2 * vx * x[0] + vy * x[1] + vz * x[2] + N * x[6]);
+  y[7] = s2 * (vx * x[1] + 2 * vy * x[3] + vz * x[4] + N * x[7]);
+  y[8] = s2 * (vx * x[2] + vy * x[4] + 2 * vz * x[5] + N * x[8]);
 }
 
 constexpr int COV_DACC = 21;      // upper triangle of the 6x6 block S_j, row-major
@@ -68,6 +64,7 @@ constexpr int COV_DACC = 21;      // upper triangle of the 6x6 block S_j, row-ma
 // pose's At / Rr rows (parked in the X / Y columns), its share of Q and of S_j; after the block-wide sum of Q
 // every lane factors the 3x3 Q redundantly and turns its own rows into X and Y.
 // ------------------------------------------------------------------------------------------------
+template <bool EXPLICIT>
 __global__ __launch_bounds__(256) void k_cov_factors(const double *__restrict__ cl, const double *__restrict__ ccov,
                                                      double sigma2, const double *__restrict__ poses,
                                                      const double *__restrict__ feat, int W, int npad, int F,
@@ -212,28 +209,40 @@ __global__ __launch_bounds__(256) void k_cov_factors(const double *__restrict__ 
               Y[r][c] = y;
             }
         }
-        // the cluster's 9x9 noise covariance
-        double cc[9][9];
-        if (ccov) {
+        // products with the cluster's 9x9 noise covariance (symmetric): explicit matrix, or the isotropic closed form
+        double cc[EXPLICIT ? 9 : 1][9];
+        if (EXPLICIT) {
           const double *src = ccov + ((size_t)a * W + i) * 81;
 #pragma unroll
           for (int r = 0; r < 9; r++)
 #pragma unroll
-            for (int k = 0; k < 9; k++) cc[r][k] = src[9 * r + k];
-        } else {
-          noise_cov_isotropic(P, v, N, sigma2, cc);
+            for (int k = 0; k < 9; k++) cc[EXPLICIT ? r : 0][k] = src[9 * r + k];
         }
-        double sg[9][3];                       // c_cov Gm^T  (Gm row 2 = [0 0 0 0 0 0 r3])
+        auto covmv = [&](const double x[9], double y[9]) {
+          if (EXPLICIT) {
 #pragma unroll
-        for (int r = 0; r < 9; r++) {
+            for (int r = 0; r < 9; r++) {
+              double t = 0.0;
 #pragma unroll
-          for (int k = 0; k < 2; k++) {
-            double s = 0.0;
-#pragma unroll
-            for (int c = 0; c < 9; c++) s += cc[r][c] * gm[k][c];
-            sg[r][k] = s;
+              for (int c = 0; c < 9; c++) t += cc[EXPLICIT ? r : 0][c] * x[c];
+              y[r] = t;
+            }
+          } else {
+            iso_cov_mv(P, v, N, sigma2, x, y);
           }
-          sg[r][2] = cc[r][6] * r3[0] + cc[r][7] * r3[1] + cc[r][8] * r3[2];
+        };
+        double sg[9][3];                       // c_cov Gm^T  (Gm row 2 = [0 0 0 0 0 0 r3])
+        {
+          double col[9];
+          covmv(gm[0], col);
+#pragma unroll
+          for (int r = 0; r < 9; r++) sg[r][0] = col[r];
+          covmv(gm[1], col);
+#pragma unroll
+          for (int r = 0; r < 9; r++) sg[r][1] = col[r];
+          covmv(gm[2], col);
+#pragma unroll
+          for (int r = 0; r < 9; r++) sg[r][2] = col[r];
         }
         {
           int t = 0;
@@ -269,17 +278,11 @@ __global__ __launch_bounds__(256) void k_cov_factors(const double *__restrict__ 
           double M[4][4];
 #pragma unroll
           for (int r = 0; r < 4; r++) {
-            double e[9];                       // row r of Y4 c_cov
+            double e[9];                       // row r of Y4 c_cov (c_cov symmetric; row 3 of Y4 is Gm's row 2)
+            if (r < 3) covmv(Y[r], e);
+            else {
 #pragma unroll
-            for (int c = 0; c < 9; c++) {
-              double sacc_ = 0.0;
-              if (r < 3) {
-#pragma unroll
-                for (int k = 0; k < 9; k++) sacc_ += Y[r][k] * cc[k][c];
-              } else {
-                sacc_ = r3[0] * cc[6][c] + r3[1] * cc[7][c] + r3[2] * cc[8][c];
-              }
-              e[c] = sacc_;
+              for (int c = 0; c < 9; c++) e[c] = sg[c][2];
             }
 #pragma unroll
             for (int k = r; k < 4; k++) {
@@ -548,10 +551,14 @@ void launch_cov_factors(hipStream_t s, const double *cl, const double *ccov, dou
   int bs = W <= 64 ? 64 : (W <= 128 ? 128 : 256);
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute((const void *)k_cov_factors, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);   // + static sq
+    hipFuncSetAttribute((const void *)k_cov_factors<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);   // + static sq
+    hipFuncSetAttribute((const void *)k_cov_factors<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL(k_cov_factors, dim3(nblk), dim3(bs), lds, s, cl, ccov, sigma2, poses, feat, W, npad, F, Gx, Gy, dpart);
+  if (ccov)
+    hipLaunchKernelGGL(k_cov_factors<true>, dim3(nblk), dim3(bs), lds, s, cl, ccov, sigma2, poses, feat, W, npad, F, Gx, Gy, dpart);
+  else
+    hipLaunchKernelGGL(k_cov_factors<false>, dim3(nblk), dim3(bs), lds, s, cl, ccov, sigma2, poses, feat, W, npad, F, Gx, Gy, dpart);
 }
 
 void launch_cov_reduce_tiles(hipStream_t s, const double *part, int SG, long tile_total, double *red) {
