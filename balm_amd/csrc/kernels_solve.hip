@@ -26,7 +26,8 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 
 // ------------------------------------------------------------------------------------------------
 // permutation by decreasing |diag H| (ties by index); padded positions (>= n) go last.
-// 64 ranks per workgroup, the j-range split over the four waves.
+// 16 ranks per workgroup, the j-range split sixteen ways (the kernel is on the critical path of every solve and
+// has no other parallelism to offer: nA / 16 workgroups instead of nA / 64).
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_rank_diag(const double *__restrict__ H, int n, int nA,
                                                    int *__restrict__ perm) {
@@ -34,12 +35,12 @@ __global__ __launch_bounds__(256) void k_rank_diag(const double *__restrict__ H,
   int *part = reinterpret_cast<int *>(dabs + nA);
   for (int i = threadIdx.x; i < nA; i += blockDim.x) dabs[i] = i < n ? fabs(H[(size_t)i * n + i]) : -1.0;
   __syncthreads();
-  const int il = threadIdx.x & 63, q = threadIdx.x >> 6;
-  const int i = blockIdx.x * 64 + il;
+  const int il = threadIdx.x & 15, q = threadIdx.x >> 4;
+  const int i = blockIdx.x * 16 + il;
   int rank = 0;
   if (i < nA) {
     const double di = dabs[i];
-    const int chunk = (nA + 3) / 4;
+    const int chunk = (nA + 15) / 16;
     const int j0 = q * chunk, j1 = min(nA, j0 + chunk);
     for (int j = j0; j < j1; j++) {
       const double dj = dabs[j];
@@ -49,7 +50,9 @@ __global__ __launch_bounds__(256) void k_rank_diag(const double *__restrict__ H,
   part[threadIdx.x] = rank;
   __syncthreads();
   if (q == 0 && i < nA) {
-    rank = part[il] + part[64 + il] + part[128 + il] + part[192 + il];
+    rank = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) rank += part[16 * k + il];
     if (dabs[i] != dabs[i]) rank = i;   // NaN: keep it somewhere valid; the solve is garbage anyway
     perm[rank] = i;
   }
@@ -331,7 +334,7 @@ void launch_solve(balm_ctx *c, double u, bool new_hessian) {
   hipStream_t s = c->stream;
   const int n = c->n, nA = c->nA;
   if (new_hessian)
-    hipLaunchKernelGGL(k_rank_diag, dim3((nA + 63) / 64), dim3(256), (size_t)nA * sizeof(double) + 256 * sizeof(int),
+    hipLaunchKernelGGL(k_rank_diag, dim3((nA + 15) / 16), dim3(256), (size_t)nA * sizeof(double) + 256 * sizeof(int),
                        s, c->d_H, n, nA, c->d_perm);
   {
     long total = (long)(2 * nA + NB) * nA;
