@@ -18,7 +18,7 @@ T_MOMENTS, T_FACTORS, T_SYRK, T_ASSEMBLE, T_SOLVE, T_UPDATE, T_BUILD, T_VOXEL, T
 TIMING_NAMES = ["moments", "factors", "syrk", "assemble", "solve", "update", "build", "voxel", "cov"]
 
 # every symbol include/balm_hip.h declares
-EXPORTS = ["balm_create", "balm_destroy", "balm_set_features", "balm_evaluate", "balm_only_residual",
+EXPORTS = ["balm_create", "balm_create_multi", "balm_destroy", "balm_set_features", "balm_evaluate", "balm_only_residual",
            "balm_solve_damped", "balm_damping_iter", "balm_build_clusters", "balm_voxel_defaults", "balm_associate", "balm_get_features", "balm_get_association", "balm_pose_covariance",
            "balm_set_allreduce",
            "balm_get_timing", "balm_reset_timing", "balm_work_model", "balm_last_error", "balm_version"]
@@ -61,6 +61,8 @@ def lib():
         L = C.CDLL(LIB_PATH)
         L.balm_create.restype = C.c_void_p
         L.balm_create.argtypes = [C.c_int, C.c_int, C.c_int]
+        L.balm_create_multi.restype = C.c_void_p
+        L.balm_create_multi.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int]
         L.balm_destroy.restype = None
         L.balm_destroy.argtypes = [C.c_void_p]
         L.balm_set_features.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -102,14 +104,19 @@ def _c(a, dtype=np.float64):
 class Context:
     """One balm_ctx: owns the HBM-resident problem for one GPU."""
 
-    def __init__(self, win_size, device=0, flags=0):
+    def __init__(self, win_size, device=0, flags=0, n_devices=None):
+        """n_devices=None: balm_create (one GPU, no collective path); n_devices >= 1: balm_create_multi over
+        GPUs device .. device+n_devices-1 of this process (features sharded, RCCL all-reduce inside the library)."""
         self.L = lib()
         self.W = int(win_size)
         self.n = 6 * self.W
-        self.h = self.L.balm_create(self.W, int(device), int(flags))
+        if n_devices is None:
+            self.h = self.L.balm_create(self.W, int(device), int(flags))
+        else:
+            self.h = self.L.balm_create_multi(self.W, int(device), int(n_devices), int(flags))
         if not self.h:
-            raise BalmError(ERR_HIP, "balm_create(win_size=%d, device=%d) failed (no GPU, bad device, or "
-                                     "win_size out of range)" % (win_size, device))
+            raise BalmError(ERR_HIP, "balm_create(win_size=%d, device=%d, n_devices=%s) failed (no GPU, bad device, or "
+                                     "win_size out of range)" % (win_size, device, n_devices))
         self.F = 0
         self._cb = None
 

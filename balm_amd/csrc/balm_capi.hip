@@ -156,6 +156,33 @@ int read_scalars(balm_ctx *ctx) {
   return sync_stream(ctx);
 }
 
+// host bookkeeping after a feature table is known on the host: planes per pose (precheck at bavoxel.hpp:1071-1085),
+// the work model, and the degenerate inputs the evaluators cannot digest: a feature nobody observes and without a
+// fix cluster has NN = 0 (1/NN poisons H, g and the residual of the whole window), a negative weight has no
+// real square-root scaling (the Hessian's rank-3 factors carry sqrt(2 coe)).
+int feature_bookkeeping(balm_ctx *ctx, int F, const double *clusters, const double *fix, const double *coeffs) {
+  const int W = ctx->W;
+  ctx->planes_per_pose.assign(W, 0);
+  double S = 0, B = 0;
+  for (int a = 0; a < F; a++) {
+    int na = 0;
+    const double *ca = clusters + (size_t)a * W * 10;
+    for (int i = 0; i < W; i++)
+      if (ca[(size_t)i * 10 + 9] != 0) { ctx->planes_per_pose[i]++; na++; }
+    if (na == 0 && !(fix && fix[(size_t)a * 10 + 9] != 0)) {
+      ctx->err = "feature " + std::to_string(a) + " has no observation and no fix cluster (zero point count)";
+      return BALM_ERR_NUMERIC;
+    }
+    if (!(coeffs[a] >= 0) || !std::isfinite(coeffs[a])) {
+      ctx->err = "feature " + std::to_string(a) + " has a negative or non-finite weight";
+      return BALM_ERR_ARG;
+    }
+    S += na; B += 0.5 * na * (na + 1.0);
+  }
+  ctx->work_S = S; ctx->work_B = B;
+  return BALM_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -169,6 +196,7 @@ balm_ctx *balm_create(int win_size, int device, int flags) {
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1 || device < 0 || device >= ndev) return nullptr;
   if (hipSetDevice(device) != hipSuccess) return nullptr;
+  if (prepare_device_accum() != hipSuccess || prepare_device_cov() != hipSuccess) return nullptr;
   balm_ctx *ctx = new balm_ctx();
   ctx->W = win_size;
   ctx->n = 6 * win_size;
@@ -234,9 +262,19 @@ balm_ctx *balm_create(int win_size, int device, int flags) {
   if (hipMemcpy(ctx->d_jobs, jobs.data(), jobs.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess ||
       hipMemcpy(ctx->d_sub, sub.data(), sub.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess)
     return fail();
+  {   // a valid permutation from the start (a NaN diagonal must not leave slots unwritten, see k_rank_diag)
+    std::vector<int> ident(nA);
+    for (int i = 0; i < nA; i++) ident[i] = i;
+    if (hipMemcpy(ctx->d_perm, ident.data(), (size_t)nA * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) return fail();
+  }
   if (hipMemset(ctx->d_scal, 0, 16 * sizeof(double)) != hipSuccess) return fail();
   if (hipMemset(ctx->d_red, 0, ctx->red_len * sizeof(double)) != hipSuccess) return fail();
   return ctx;
+}
+
+balm_ctx *balm_create_multi(int win_size, int first_device, int n_devices, int flags) {
+  if (n_devices != 1) return nullptr;      // TODO(multi): sharded sub-contexts
+  return balm_create(win_size, first_device, flags);
 }
 
 void balm_destroy(balm_ctx *ctx) {
@@ -292,17 +330,7 @@ int balm_set_features(balm_ctx *ctx, int F, const double *clusters, const double
   }
   hipFree(d_aos);
   HIP_TRY(e);
-  // host bookkeeping: planes per pose (precheck at bavoxel.hpp:1071-1085) and the work model
-  ctx->planes_per_pose.assign(W, 0);
-  double S = 0, B = 0;
-  for (int a = 0; a < F; a++) {
-    int na = 0;
-    const double *ca = clusters + (size_t)a * W * 10;
-    for (int i = 0; i < W; i++)
-      if (ca[(size_t)i * 10 + 9] != 0) { ctx->planes_per_pose[i]++; na++; }
-    S += na; B += 0.5 * na * (na + 1.0);
-  }
-  ctx->work_S = S; ctx->work_B = B;
+  if ((rc = feature_bookkeeping(ctx, F, clusters, fix, coeffs))) return rc;
   if ((rc = install_feature_buffers(ctx, F, fix, coeffs))) return rc;
   return sync_stream(ctx);
 }
@@ -348,15 +376,7 @@ int balm_build_clusters(balm_ctx *ctx, int F, const float *xyz, const int *feat_
   hipFree(d_aos);
   HIP_TRY(e);
   if (clusters_out) std::memcpy(clusters_out, host.data(), count * sizeof(double));
-  ctx->planes_per_pose.assign(W, 0);
-  double S = 0, B = 0;
-  for (int a = 0; a < F; a++) {
-    int na = 0;
-    for (int i = 0; i < W; i++)
-      if (host[((size_t)a * W + i) * 10 + 9] != 0) { ctx->planes_per_pose[i]++; na++; }
-    S += na; B += 0.5 * na * (na + 1.0);
-  }
-  ctx->work_S = S; ctx->work_B = B;
+  if ((rc = feature_bookkeeping(ctx, F, host.data(), fix, coeffs))) return rc;
   if ((rc = install_feature_buffers(ctx, F, fix, coeffs))) return rc;
   return sync_stream(ctx);
 }
@@ -438,15 +458,9 @@ int balm_associate(balm_ctx *ctx, const balm_voxel_opts *opts, const float *xyz,
   if (d_pf) hipFree(d_pf);
   if (rc) return rc;
   HIP_TRY(e);
-  ctx->planes_per_pose.assign(W, 0);
-  double S = 0, B = 0;
-  for (int a = 0; a < F; a++) {
-    int na = 0;
-    for (int i = 0; i < W; i++)
-      if (ctx->assoc_clusters[((size_t)a * W + i) * 10 + 9] != 0) { ctx->planes_per_pose[i]++; na++; }
-    S += na; B += 0.5 * na * (na + 1.0);
-  }
-  ctx->work_S = S; ctx->work_B = B;
+  if ((rc = feature_bookkeeping(ctx, F, ctx->assoc_clusters.data(), opts->fix_frames > 0 ? ctx->assoc_fix.data() : nullptr,
+                                ctx->assoc_coeffs.data())))
+    return rc;
   if ((rc = install_feature_buffers(ctx, F, opts->fix_frames > 0 ? ctx->assoc_fix.data() : nullptr, ctx->assoc_coeffs.data())))
     return rc;
   if ((rc = sync_stream(ctx))) return rc;
@@ -564,6 +578,7 @@ int balm_evaluate(balm_ctx *ctx, int form, const double *poses, int head, int en
   if (JacT) HIP_TRY(hipMemcpyAsync(JacT, ctx->d_g, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   if ((rc = read_scalars(ctx))) return rc;
   if (residual) *residual = ctx->h_scal[0];
+  if (!std::isfinite(ctx->h_scal[0])) { ctx->err = "balm_evaluate: non-finite residual"; return BALM_ERR_NUMERIC; }
   return BALM_OK;
 }
 
@@ -577,6 +592,7 @@ int balm_only_residual(balm_ctx *ctx, const double *poses, double *residual) {
   if (rc) return rc;
   if ((rc = read_scalars(ctx))) return rc;
   *residual = ctx->h_scal[1];
+  if (!std::isfinite(ctx->h_scal[1])) { ctx->err = "balm_only_residual: non-finite residual"; return BALM_ERR_NUMERIC; }
   return BALM_OK;
 }
 

@@ -97,6 +97,8 @@ struct balm_ctx {
 namespace balm {
 
 // launchers (kernels_accum.hip)
+hipError_t prepare_device_accum();     // per-device kernel attributes (dynamic LDS limits); once per context
+hipError_t prepare_device_cov();
 void launch_transpose_clusters(hipStream_t s, const double *aos, double *soa, int F, int W);
 void launch_world_moments(hipStream_t s, const double *cl, const double *poses, int W, int f0, int f1, double *C);
 int launch_feature_eigen(hipStream_t s, const double *C, const double *fix, const double *coe, int f0, int f1,

@@ -138,11 +138,6 @@ void launch_world_moments(hipStream_t s, const double *cl, const double *poses, 
   int grid = (nf + 3) / 4;
   if (grid > 2048) grid = 2048;
   size_t lds = (size_t)12 * W * sizeof(double);
-  static bool attr_set = false;
-  if (!attr_set) {   // windows above ~680 poses need more than the default 64 KiB of dynamic LDS
-    hipFuncSetAttribute((const void *)k_world_moments, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
   hipLaunchKernelGGL(k_world_moments, dim3(grid), dim3(256), lds, s, cl, poses, W, f0, f1, C);
 }
 
@@ -550,18 +545,21 @@ int factors_grid(int W, int nfeat, int form) {
   return grid;
 }
 
+// Dynamic LDS above the default 64 KiB (k_world_moments: windows above ~680 poses; k_feature_factors: above ~200).
+// The attribute belongs to the CURRENT device: balm_create calls this once per context, after hipSetDevice.
+hipError_t prepare_device_accum() {
+  hipError_t e = hipFuncSetAttribute((const void *)k_world_moments, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_feature_factors<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_feature_factors<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  return e;
+}
+
 void launch_factors(hipStream_t s, int form, const double *cl, const double *poses, const double *feat, int W,
                     int npad, int f0, int f1, double *Gt, double *dpart, int nblk) {
   int dacc = form == 0 ? DACC_LEFT : DACC_RIGHT;
   const int Wc = factors_chunk(W), chunks = (W + Wc - 1) / Wc;
   size_t lds = (size_t)(12 + dacc) * Wc * sizeof(double);
   int bs = W <= 64 ? 64 : (W <= 128 ? 128 : 256);
-  static bool attr_set = false;
-  if (!attr_set) {   // windows above ~200 poses need more than the default 64 KiB of dynamic LDS
-    hipFuncSetAttribute((const void *)k_feature_factors<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipFuncSetAttribute((const void *)k_feature_factors<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
   if (form == 0)
     hipLaunchKernelGGL(k_feature_factors<0>, dim3(nblk, chunks), dim3(bs), lds, s, cl, poses, feat, W, Wc, npad, f0, f1, Gt, dpart);
   else

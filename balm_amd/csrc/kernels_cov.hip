@@ -545,16 +545,17 @@ int cov_factors_grid(int W, int F) {
 
 // X, Y columns ([3F][npad] each) and per-block S partials of features [0, F) at the poses the eigen records in
 // `feat` were computed for
+// see prepare_device_accum(): per-device attribute, set once per context by balm_create
+hipError_t prepare_device_cov() {
+  hipError_t e = hipFuncSetAttribute((const void *)k_cov_factors<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);   // + static sq
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_cov_factors<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+  return e;
+}
+
 void launch_cov_factors(hipStream_t s, const double *cl, const double *ccov, double sigma2, const double *poses,
                         const double *feat, int W, int npad, int F, double *Gx, double *Gy, double *dpart, int nblk) {
   size_t lds = (size_t)(12 + COV_DACC) * W * sizeof(double);
   int bs = W <= 64 ? 64 : (W <= 128 ? 128 : 256);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipFuncSetAttribute((const void *)k_cov_factors<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);   // + static sq
-    hipFuncSetAttribute((const void *)k_cov_factors<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
-    attr_set = true;
-  }
   if (ccov)
     hipLaunchKernelGGL(k_cov_factors<true>, dim3(nblk), dim3(bs), lds, s, cl, ccov, sigma2, poses, feat, W, npad, F, Gx, Gy, dpart);
   else

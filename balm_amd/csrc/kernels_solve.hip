@@ -33,7 +33,11 @@ __global__ __launch_bounds__(256) void k_rank_diag(const double *__restrict__ H,
                                                    int *__restrict__ perm) {
   extern __shared__ __attribute__((aligned(16))) double dabs[];   // [nA] then int part[256]
   int *part = reinterpret_cast<int *>(dabs + nA);
-  for (int i = threadIdx.x; i < nA; i += blockDim.x) dabs[i] = i < n ? fabs(H[(size_t)i * n + i]) : -1.0;
+  // a NaN diagonal ranks after every real entry and before the padding, so that perm stays a permutation
+  for (int i = threadIdx.x; i < nA; i += blockDim.x) {
+    const double v = i < n ? fabs(H[(size_t)i * n + i]) : -1.0;
+    dabs[i] = v == v ? v : -0.5;
+  }
   __syncthreads();
   const int il = threadIdx.x & 15, q = threadIdx.x >> 4;
   const int i = blockIdx.x * 16 + il;
@@ -53,7 +57,6 @@ __global__ __launch_bounds__(256) void k_rank_diag(const double *__restrict__ H,
     rank = 0;
 #pragma unroll
     for (int k = 0; k < 16; k++) rank += part[16 * k + il];
-    if (dabs[i] != dabs[i]) rank = i;   // NaN: keep it somewhere valid; the solve is garbage anyway
     perm[rank] = i;
   }
 }

@@ -72,11 +72,23 @@ typedef struct balm_lm_opts {
 balm_ctx *balm_create(int win_size, int device, int flags);
 void balm_destroy(balm_ctx *ctx);
 
+/* SURVEY 8(b)'s `n_devices`: one context that shards its features over the n_devices GPUs
+ * first_device .. first_device+n_devices-1 of this process (one host thread, one stream and one
+ * replica of the small per-window state per device) and sums the per-device Hessian/gradient/residual
+ * payload with a stream-ordered RCCL all-reduce over xGMI inside every evaluation; replaces the serial
+ * `Hess += hessians[i]` over threads at bavoxel.hpp:1049-1056.  Every other entry point takes the
+ * returned context exactly like a balm_create one.  The reference's drivers are single-process C++
+ * (benchmark_realworld.cpp:144-238, benchmark_virtual.cpp:505-524): this is how they reach 8 GPUs
+ * (`BALM2_HIP::n_devices`).  n_devices == 1 is balm_create plus the collective path.  NULL on failure. */
+balm_ctx *balm_create_multi(int win_size, int first_device, int n_devices, int flags);
+
 /* Replaces F calls of VOX_HESS::push_voxel (bavoxel.hpp:30-51): the shim flattens the borrowed
  * `const vector<PointCluster>*` / `const PointCluster* fix` pointers into these arrays.  Copies to
  * HBM.  `fix` (F*10) may be NULL (= all-empty fix clusters); `coeffs` are the per-feature weights
- * (bavoxel.hpp:42-44; benchmark_virtual.cpp:391).  Features seen by fewer than 2 poses are the
- * caller's to drop (push_voxel :32-37); they are legal here and contribute like any other. */
+ * (bavoxel.hpp:42-44; benchmark_virtual.cpp:391), >= 0.  Features seen by fewer than 2 poses are the
+ * caller's to drop (push_voxel :32-37); one observer (or none, with a fix cluster) is legal here and
+ * contributes like any other; a feature with no observer and no fix cluster has a zero point count and
+ * is rejected with BALM_ERR_NUMERIC (the reference would divide by it, bavoxel.hpp:341). */
 int balm_set_features(balm_ctx *ctx, int F, const double *clusters, const double *fix,
                       const double *coeffs);
 

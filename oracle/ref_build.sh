@@ -26,3 +26,12 @@ if ! { [ "$OUT" -nt "$HERE/ref_sim_driver.cpp" ] && [ "$OUT" -nt "$HERE/compat/E
       -o "$OUT" "$HERE/ref_sim_driver.cpp"
   echo "ref_build: built $OUT"
 fi
+# the virtual benchmark's translation unit (its own class BALM2, the copy BASELINE configs[0..3] name): separate
+# object, its main() renamed, symbols bound locally
+OUT="$HERE/_ref/libbalm_ref_virtual.so"
+if ! { [ "$OUT" -nt "$HERE/ref_virtual_driver.cpp" ] && [ "$OUT" -nt "$HERE/compat/Eigen/Core" ] && [ -z "$BALM_FORCE_BUILD" ]; }; then
+  g++ -std=c++14 -O3 -fPIC -pthread -shared -w -Wl,-Bsymbolic \
+      -I"$HERE/compat" -I"$REF/include" -I"$REF/src/benchmark" \
+      -o "$OUT" "$HERE/ref_virtual_driver.cpp"
+  echo "ref_build: built $OUT"
+fi

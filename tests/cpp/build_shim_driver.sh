@@ -15,3 +15,8 @@ g++ -std=c++14 -O2 -w -pthread -I"$ROOT/oracle/compat" -I"$REF/src/simulation" -
     -o "$ROOT/oracle/_ref/shim_sim_driver" "$ROOT/tests/cpp/shim_sim_driver.cpp" \
     -L"$ROOT/balm_amd/lib" -lbalm_hip -ldl -Wl,-rpath,'$ORIGIN/../../balm_amd/lib'
 echo "built $ROOT/oracle/_ref/shim_sim_driver"
+# the virtual benchmark's translation unit + include/balm_shim_virtual.hpp (its own class BALM2: separate binary)
+g++ -std=c++14 -O3 -w -pthread -I"$ROOT/oracle/compat" -I"$REF/include" -I"$REF/src/benchmark" -I"$ROOT/include" \
+    -o "$ROOT/oracle/_ref/shim_virtual_driver" "$ROOT/tests/cpp/shim_virtual_driver.cpp" \
+    -L"$ROOT/balm_amd/lib" -lbalm_hip -ldl -Wl,-rpath,'$ORIGIN/../../balm_amd/lib'
+echo "built $ROOT/oracle/_ref/shim_virtual_driver"

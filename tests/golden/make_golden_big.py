@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Golden LM traces + final poses at the BASELINE sizes themselves -- the north star's acceptance test
+(final poses within 1e-5 rad / 1e-4 m of the reference CPU optimizer) pinned at its own size.
+
+    python tests/golden/make_golden_big.py [case ...]     # needs /root/reference (build container only)
+
+Both of the reference's optimizers are run, each from ITS OWN SOURCE compiled where it lies (oracle/ref_build.sh):
+  virtual  BALM2::dampingIter(x_stats, plSurfs)  src/benchmark/benchmark_virtual.cpp:375-482   (u0 = 0.1, <= 20 iterations,
+           clusters pushed from the float point clouds :392-403, weights winSize*ptsSize :391, single thread,
+           pose 0 -> identity at the end :472-479)                         -> oracle/_ref/libbalm_ref_virtual.so
+  bavoxel  BALM2::damping_iter(x_stats, voxhess) src/benchmark/bavoxel.hpp:1069-1166            (u0 = 0.01, <= 10 iterations,
+           4 std::threads, >= 20 planes per pose, re-anchor :1159-1164)    -> oracle/_ref/libbalm_ref.so
+Inputs are NOT stored (800 MB at W=200/F=50k): they regenerate from the seed with balm_amd.scene.generate(mode=1);
+the fixture carries checksums of the regenerated inputs so that a drifted generator fails loudly instead of
+silently comparing different problems.  Outputs per case: lm_log_* rows (r1 r2 u v q q1 accepted, parsed from the
+reference's printf line: 6 decimals), lm_poses_* [W,12], seconds_* (this container's CPU).
+
+Cases = BASELINE.json configs[1] (W=64, F=5 000, ~2 M points) and configs[2] (W=200, F=50 000; the bench workload,
+same seed as bench.py).
+"""
+import os
+import sys
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+from balm_amd import scene  # noqa: E402
+from oracle import ref, ref_virtual  # noqa: E402
+
+CASES = {
+    "lm_big_w64_f5000": dict(seed=2025, W=64, F=5000, pts=6),
+    "lm_big_w200_f50000": dict(seed=2024, W=200, F=50000, pts=6),      # bench.py's scene
+}
+
+
+def checksums(sc):
+    """position-weighted sums: sensitive to any permuted or perturbed entry, cheap to recompute"""
+    cl = sc.clusters.reshape(-1)
+    w = (np.arange(cl.size, dtype=np.float64) % 977.0) + 1.0
+    return np.array([cl.sum(), float(np.dot(cl, w)), sc.poses_init.sum(), sc.coeffs.sum(),
+                     float(np.dot(sc.poses_init.reshape(-1), np.arange(1, sc.poses_init.size + 1)))])
+
+
+def main():
+    ref.build()
+    names = sys.argv[1:] or list(CASES)
+    for name in names:
+        c = CASES[name]
+        sc = scene.generate(c["seed"], c["W"], c["F"], c["pts"], mode=1, keep_points=True)
+        out = dict(seed=c["seed"], W=c["W"], F=c["F"], pts=c["pts"], checksums=checksums(sc), poses_gt=sc.poses_gt)
+        t0 = time.time()
+        poses, lg, sec = ref_virtual.damping_iter(sc.points, sc.poses_init)
+        out["lm_poses_virtual"], out["lm_log_virtual"], out["seconds_virtual"] = poses, lg, sec
+        print(name, "virtual: %d iterations, %.1f s (%.1f s wall)" % (len(lg), sec, time.time() - t0), flush=True)
+        print(lg[:, :3], flush=True)
+        t0 = time.time()
+        poses, lg = ref.damping_iter(sc.clusters, None, sc.coeffs, sc.poses_init)
+        out["lm_poses_bavoxel"], out["lm_log_bavoxel"], out["seconds_bavoxel"] = poses, lg, time.time() - t0
+        print(name, "bavoxel: %d iterations, %.1f s" % (len(lg), time.time() - t0), flush=True)
+        print(lg[:, :3], flush=True)
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+
+
+if __name__ == "__main__":
+    main()

@@ -46,3 +46,16 @@ def test_bad_window_is_rejected():
         capi.Context(0)
     with pytest.raises(capi.BalmError):
         capi.Context(100000)
+
+
+def test_syrk_accumulators_stay_pinned():
+    """the hand-pinned AGPR accumulators of k_hessian_syrk are only ever touched by the generated instructions
+    (tools/check_syrk_agprs.py disassembles the built object): a compiler spill into an AGPR would corrupt the
+    Hessian silently, and only the GPU parity tests would notice."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import check_syrk_agprs
+    obj = os.path.join(ROOT, "balm_amd", "lib", "kernels_accum.o")
+    if not os.path.exists(obj) or not os.path.exists(check_syrk_agprs.LLVM + "/llvm-objdump"):
+        pytest.skip("object file or llvm-objdump not present")
+    assert check_syrk_agprs.check(obj, verbose=False) == []
