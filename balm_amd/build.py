@@ -10,7 +10,7 @@ import sys
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIBDIR = os.path.join(_HERE, "lib")
-HIP_SOURCES = ["kernels_accum.hip", "kernels_solve.hip", "kernels_build.hip", "kernels_voxel.hip", "kernels_cov.hip", "balm_capi.hip"]
+HIP_SOURCES = ["kernels_accum.hip", "kernels_solve.hip", "kernels_build.hip", "kernels_voxel.hip", "kernels_cov.hip", "balm_multi.hip", "balm_capi.hip"]
 # association decisions must reproduce the reference's un-fused float/double arithmetic bit for bit
 EXTRA_FLAGS = {"kernels_voxel.hip": ["-ffp-contract=off"]}
 HIP_DEPS = ["balm_internal.h", "syrk_mfma_asm.inc", os.path.join("..", "..", "include", "balm_hip.h")]
@@ -44,7 +44,7 @@ def build_hip(force=False, verbose=False):
         if p.wait() != 0:
             raise RuntimeError("hipcc failed: " + " ".join(cmd))
     if relink:
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", so] + objs
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", so] + objs + ["-ldl", "-pthread"]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)

@@ -14,13 +14,14 @@ LIB_PATH = os.environ.get("BALM_HIP_LIB") or os.path.join(_HERE, "lib", "libbalm
 FORM_LEFT, FORM_RIGHT = 0, 1
 OK, ERR_ARG, ERR_HIP, ERR_STATE, ERR_TOO_FEW_PLANES, ERR_NUMERIC = range(6)
 FLAG_TIMING = 1
+FLAG_LOOPBACK_SHARDS = 2
 T_MOMENTS, T_FACTORS, T_SYRK, T_ASSEMBLE, T_SOLVE, T_UPDATE, T_BUILD, T_VOXEL, T_COV, T_COUNT = range(10)
 TIMING_NAMES = ["moments", "factors", "syrk", "assemble", "solve", "update", "build", "voxel", "cov"]
 
 # every symbol include/balm_hip.h declares
 EXPORTS = ["balm_create", "balm_create_multi", "balm_destroy", "balm_set_features", "balm_evaluate", "balm_only_residual",
            "balm_solve_damped", "balm_damping_iter", "balm_build_clusters", "balm_voxel_defaults", "balm_associate", "balm_get_features", "balm_get_association", "balm_pose_covariance",
-           "balm_set_allreduce",
+           "balm_set_allreduce", "balm_comm_unique_id", "balm_comm_init_rank",
            "balm_get_timing", "balm_reset_timing", "balm_work_model", "balm_last_error", "balm_version"]
 
 
@@ -83,6 +84,8 @@ def lib():
         L.balm_voxel_defaults.argtypes = [C.POINTER(VoxelOpts)]
         L.balm_pose_covariance.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p]
         L.balm_set_allreduce.argtypes = [C.c_void_p, ALLREDUCE_FN, C.c_void_p]
+        L.balm_comm_unique_id.argtypes = [C.c_void_p]
+        L.balm_comm_init_rank.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.balm_get_timing.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.balm_reset_timing.argtypes = [C.c_void_p]
         L.balm_work_model.argtypes = [C.c_void_p, C.c_void_p]
@@ -256,6 +259,20 @@ class Context:
 
         self._cb = ALLREDUCE_FN(tramp)
         self._check(self.L.balm_set_allreduce(self.h, self._cb, None))
+
+    @staticmethod
+    def comm_unique_id():
+        """128 bytes (ncclUniqueId) drawn by ONE rank; hand them to every rank's comm_init_rank."""
+        buf = C.create_string_buffer(128)
+        rc = lib().balm_comm_unique_id(buf)
+        if rc != OK:
+            raise BalmError(rc, "balm_comm_unique_id failed (librccl.so.1 not loadable?)")
+        return buf.raw
+
+    def comm_init_rank(self, n_ranks, rank, unique_id):
+        """RCCL inside the library for the one-process-per-GPU launch: no hook, no host synchronisation."""
+        buf = C.create_string_buffer(bytes(unique_id), 128)
+        self._check(self.L.balm_comm_init_rank(self.h, int(n_ranks), int(rank), buf))
 
     def timing(self):
         ms = np.zeros(T_COUNT)

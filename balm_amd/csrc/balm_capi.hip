@@ -77,7 +77,15 @@ int sync_stream(balm_ctx *ctx) {
 long red_dacc_off(const balm_ctx *c) { return (long)c->ntiles * TILE_ELEMS; }
 long red_r_off(const balm_ctx *c) { return red_dacc_off(c) + (long)DACC_MAX * c->W; }
 
+// Sum `n` doubles at `buf` over all ranks, in place, ordered after everything enqueued on ctx->stream so far and
+// before everything enqueued later.  Transports: RCCL inside the library (a device of a balm_create_multi context, or
+// a rank of balm_comm_init_rank) -- stream-ordered, no host synchronisation; the loopback sum of shards that share one
+// physical device; or the caller's hook (balm_set_allreduce), which gets a synchronised stream.
+bool has_transport(const balm_ctx *ctx) { return ctx->comm || multi_is_loopback(ctx) || ctx->allreduce; }
+
 int hook_allreduce(balm_ctx *ctx, double *buf, long n) {
+  if (ctx->comm) return comm_allreduce(ctx, buf, n);
+  if (multi_is_loopback(ctx)) return loopback_allreduce(ctx, buf, n);
   if (!ctx->allreduce) return BALM_OK;
   int rc = sync_stream(ctx);
   if (rc) return rc;
@@ -93,7 +101,10 @@ int hook_allreduce(balm_ctx *ctx, double *buf, long n) {
 // they are exactly what the next Hessian evaluation needs at the same poses (the reference recomputes
 // them, bavoxel.hpp:331-351 after :443-457).
 int residual_device(balm_ctx *ctx, const double *d_poses, int f0, int f1, int slot) {
-  {
+  if (f1 <= f0) {          // a shard the requested feature range does not reach: contributes zero
+    HIP_TRY(hipMemsetAsync(ctx->d_scal + slot, 0, sizeof(double), ctx->stream));
+    ctx->nr_tmp = 0;
+  } else {
     Span sp(ctx, BALM_T_MOMENTS);
     launch_world_moments(ctx->stream, ctx->d_cl, d_poses, ctx->W, f0, f1, ctx->d_C);
     ctx->nr_tmp = launch_feature_eigen(ctx->stream, ctx->d_C, ctx->d_fix, ctx->d_coe, f0, f1, ctx->d_feat_tmp,
@@ -103,16 +114,33 @@ int residual_device(balm_ctx *ctx, const double *d_poses, int f0, int f1, int sl
   return hook_allreduce(ctx, ctx->d_scal + slot, 1);
 }
 
+// scratch of one Hessian evaluation over nf features (grown, never shrunk): every allocation an evaluation can need
+// happens here, so that a rank of a sharded run can fail BEFORE the collectives start (see one_damping_iter)
+int prepare_evaluate(balm_ctx *ctx, int form, int nf) {
+  if (nf <= 0) return BALM_OK;
+  const SyrkPlan plan = plan_syrk(ctx->ntiles, 3L * nf);
+  int rc;
+  if ((rc = ensure(ctx, &ctx->d_Gt, &ctx->cap_Gt, (size_t)(plan.Kpad + 64) * ctx->npad))) return rc;
+  if ((rc = ensure(ctx, &ctx->d_part, &ctx->cap_part, (size_t)plan.SG * ctx->ntiles * TILE_ELEMS))) return rc;
+  return ensure(ctx, &ctx->d_dpart, &ctx->cap_dpart, (size_t)factors_grid(ctx->W, nf, form) * DACC_MAX * ctx->W);
+}
+
 // Hessian + gradient + residual of features [f0,f1) at device poses -> d_H, d_g, d_scal[slot]
 int evaluate_device(balm_ctx *ctx, int form, const double *d_poses, int f0, int f1, int slot) {
   const int W = ctx->W, nf = f1 - f0;
   const int dacc = form == 0 ? DACC_LEFT : DACC_RIGHT;
-  SyrkPlan plan = plan_syrk(ctx->ntiles, 3L * nf);
   int rc;
-  if ((rc = ensure(ctx, &ctx->d_Gt, &ctx->cap_Gt, (size_t)(plan.Kpad + 64) * ctx->npad))) return rc;
-  if ((rc = ensure(ctx, &ctx->d_part, &ctx->cap_part, (size_t)plan.SG * ctx->ntiles * TILE_ELEMS))) return rc;
+  if (nf <= 0) {           // a shard the requested feature range does not reach: an all-zero payload
+    HIP_TRY(hipMemsetAsync(ctx->d_red, 0, ctx->red_len * sizeof(double), ctx->stream));
+    if ((rc = hook_allreduce(ctx, ctx->d_red, (long)ctx->red_len))) return rc;
+    Span sp(ctx, BALM_T_ASSEMBLE);
+    launch_assemble(ctx->stream, form, ctx->d_red, red_dacc_off(ctx), ctx->d_sub, ctx->ntiles, W, ctx->d_H, ctx->d_g);
+    HIP_TRY(hipMemcpyAsync(ctx->d_scal + slot, ctx->d_red + red_r_off(ctx), sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    return BALM_OK;
+  }
+  SyrkPlan plan = plan_syrk(ctx->ntiles, 3L * nf);
+  if ((rc = prepare_evaluate(ctx, form, nf))) return rc;
   const int nblk = factors_grid(W, nf, form);
-  if ((rc = ensure(ctx, &ctx->d_dpart, &ctx->cap_dpart, (size_t)nblk * DACC_MAX * W))) return rc;
   hipStream_t s = ctx->stream;
   if (!(ctx->feat_cur_valid && f0 == 0 && f1 == ctx->F)) {
     Span sp(ctx, BALM_T_MOMENTS);
@@ -191,6 +219,8 @@ const char *balm_version(void) { return "balm_hip 0.1.0 (gfx950)"; }
 
 const char *balm_last_error(balm_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 
+static void one_destroy(balm_ctx *ctx);
+
 balm_ctx *balm_create(int win_size, int device, int flags) {
   if (win_size < 1 || win_size > MAX_W) return nullptr;
   int ndev = 0;
@@ -206,7 +236,7 @@ balm_ctx *balm_create(int win_size, int device, int flags) {
   ctx->device = device;
   ctx->flags = flags;
   ctx->timer.on = (flags & BALM_FLAG_TIMING) != 0;
-  auto fail = [&]() -> balm_ctx * { balm_destroy(ctx); return nullptr; };
+  auto fail = [&]() -> balm_ctx * { one_destroy(ctx); return nullptr; };
   // The SYRK's jobs per k-slice, each 25 accumulator sub-tiles (16x16) = one wavefront:
   //   the off-diagonal 80x80 tiles (I < J), in shells of growing J: a prefix of the list touches few row blocks.
   //     An XCD has 128 wave slots for the jobs of a k-slice, so every "generation" of waves holds the tail of one
@@ -256,7 +286,7 @@ balm_ctx *balm_create(int win_size, int device, int flags) {
       dalloc(ctx, &ctx->d_A, (size_t)(2 * nA + NB) * nA) || dalloc(ctx, &ctx->d_Wp, (size_t)NB * (2 * nA + NB)) ||
       dalloc(ctx, &ctx->d_dvec, (size_t)nA) || dalloc(ctx, &ctx->d_z, (size_t)nA) || dalloc(ctx, &ctx->d_x, (size_t)16 * nA) ||
       dalloc(ctx, &ctx->d_perm, (size_t)nA) || dalloc(ctx, &ctx->d_dx, (size_t)n) ||
-      dalloc(ctx, &ctx->d_scal, (size_t)16))
+      dalloc(ctx, &ctx->d_scal, (size_t)16) || dalloc(ctx, &ctx->d_pre, (size_t)W + 2))
     return fail();
   if (hipHostMalloc((void **)&ctx->h_scal, 16 * sizeof(double)) != hipSuccess) return fail();
   if (hipMemcpy(ctx->d_jobs, jobs.data(), jobs.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess ||
@@ -272,18 +302,14 @@ balm_ctx *balm_create(int win_size, int device, int flags) {
   return ctx;
 }
 
-balm_ctx *balm_create_multi(int win_size, int first_device, int n_devices, int flags) {
-  if (n_devices != 1) return nullptr;      // TODO(multi): sharded sub-contexts
-  return balm_create(win_size, first_device, flags);
-}
-
-void balm_destroy(balm_ctx *ctx) {
+static void one_destroy(balm_ctx *ctx) {
   if (!ctx) return;
+  comm_destroy(ctx);
   hipSetDevice(ctx->device);
   if (ctx->stream) hipStreamSynchronize(ctx->stream);
   void *ptrs[] = {ctx->d_cl, ctx->d_fix, ctx->d_coe, ctx->d_poses, ctx->d_poses_tmp, ctx->d_C, ctx->d_feat,
                   ctx->d_Gt, ctx->d_part, ctx->d_dpart, ctx->d_rpart, ctx->d_feat_tmp, ctx->d_rpart_tmp, ctx->d_red, ctx->d_jobs, ctx->d_sub, ctx->d_H,
-                  ctx->d_g, ctx->d_A, ctx->d_Wp, ctx->d_dvec, ctx->d_z, ctx->d_x, ctx->d_perm, ctx->d_dx, ctx->d_scal, ctx->d_arena};
+                  ctx->d_g, ctx->d_A, ctx->d_Wp, ctx->d_dvec, ctx->d_z, ctx->d_x, ctx->d_perm, ctx->d_dx, ctx->d_scal, ctx->d_arena, ctx->d_pre};
   for (void *p : ptrs) if (p) hipFree(p);
   if (ctx->h_scal) hipHostFree(ctx->h_scal);
   for (auto &sp : ctx->timer.pending) { hipEventDestroy(sp.a); hipEventDestroy(sp.b); }
@@ -312,8 +338,9 @@ static int install_feature_buffers(balm_ctx *ctx, int F, const double *fix, cons
   return BALM_OK;
 }
 
-int balm_set_features(balm_ctx *ctx, int F, const double *clusters, const double *fix, const double *coeffs) {
+static int one_set_features(balm_ctx *ctx, int F, const double *clusters, const double *fix, const double *coeffs) {
   if (!ctx) return BALM_ERR_ARG;
+  if (ctx->multi && F == 0) { ctx->F = 0; ctx->feat_cur_valid = false; return BALM_OK; }      // a shard without features
   if (F < 1 || !clusters || !coeffs) { ctx->err = "balm_set_features: bad argument"; return BALM_ERR_ARG; }
   HIP_TRY(hipSetDevice(ctx->device));
   const int W = ctx->W;
@@ -330,12 +357,12 @@ int balm_set_features(balm_ctx *ctx, int F, const double *clusters, const double
   }
   hipFree(d_aos);
   HIP_TRY(e);
-  if ((rc = feature_bookkeeping(ctx, F, clusters, fix, coeffs))) return rc;
+  if (!ctx->multi && (rc = feature_bookkeeping(ctx, F, clusters, fix, coeffs))) return rc;    // sharded: done once on the whole table
   if ((rc = install_feature_buffers(ctx, F, fix, coeffs))) return rc;
   return sync_stream(ctx);
 }
 
-int balm_build_clusters(balm_ctx *ctx, int F, const float *xyz, const int *feat_id, const int *pose_id, long n_pts,
+static int one_build_clusters(balm_ctx *ctx, int F, const float *xyz, const int *feat_id, const int *pose_id, long n_pts,
                         const double *fix, const double *coeffs, double *clusters_out) {
   if (!ctx) return BALM_ERR_ARG;
   if (F < 1 || n_pts < 0 || !xyz || !feat_id || !pose_id || !coeffs) {
@@ -390,7 +417,7 @@ void balm_voxel_defaults(balm_voxel_opts *o) {
   o->want_point_features = 0;
 }
 
-int balm_associate(balm_ctx *ctx, const balm_voxel_opts *opts, const float *xyz, const int *frame_id, long n_pts,
+static int one_associate(balm_ctx *ctx, const balm_voxel_opts *opts, const float *xyz, const int *frame_id, long n_pts,
                    const double *poses, int *F_out, long *n_root_voxels) {
   if (!ctx) return BALM_ERR_ARG;
   if (!opts || !xyz || !frame_id || !poses || !F_out || n_pts < 1 || !(opts->voxel_size > 0) || opts->fix_frames < 0 ||
@@ -488,10 +515,10 @@ int balm_get_association(balm_ctx *ctx, double *fix, int *point_feature) {
   return BALM_OK;
 }
 
-int balm_pose_covariance(balm_ctx *ctx, const double *poses, const double *cluster_cov, double point_sigma, double *Rcov,
+static int one_pose_covariance(balm_ctx *ctx, const double *poses, const double *cluster_cov, double point_sigma, double *Rcov,
                          double *Rcov_raw) {
   if (!ctx) return BALM_ERR_ARG;
-  if (ctx->F < 1) { ctx->err = "balm_pose_covariance: no features installed"; return BALM_ERR_STATE; }
+  if (!ctx->multi && ctx->F < 1) { ctx->err = "balm_pose_covariance: no features installed"; return BALM_ERR_STATE; }
   if (!poses || (!cluster_cov && !(point_sigma > 0))) { ctx->err = "balm_pose_covariance: bad argument"; return BALM_ERR_ARG; }
   if (ctx->W > MAX_W_LDS) { ctx->err = "balm_pose_covariance: windows above 480 poses are not supported"; return BALM_ERR_ARG; }
   HIP_TRY(hipSetDevice(ctx->device));
@@ -502,11 +529,11 @@ int balm_pose_covariance(balm_ctx *ctx, const double *poses, const double *clust
   int rc = evaluate_device(ctx, BALM_FORM_LEFT, ctx->d_poses, 0, F, 0);     // d_H, and the eigen records in d_feat
   ctx->feat_cur_valid = false;
   if (rc) return rc;
-  const SyrkPlan plan = plan_syrk(ctx->ntiles, 3L * F);
+  const SyrkPlan plan = plan_syrk(ctx->ntiles, 3L * (F > 0 ? F : 1));
   const size_t gcols = (size_t)plan.Kpad + 64, tiles = (size_t)ctx->ntiles * TILE_ELEMS;
   if ((rc = ensure(ctx, &ctx->d_Gt, &ctx->cap_Gt, 2 * gcols * ctx->npad))) return rc;
   if ((rc = ensure(ctx, &ctx->d_part, &ctx->cap_part, (size_t)plan.SG * tiles))) return rc;
-  const int nblk = cov_factors_grid(W, F);
+  const int nblk = cov_factors_grid(W, F > 0 ? F : 1);
   if ((rc = ensure(ctx, &ctx->d_dpart, &ctx->cap_dpart, (size_t)nblk * DACC_MAX * W))) return rc;
   // scratch: [redX | redY | S (21 W)] (one all-reduce payload) | Rraw | Rcov | T0, T1 (nA x nA each)
   const size_t pay = 2 * tiles + (size_t)21 * W, nn = (size_t)n * n;
@@ -515,12 +542,13 @@ int balm_pose_covariance(balm_ctx *ctx, const double *poses, const double *clust
   double *redx = buf, *redy = buf + tiles, *sdiag = buf + 2 * tiles, *Rraw = buf + pay, *Rc = Rraw + nn,
          *T0 = Rc + nn, *T1 = T0 + (size_t)nA * nA;
   hipError_t e = hipSuccess;
-  if (cluster_cov) {
+  if (cluster_cov && F > 0) {
     e = hipMalloc((void **)&d_cc, (size_t)F * W * 81 * sizeof(double));
     if (e == hipSuccess) e = hipMemcpyAsync(d_cc, cluster_cov, (size_t)F * W * 81 * sizeof(double), hipMemcpyHostToDevice, s);
   }
   double *Gx = ctx->d_Gt, *Gy = ctx->d_Gt + gcols * ctx->npad;
-  if (e == hipSuccess) {
+  if (e == hipSuccess && F == 0) e = hipMemsetAsync(buf, 0, pay * sizeof(double), s);      // a shard without features
+  if (e == hipSuccess && F > 0) {
     Span sp(ctx, BALM_T_COV);
     const size_t k0 = (size_t)3 * F;
     hipMemsetAsync(Gx + k0 * ctx->npad, 0, (gcols - k0) * ctx->npad * sizeof(double), s);
@@ -555,17 +583,20 @@ int balm_pose_covariance(balm_ctx *ctx, const double *poses, const double *clust
 
 int balm_set_allreduce(balm_ctx *ctx, balm_allreduce_fn fn, void *user) {
   if (!ctx) return BALM_ERR_ARG;
+  if (fn && (ctx->multi || ctx->comm)) { ctx->err = "balm_set_allreduce: the context already has a collective transport"; return BALM_ERR_STATE; }
   ctx->allreduce = fn;
   ctx->allreduce_user = user;
   return BALM_OK;
 }
 
-int balm_evaluate(balm_ctx *ctx, int form, const double *poses, int head, int end, double *Hess, double *JacT,
+static int one_evaluate(balm_ctx *ctx, int form, const double *poses, int head, int end, double *Hess, double *JacT,
                   double *residual) {
   if (!ctx) return BALM_ERR_ARG;
-  if (ctx->F < 1) { ctx->err = "balm_evaluate: no features installed"; return BALM_ERR_STATE; }
-  if ((form != 0 && form != 1) || !poses || head < 0 || end > ctx->F || head >= end) {
-    ctx->err = "balm_evaluate: bad argument"; return BALM_ERR_ARG;
+  if (!ctx->multi) {
+    if (ctx->F < 1) { ctx->err = "balm_evaluate: no features installed"; return BALM_ERR_STATE; }
+    if ((form != 0 && form != 1) || !poses || head < 0 || end > ctx->F || head >= end) {
+      ctx->err = "balm_evaluate: bad argument"; return BALM_ERR_ARG;
+    }
   }
   HIP_TRY(hipSetDevice(ctx->device));
   const int n = ctx->n;
@@ -582,9 +613,9 @@ int balm_evaluate(balm_ctx *ctx, int form, const double *poses, int head, int en
   return BALM_OK;
 }
 
-int balm_only_residual(balm_ctx *ctx, const double *poses, double *residual) {
+static int one_only_residual(balm_ctx *ctx, const double *poses, double *residual) {
   if (!ctx) return BALM_ERR_ARG;
-  if (ctx->F < 1) { ctx->err = "balm_only_residual: no features installed"; return BALM_ERR_STATE; }
+  if (!ctx->multi && ctx->F < 1) { ctx->err = "balm_only_residual: no features installed"; return BALM_ERR_STATE; }
   if (!poses || !residual) { ctx->err = "balm_only_residual: bad argument"; return BALM_ERR_ARG; }
   HIP_TRY(hipSetDevice(ctx->device));
   HIP_TRY(hipMemcpyAsync(ctx->d_poses_tmp, poses, (size_t)12 * ctx->W * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
@@ -614,32 +645,46 @@ int balm_solve_damped(balm_ctx *ctx, const double *Hess, const double *JacT, dou
   return BALM_OK;
 }
 
-int balm_damping_iter(balm_ctx *ctx, const balm_lm_opts *o, double *poses, balm_iter_log *log, int *n_iters) {
+static int one_damping_iter(balm_ctx *ctx, const balm_lm_opts *o, double *poses, balm_iter_log *log, int *n_iters) {
   if (!ctx) return BALM_ERR_ARG;
-  if (ctx->F < 1) { ctx->err = "balm_damping_iter: no features installed"; return BALM_ERR_STATE; }
+  if (!ctx->multi && ctx->F < 1) { ctx->err = "balm_damping_iter: no features installed"; return BALM_ERR_STATE; }
   if (!o || !poses || (o->form != 0 && o->form != 1) || o->max_iter < 1) {
     ctx->err = "balm_damping_iter: bad argument"; return BALM_ERR_ARG;
   }
   if (n_iters) *n_iters = 0;
-  // bavoxel.hpp:1071-1085: every pose must see >= 20 planes (printf + exit(0) in the reference).
-  // With an all-reduce hook the counts are per-shard, so the caller prechecks the global counts.
-  if (o->min_planes_per_pose > 0 && !ctx->allreduce) {
-    int mn = ctx->planes_per_pose.empty() ? 0 : ctx->planes_per_pose[0];
-    for (int v : ctx->planes_per_pose) mn = v < mn ? v : mn;
+  HIP_TRY(hipSetDevice(ctx->device));
+  const int W = ctx->W, F = ctx->F;
+  hipStream_t s = ctx->stream;
+  int rc = prepare_evaluate(ctx, o->form, F);
+  // bavoxel.hpp:1071-1085: every pose must see >= 20 planes (printf + exit(0) in the reference).  Sharded runs hold
+  // per-shard counts: they are summed once, before the loop, in a collective that also carries an error flag, so that
+  // a rank that could not allocate its scratch takes every rank out together instead of leaving them in an all-reduce.
+  std::vector<double> pre((size_t)W + 2, 0.0);
+  for (size_t i = 0; i < ctx->planes_per_pose.size() && i < (size_t)W; i++) pre[i] = ctx->planes_per_pose[i];
+  pre[(size_t)W] = rc ? 1.0 : 0.0;
+  if (has_transport(ctx)) {
+    int rc2;
+    if (hipMemcpyAsync(ctx->d_pre, pre.data(), pre.size() * sizeof(double), hipMemcpyHostToDevice, s) != hipSuccess) return BALM_ERR_HIP;
+    if ((rc2 = hook_allreduce(ctx, ctx->d_pre, (long)pre.size()))) return rc2;
+    if (hipMemcpyAsync(pre.data(), ctx->d_pre, pre.size() * sizeof(double), hipMemcpyDeviceToHost, s) != hipSuccess) return BALM_ERR_HIP;
+    if ((rc2 = sync_stream(ctx))) return rc2;
+    if (pre[(size_t)W] != 0.0 && !rc) { ctx->err = "balm_damping_iter: another rank failed before the loop"; rc = BALM_ERR_STATE; }
+  }
+  if (rc) return rc;
+  if (o->min_planes_per_pose > 0) {
+    double mn = pre[0];
+    for (int i = 1; i < W; i++) mn = pre[(size_t)i] < mn ? pre[(size_t)i] : mn;
     if (mn < o->min_planes_per_pose) {
       ctx->err = "Initial error too large. Please loose plane determination criteria for more planes. "
                  "The optimization is terminated.";
       return BALM_ERR_TOO_FEW_PLANES;
     }
   }
-  HIP_TRY(hipSetDevice(ctx->device));
-  const int W = ctx->W, F = ctx->F;
-  hipStream_t s = ctx->stream;
   HIP_TRY(hipMemcpyAsync(ctx->d_poses, poses, (size_t)12 * W * sizeof(double), hipMemcpyHostToDevice, s));
   ctx->feat_cur_valid = false;
   double u = o->u0, v = 2, r1 = 0, r2 = 0;
   bool calc = true;
-  int it = 0, rc;
+  int it = 0;
   while (it < o->max_iter) {
     const bool evaluated = calc || o->force_hess;
     if (evaluated && (rc = evaluate_device(ctx, o->form, ctx->d_poses, 0, F, 0))) return rc;
@@ -653,8 +698,10 @@ int balm_damping_iter(balm_ctx *ctx, const balm_lm_opts *o, double *poses, balm_
     }
     if ((rc = residual_device(ctx, ctx->d_poses_tmp, 0, F, 1))) return rc;
     if ((rc = read_scalars(ctx))) return rc;
-    r1 = ctx->h_scal[0]; r2 = ctx->h_scal[1];
-    const double q1 = ctx->h_scal[2];
+    double sc[3] = {ctx->h_scal[0], ctx->h_scal[1], ctx->h_scal[2]};
+    multi_share_scalars(ctx, it, sc, 3);         // device 0's scalars decide on every device thread
+    r1 = sc[0]; r2 = sc[1];
+    const double q1 = sc[2];
     double q = r1 - r2;
     if (!(std::isfinite(r1) && std::isfinite(r2))) {
       ctx->err = "balm_damping_iter: non-finite residual";
@@ -692,6 +739,157 @@ int balm_damping_iter(balm_ctx *ctx, const balm_lm_opts *o, double *poses, balm_
   return BALM_OK;
 }
 
+// ---- public entry points: one device, or the devices of a balm_create_multi context ---------------------------------
+static balm_multi *leader_of(balm_ctx *ctx) { return (ctx && ctx->multi && ctx->rank == 0) ? ctx->multi : nullptr; }
+
+balm_ctx *balm_create_multi(int win_size, int first_device, int n_devices, int flags) {
+  if (n_devices < 1 || n_devices > MAX_SHARDS) return nullptr;
+  const bool loopback = (flags & BALM_FLAG_LOOPBACK_SHARDS) != 0;
+  std::vector<balm_ctx *> subs;
+  for (int k = 0; k < n_devices; k++) {
+    balm_ctx *c = balm_create(win_size, loopback ? first_device : first_device + k, flags);
+    if (!c) { for (auto *q : subs) one_destroy(q); return nullptr; }
+    subs.push_back(c);
+  }
+  std::string err;
+  balm_multi *m = multi_new(subs, loopback, &err);
+  if (!m) {
+    fprintf(stderr, "balm_create_multi: %s\n", err.c_str());
+    for (auto *q : subs) one_destroy(q);
+    return nullptr;
+  }
+  return subs[0];
+}
+
+void balm_destroy(balm_ctx *ctx) {
+  if (!ctx) return;
+  if (balm_multi *m = ctx->multi) {
+    std::vector<balm_ctx *> subs = m->sub;
+    for (auto *q : subs) { hipSetDevice(q->device); if (q->stream) hipStreamSynchronize(q->stream); }
+    multi_delete(m);
+    for (auto *q : subs) { q->multi = nullptr; one_destroy(q); }
+    return;
+  }
+  one_destroy(ctx);
+}
+
+int balm_comm_unique_id(void *id128) {
+  if (!id128) return BALM_ERR_ARG;
+  return comm_unique_id(id128);
+}
+
+int balm_comm_init_rank(balm_ctx *ctx, int n_ranks, int rank, const void *id128) {
+  if (!ctx) return BALM_ERR_ARG;
+  if (!id128 || n_ranks < 1 || rank < 0 || rank >= n_ranks) { ctx->err = "balm_comm_init_rank: bad argument"; return BALM_ERR_ARG; }
+  if (ctx->multi || ctx->comm) { ctx->err = "balm_comm_init_rank: the context already has a collective transport"; return BALM_ERR_STATE; }
+  HIP_TRY(hipSetDevice(ctx->device));
+  return comm_init_rank(ctx, n_ranks, rank, id128);
+}
+
+// the whole table is checked and counted once; shard k gets the contiguous range [fbeg[k], fbeg[k+1])
+static int multi_set_features(balm_ctx *ctx, balm_multi *m, int F, const double *clusters, const double *fix, const double *coeffs) {
+  if (F < 1 || !clusters || !coeffs) { ctx->err = "balm_set_features: bad argument"; return BALM_ERR_ARG; }
+  m->F = 0;
+  int rc = feature_bookkeeping(ctx, F, clusters, fix, coeffs);
+  if (rc) return rc;
+  for (int k = 0; k <= m->n; k++) m->fbeg[(size_t)k] = (int)((long)F * k / m->n);   // every feature costs the same (dense K3)
+  const size_t W = (size_t)ctx->W;
+  rc = multi_run(m, [&](int k) {
+    const int f0 = m->fbeg[(size_t)k], nf = m->fbeg[(size_t)k + 1] - f0;
+    return one_set_features(m->sub[(size_t)k], nf, clusters + (size_t)f0 * W * 10, fix ? fix + (size_t)f0 * 10 : nullptr, coeffs + f0);
+  });
+  if (rc) { if (ctx->err.empty()) ctx->err = "balm_set_features: a device failed"; return rc; }
+  m->F = F;
+  return BALM_OK;
+}
+
+int balm_set_features(balm_ctx *ctx, int F, const double *clusters, const double *fix, const double *coeffs) {
+  if (balm_multi *m = leader_of(ctx)) return multi_set_features(ctx, m, F, clusters, fix, coeffs);
+  return one_set_features(ctx, F, clusters, fix, coeffs);
+}
+
+int balm_build_clusters(balm_ctx *ctx, int F, const float *xyz, const int *feat_id, const int *pose_id, long n_pts,
+                        const double *fix, const double *coeffs, double *clusters_out) {
+  balm_multi *m = leader_of(ctx);
+  if (!m) return one_build_clusters(ctx, F, xyz, feat_id, pose_id, n_pts, fix, coeffs, clusters_out);
+  // one-off stage: the first device builds the whole table, then it is sharded like any other
+  if (F < 1) { ctx->err = "balm_build_clusters: bad argument"; return BALM_ERR_ARG; }
+  std::vector<double> host((size_t)F * ctx->W * 10);
+  ctx->multi = nullptr;                               // as a plain context for this one call
+  int rc = one_build_clusters(ctx, F, xyz, feat_id, pose_id, n_pts, fix, coeffs, host.data());
+  ctx->multi = m;
+  if (rc) return rc;
+  if (clusters_out) std::memcpy(clusters_out, host.data(), host.size() * sizeof(double));
+  return multi_set_features(ctx, m, F, host.data(), fix, coeffs);
+}
+
+int balm_associate(balm_ctx *ctx, const balm_voxel_opts *opts, const float *xyz, const int *frame_id, long n_pts,
+                   const double *poses, int *F_out, long *n_root_voxels) {
+  balm_multi *m = leader_of(ctx);
+  if (!m) return one_associate(ctx, opts, xyz, frame_id, n_pts, poses, F_out, n_root_voxels);
+  ctx->multi = nullptr;
+  int rc = one_associate(ctx, opts, xyz, frame_id, n_pts, poses, F_out, n_root_voxels);
+  ctx->multi = m;
+  m->F = 0;
+  if (rc || *F_out == 0) return rc;
+  return multi_set_features(ctx, m, *F_out, ctx->assoc_clusters.data(), opts->fix_frames > 0 ? ctx->assoc_fix.data() : nullptr,
+                            ctx->assoc_coeffs.data());
+}
+
+int balm_evaluate(balm_ctx *ctx, int form, const double *poses, int head, int end, double *Hess, double *JacT, double *residual) {
+  balm_multi *m = leader_of(ctx);
+  if (!m) return one_evaluate(ctx, form, poses, head, end, Hess, JacT, residual);
+  if (m->F < 1) { ctx->err = "balm_evaluate: no features installed"; return BALM_ERR_STATE; }
+  if ((form != 0 && form != 1) || !poses || head < 0 || end > m->F || head >= end) { ctx->err = "balm_evaluate: bad argument"; return BALM_ERR_ARG; }
+  return multi_run(m, [&](int k) {
+    const int f0 = m->fbeg[(size_t)k], f1 = m->fbeg[(size_t)k + 1];
+    const int lh = (head > f0 ? head : f0) - f0, le = (end < f1 ? end : f1) - f0;
+    double r = 0;
+    return one_evaluate(m->sub[(size_t)k], form, poses, lh, le > lh ? le : lh, k ? nullptr : Hess, k ? nullptr : JacT, k ? &r : residual);
+  });
+}
+
+int balm_only_residual(balm_ctx *ctx, const double *poses, double *residual) {
+  balm_multi *m = leader_of(ctx);
+  if (!m) return one_only_residual(ctx, poses, residual);
+  if (m->F < 1) { ctx->err = "balm_only_residual: no features installed"; return BALM_ERR_STATE; }
+  if (!poses || !residual) { ctx->err = "balm_only_residual: bad argument"; return BALM_ERR_ARG; }
+  return multi_run(m, [&](int k) { double r = 0; return one_only_residual(m->sub[(size_t)k], poses, k ? &r : residual); });
+}
+
+int balm_damping_iter(balm_ctx *ctx, const balm_lm_opts *o, double *poses, balm_iter_log *log, int *n_iters) {
+  balm_multi *m = leader_of(ctx);
+  if (!m) return one_damping_iter(ctx, o, poses, log, n_iters);
+  if (m->F < 1) { ctx->err = "balm_damping_iter: no features installed"; return BALM_ERR_STATE; }
+  if (!o || !poses || o->max_iter < 1) { ctx->err = "balm_damping_iter: bad argument"; return BALM_ERR_ARG; }
+  const size_t np = (size_t)12 * ctx->W;
+  std::vector<std::vector<double>> pk((size_t)m->n, std::vector<double>(poses, poses + np));     // every device thread: its own copy
+  std::vector<int> its((size_t)m->n, 0);
+  balm_lm_opts ok = *o;
+  int rc = multi_run(m, [&](int k) {
+    balm_lm_opts oo = ok;
+    if (k) oo.verbose = 0;
+    return one_damping_iter(m->sub[(size_t)k], &oo, pk[(size_t)k].data(), k ? nullptr : log, &its[(size_t)k]);
+  });
+  if (rc) { if (ctx->err.empty()) for (auto *q : m->sub) if (!q->err.empty()) { ctx->err = q->err; break; } return rc; }
+  std::memcpy(poses, pk[0].data(), np * sizeof(double));
+  if (n_iters) *n_iters = its[0];
+  return BALM_OK;
+}
+
+int balm_pose_covariance(balm_ctx *ctx, const double *poses, const double *cluster_cov, double point_sigma, double *Rcov,
+                         double *Rcov_raw) {
+  balm_multi *m = leader_of(ctx);
+  if (!m) return one_pose_covariance(ctx, poses, cluster_cov, point_sigma, Rcov, Rcov_raw);
+  if (m->F < 1) { ctx->err = "balm_pose_covariance: no features installed"; return BALM_ERR_STATE; }
+  const size_t W = (size_t)ctx->W;
+  return multi_run(m, [&](int k) {
+    const size_t f0 = (size_t)m->fbeg[(size_t)k];
+    return one_pose_covariance(m->sub[(size_t)k], poses, cluster_cov ? cluster_cov + f0 * W * 81 : nullptr, point_sigma,
+                               k ? nullptr : Rcov, k ? nullptr : Rcov_raw);
+  });
+}
+
 int balm_get_timing(balm_ctx *ctx, double *ms, long *count) {
   if (!ctx) return BALM_ERR_ARG;
   for (int k = 0; k < BALM_T_COUNT; k++) {
@@ -709,11 +907,11 @@ int balm_reset_timing(balm_ctx *ctx) {
 
 int balm_work_model(balm_ctx *ctx, double *out4) {
   if (!ctx || !out4) return BALM_ERR_ARG;
-  const double W = ctx->W, F = ctx->F;
+  const double W = ctx->W, F = ctx->multi ? ctx->multi->F : ctx->F;
   out4[0] = ctx->work_S;
   out4[1] = ctx->work_B;
   out4[2] = 108.0 * F * W * (W + 1.0);            // 108 FMA = 216 flop per unordered pair incl. diagonal -> x2/2
-  SyrkPlan p = plan_syrk(ctx->ntiles, 3L * ctx->F);
+  SyrkPlan p = plan_syrk(ctx->ntiles, 3L * (long)F);
   out4[3] = (double)ctx->ntiles * 25.0 * 2048.0 * ((double)p.Kpad / 4.0);   // 25 MFMAs per k-step of every job
   return BALM_OK;
 }

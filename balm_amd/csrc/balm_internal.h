@@ -1,9 +1,14 @@
 // Internal declarations shared by the HIP translation units of libbalm_hip.so (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
+#include <condition_variable>
 #include <cstddef>
 #include <cstdint>
+#include <functional>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/balm_hip.h"
@@ -21,6 +26,7 @@ constexpr int DACC_MAX = 30;
 constexpr int NB = 48;              // LDL^T panel width
 constexpr int MAX_W_LDS = 480;      // feature_factors keeps (12 + DACC) * W doubles in LDS up to here, pose chunks beyond
 constexpr int MAX_W = 1024;         // window limit of a context (n = 6144 unknowns)
+constexpr int MAX_SHARDS = 16;      // devices of one balm_create_multi context
 
 // feat record layout
 enum { FT_NN = 0, FT_VBAR = 1, FT_LAM = 4, FT_U0 = 7, FT_U1 = 10, FT_U2 = 13, FT_C0 = 16, FT_C1 = 17,
@@ -92,6 +98,12 @@ struct balm_ctx {
   balm_allreduce_fn allreduce = nullptr;
   void *allreduce_user = nullptr;
   balm::Timer timer;
+  // collective transport (balm_multi.hip): stream-ordered RCCL inside the library, either as one of the devices of a
+  // balm_create_multi context or as one rank of a multi-process job (balm_comm_init_rank)
+  void *comm = nullptr;             // ncclComm_t
+  int rank = 0, nranks = 1;
+  struct balm_multi *multi = nullptr;   // set on every device context of a balm_create_multi context
+  double *d_pre = nullptr;          // [W + 2] pre-loop all-reduce: planes per pose, error flag
 };
 
 namespace balm {
@@ -115,6 +127,50 @@ void launch_reduce(hipStream_t s, const double *part, int SG, long tile_elems_to
 void launch_assemble(hipStream_t s, int form, const double *red, long red_dacc_off, const int *tileIJ, int ntiles,
                      int W, double *H, double *g);
 void launch_sum_scalar(hipStream_t s, const double *rpart, int nr, double *out);
+
+// balm_multi.hip: one context over several devices of this process, RCCL loaded on first use
+struct Barrier;
+}  // namespace balm
+
+struct balm_multi {
+  int n = 0;                                // device contexts; sub[0] is the public handle
+  bool loopback = false;                    // all shards on one physical device, in-library sum instead of RCCL
+  std::vector<balm_ctx *> sub;
+  std::vector<int> fbeg;                    // shard k holds features [fbeg[k], fbeg[k+1]) of the caller's table
+  int F = 0;
+  // device threads (device 0 is driven by the calling thread)
+  std::vector<std::thread> th;
+  std::mutex mu;
+  std::condition_variable cv_go, cv_done;
+  uint64_t gen = 0;
+  int pending = 0;
+  bool quit = false;
+  const std::function<int(int)> *job = nullptr;
+  std::vector<int> rc;
+  balm::Barrier *bar = nullptr;
+  // LM decision scalars of device 0, per iteration parity
+  std::atomic<uint64_t> lm_seq{0};
+  uint64_t lm_epoch = 0;
+  double lm_vals[2][8] = {{0}};
+  // loopback transport
+  std::vector<hipEvent_t> ev1, ev2;
+  std::vector<double *> lb_tmp, lb_buf;
+  std::vector<size_t> lb_cap;
+};
+
+namespace balm {
+balm_multi *multi_new(const std::vector<balm_ctx *> &subs, bool loopback, std::string *err);
+void multi_delete(balm_multi *m);
+int multi_run(balm_multi *m, const std::function<int(int)> &f);
+int comm_unique_id(void *out128);
+int comm_init_rank(balm_ctx *ctx, int nranks, int rank, const void *id128);
+void comm_destroy(balm_ctx *ctx);
+const char *rccl_load_error();
+int comm_allreduce(balm_ctx *ctx, double *buf, long n);      // stream-ordered sum over the ranks of ctx->comm
+int loopback_allreduce(balm_ctx *ctx, double *buf, long n);   // shards of one physical device (test transport)
+bool multi_is_loopback(const balm_ctx *ctx);
+void multi_share_scalars(balm_ctx *ctx, int it, double *vals, int count);   // rank 0's LM scalars -> all device threads
+int multi_host_barrier_rc(balm_ctx *ctx, int rc);             // all device threads meet; returns the first non-zero rc
 
 // launchers (kernels_solve.hip)
 void launch_solve(balm_ctx *c, double u, bool new_hessian);      // (H + u diag H) dx = -g ; q1 -> d_scal[2]

@@ -1,0 +1,250 @@
+// One context over several GPUs of one process (balm_create_multi), and the collective transport of the path.
+//
+// The path shards over features: Hess, JacT and the residual are sums over features, which the reference
+// adds thread by thread (`Hess += hessians[i]`, src/benchmark/bavoxel.hpp:1049-1056).  Here every device holds a
+// contiguous shard of the features and a replica of the small per-window state; one host thread per device enqueues
+// that device's kernels on its own stream; the per-device payload [SYRK tiles | per-pose gradient + block diagonal |
+// residual] is summed in place by ONE stream-ordered RCCL all-reduce over xGMI per Hessian evaluation (one 8-byte
+// all-reduce per residual-only evaluation), and assemble + LDL^T solve + pose update run replicated on every device
+// (identical inputs, identical arithmetic -> identical steps; the LM decision scalars are nevertheless taken from
+// device 0 on all threads so that the collective sequences can never diverge).
+//
+// RCCL is loaded on first use (dlopen "librccl.so.1": a process that already carries RCCL -- PyTorch's process group --
+// shares that copy), so a single-GPU user of libbalm_hip.so never needs it.  The same transport serves the
+// one-process-per-GPU launch (torchrun): balm_comm_unique_id / balm_comm_init_rank.
+//
+// BALM_FLAG_LOOPBACK_SHARDS puts all shards on ONE physical device and replaces the RCCL call by an in-library sum over
+// the shards' buffers (same place in the stream order): the test vehicle for the sharding / threading / replication
+// logic on a one-GPU box, where a communicator cannot hold the same device twice.
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <cstring>
+#include <mutex>
+#include <thread>
+
+#include "balm_internal.h"
+
+namespace balm {
+
+// ---- RCCL, loaded lazily ---------------------------------------------------------------------------------------
+namespace {
+struct Rccl {
+  void *h = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
+  ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  const char *(*GetErrorString)(ncclResult_t) = nullptr;
+  std::string err;
+};
+Rccl g_rccl;
+std::once_flag g_rccl_once;
+
+const Rccl *rccl() {
+  std::call_once(g_rccl_once, [] {
+    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char *nm : names)
+      if ((g_rccl.h = dlopen(nm, RTLD_NOW | RTLD_LOCAL))) break;
+    if (!g_rccl.h) { g_rccl.err = std::string("cannot load librccl.so.1: ") + dlerror(); return; }
+    auto sym = [&](const char *s) { void *p = dlsym(g_rccl.h, s); if (!p) g_rccl.err = std::string("librccl: missing ") + s; return p; };
+    g_rccl.GetUniqueId = (decltype(g_rccl.GetUniqueId))sym("ncclGetUniqueId");
+    g_rccl.CommInitRank = (decltype(g_rccl.CommInitRank))sym("ncclCommInitRank");
+    g_rccl.CommInitAll = (decltype(g_rccl.CommInitAll))sym("ncclCommInitAll");
+    g_rccl.AllReduce = (decltype(g_rccl.AllReduce))sym("ncclAllReduce");
+    g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))sym("ncclCommDestroy");
+    g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))sym("ncclGetErrorString");
+  });
+  return g_rccl.err.empty() ? &g_rccl : nullptr;
+}
+}  // namespace
+
+const char *rccl_load_error() { rccl(); return g_rccl.err.c_str(); }
+
+int comm_unique_id(void *out128) {
+  const Rccl *r = rccl();
+  if (!r) return BALM_ERR_STATE;
+  ncclUniqueId id;
+  if (r->GetUniqueId(&id) != ncclSuccess) return BALM_ERR_HIP;
+  std::memcpy(out128, id.internal, NCCL_UNIQUE_ID_BYTES);
+  return BALM_OK;
+}
+
+int comm_init_rank(balm_ctx *ctx, int nranks, int rank, const void *id128) {
+  const Rccl *r = rccl();
+  if (!r) { ctx->err = rccl_load_error(); return BALM_ERR_STATE; }
+  ncclUniqueId id;
+  std::memcpy(id.internal, id128, NCCL_UNIQUE_ID_BYTES);
+  ncclComm_t c = nullptr;
+  const ncclResult_t e = r->CommInitRank(&c, nranks, id, rank);
+  if (e != ncclSuccess) { ctx->err = std::string("ncclCommInitRank: ") + r->GetErrorString(e); return BALM_ERR_HIP; }
+  ctx->comm = (void *)c; ctx->rank = rank; ctx->nranks = nranks;
+  return BALM_OK;
+}
+
+void comm_destroy(balm_ctx *ctx) {
+  if (!ctx->comm) return;
+  const Rccl *r = rccl();
+  if (r) r->CommDestroy((ncclComm_t)ctx->comm);
+  ctx->comm = nullptr;
+}
+
+int comm_allreduce(balm_ctx *ctx, double *buf, long n) {
+  const Rccl *r = rccl();
+  const ncclResult_t e = r->AllReduce(buf, buf, (size_t)n, ncclDouble, ncclSum, (ncclComm_t)ctx->comm, ctx->stream);
+  if (e != ncclSuccess) { ctx->err = std::string("ncclAllReduce: ") + r->GetErrorString(e); return BALM_ERR_HIP; }
+  return BALM_OK;
+}
+
+// ---- device threads ----------------------------------------------------------------------------------------------
+struct Barrier {
+  std::mutex mu; std::condition_variable cv; int n = 1, waiting = 0; uint64_t gen = 0; int rc_acc = 0, rc_out = 0;
+  int arrive(int rc) {          // returns the first non-zero rc any thread brought to this round
+    std::unique_lock<std::mutex> lk(mu);
+    if (rc && !rc_acc) rc_acc = rc;
+    const uint64_t g = gen;
+    if (++waiting == n) { waiting = 0; rc_out = rc_acc; rc_acc = 0; gen++; cv.notify_all(); return rc_out; }
+    cv.wait(lk, [&] { return gen != g; });
+    return rc_out;
+  }
+};
+
+static void worker_main(balm_multi *m, int k) {
+  hipSetDevice(m->sub[(size_t)k]->device);
+  uint64_t seen = 0;
+  for (;;) {
+    std::unique_lock<std::mutex> lk(m->mu);
+    m->cv_go.wait(lk, [&] { return m->quit || m->gen != seen; });
+    if (m->quit) return;
+    seen = m->gen;
+    lk.unlock();
+    const int rc = (*m->job)(k);
+    lk.lock();
+    m->rc[(size_t)k] = rc;
+    if (--m->pending == 0) m->cv_done.notify_all();
+  }
+}
+
+// f(k) on the thread of device k (k = 0: the calling thread); returns the first non-zero result
+int multi_run(balm_multi *m, const std::function<int(int)> &f) {
+  if (m->n == 1) return f(0);
+  {
+    std::lock_guard<std::mutex> lk(m->mu);
+    m->job = &f; m->pending = m->n - 1; m->gen++; m->lm_epoch++;
+  }
+  m->cv_go.notify_all();
+  hipSetDevice(m->sub[0]->device);
+  m->rc[0] = f(0);
+  {
+    std::unique_lock<std::mutex> lk(m->mu);
+    m->cv_done.wait(lk, [&] { return m->pending == 0; });
+    m->job = nullptr;
+  }
+  for (int rc : m->rc) if (rc) return rc;
+  return BALM_OK;
+}
+
+balm_multi *multi_new(const std::vector<balm_ctx *> &subs, bool loopback, std::string *err) {
+  balm_multi *m = new balm_multi();
+  m->n = (int)subs.size(); m->sub = subs; m->loopback = loopback;
+  m->fbeg.assign((size_t)m->n + 1, 0); m->rc.assign((size_t)m->n, 0);
+  m->bar = new Barrier(); m->bar->n = m->n;
+  if (!loopback) {
+    const Rccl *r = rccl();
+    if (!r) { *err = rccl_load_error(); delete m->bar; delete m; return nullptr; }
+    std::vector<int> devs;
+    for (auto *c : subs) devs.push_back(c->device);
+    std::vector<ncclComm_t> comms((size_t)m->n, nullptr);
+    const ncclResult_t e = r->CommInitAll(comms.data(), m->n, devs.data());
+    if (e != ncclSuccess) { *err = std::string("ncclCommInitAll: ") + r->GetErrorString(e); delete m->bar; delete m; return nullptr; }
+    for (int k = 0; k < m->n; k++) subs[(size_t)k]->comm = (void *)comms[(size_t)k];
+  } else {
+    m->ev1.assign((size_t)m->n, nullptr); m->ev2.assign((size_t)m->n, nullptr);
+    m->lb_tmp.assign((size_t)m->n, nullptr); m->lb_cap.assign((size_t)m->n, 0); m->lb_buf.assign((size_t)m->n, nullptr);
+    for (int k = 0; k < m->n; k++) {
+      hipSetDevice(subs[(size_t)k]->device);
+      if (hipEventCreateWithFlags(&m->ev1[(size_t)k], hipEventDisableTiming) != hipSuccess ||
+          hipEventCreateWithFlags(&m->ev2[(size_t)k], hipEventDisableTiming) != hipSuccess) {
+        *err = "loopback transport: event / table allocation failed"; delete m->bar; delete m; return nullptr;
+      }
+    }
+  }
+  for (int k = 0; k < m->n; k++) { subs[(size_t)k]->multi = m; subs[(size_t)k]->rank = k; subs[(size_t)k]->nranks = m->n; }
+  for (int k = 1; k < m->n; k++) m->th.emplace_back(worker_main, m, k);
+  return m;
+}
+
+void multi_delete(balm_multi *m) {
+  {
+    std::lock_guard<std::mutex> lk(m->mu);
+    m->quit = true;
+  }
+  m->cv_go.notify_all();
+  for (auto &t : m->th) t.join();
+  for (auto *c : m->sub) comm_destroy(c);
+  for (auto e : m->ev1) if (e) hipEventDestroy(e);
+  for (auto e : m->ev2) if (e) hipEventDestroy(e);
+  for (auto p : m->lb_tmp) if (p) hipFree(p);
+  delete m->bar;
+  delete m;
+}
+
+bool multi_is_loopback(const balm_ctx *ctx) { return ctx->multi && ctx->multi->loopback; }
+
+int multi_host_barrier_rc(balm_ctx *ctx, int rc) {
+  if (!ctx->multi || ctx->multi->n == 1) return rc;
+  return ctx->multi->bar->arrive(rc);
+}
+
+// the LM decision scalars of device 0 reach every device thread (identical by construction; this makes it a guarantee)
+void multi_share_scalars(balm_ctx *ctx, int it, double *vals, int count) {
+  balm_multi *m = ctx->multi;
+  if (!m || m->n == 1) return;
+  const uint64_t want = (m->lm_epoch << 24) + (uint64_t)it + 1;
+  if (ctx->rank == 0) {
+    for (int k = 0; k < count; k++) m->lm_vals[it & 1][k] = vals[k];
+    m->lm_seq.store(want, std::memory_order_release);
+  } else {
+    while (m->lm_seq.load(std::memory_order_acquire) < want) std::this_thread::yield();
+    for (int k = 0; k < count; k++) vals[k] = m->lm_vals[it & 1][k];
+  }
+}
+
+// ---- loopback transport: sum over the shards' buffers on one physical device ------------------------------------
+struct BufList { const double *p[MAX_SHARDS]; };
+__global__ __launch_bounds__(256) void k_sum_buffers(BufList bufs, int nb, long n, double *__restrict__ out) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    double s = bufs.p[0][i];
+    for (int b = 1; b < nb; b++) s += bufs.p[b][i];     // fixed order: every shard gets the same bits
+    out[i] = s;
+  }
+}
+
+int loopback_allreduce(balm_ctx *ctx, double *buf, long n) {
+  balm_multi *m = ctx->multi;
+  const int k = ctx->rank;
+  if (m->n == 1) return BALM_OK;
+  int rc = BALM_OK;
+  if (m->lb_cap[(size_t)k] < (size_t)n) {
+    if (m->lb_tmp[(size_t)k]) hipFree(m->lb_tmp[(size_t)k]);
+    m->lb_tmp[(size_t)k] = nullptr; m->lb_cap[(size_t)k] = 0;
+    if (hipMalloc((void **)&m->lb_tmp[(size_t)k], (size_t)n * sizeof(double)) != hipSuccess) rc = BALM_ERR_HIP;
+    else m->lb_cap[(size_t)k] = (size_t)n;
+  }
+  m->lb_buf[(size_t)k] = buf;
+  if (hipEventRecord(m->ev1[(size_t)k], ctx->stream) != hipSuccess) rc = BALM_ERR_HIP;
+  if ((rc = m->bar->arrive(rc))) { ctx->err = "loopback all-reduce failed"; return rc; }     // every payload is enqueued
+  for (int j = 0; j < m->n; j++) hipStreamWaitEvent(ctx->stream, m->ev1[(size_t)j], 0);
+  BufList bl;
+  for (int j = 0; j < m->n; j++) bl.p[j] = m->lb_buf[(size_t)j];
+  long grid = (n + 255) / 256; if (grid > 2048) grid = 2048;
+  hipLaunchKernelGGL(k_sum_buffers, dim3((unsigned)grid), dim3(256), 0, ctx->stream, bl, m->n, n, m->lb_tmp[(size_t)k]);
+  hipEventRecord(m->ev2[(size_t)k], ctx->stream);
+  m->bar->arrive(0);                                                                          // every sum is enqueued
+  for (int j = 0; j < m->n; j++) hipStreamWaitEvent(ctx->stream, m->ev2[(size_t)j], 0);      // ... and done reading buf
+  hipMemcpyAsync(buf, m->lb_tmp[(size_t)k], (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream);
+  return BALM_OK;
+}
+
+}  // namespace balm

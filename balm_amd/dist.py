@@ -85,20 +85,23 @@ class DeviceAllReduce:
     def __call__(self, ptr, n):
         torch, dist = self.torch, self.dist
         if self.zero_copy:
-            try:
-                t = self._views.get((ptr, n))
-                if t is None:
+            t = self._views.get((ptr, n))
+            if t is None:
+                try:      # only the VIEW may fall back: a failed collective must surface, not trigger a second one
                     t = torch.as_tensor(_DevMem(ptr, n), device="cuda")
                     if t.data_ptr() != ptr:
                         raise RuntimeError("as_tensor copied")
+                except Exception:
+                    self.zero_copy = False
+                    t = None
+                if t is not None:
                     if len(self._views) > 64:
                         self._views.clear()
                     self._views[(ptr, n)] = t
+            if t is not None:
                 dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
                 torch.cuda.synchronize()
                 return
-            except Exception:
-                self.zero_copy = False
         if self._hip is None:
             self._hip = C.CDLL("libamdhip64.so")
             self._hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
@@ -120,6 +123,20 @@ def install_allreduce(ctx, group=None):
     hook = DeviceAllReduce(group)
     ctx.set_allreduce(hook)
     return hook
+
+
+def install_rccl(ctx, group=None):
+    """The library's own RCCL transport for this one-process-per-GPU job: rank 0 draws the communicator id, the
+    process group carries its 128 bytes to every rank, and every rank joins with its context.  After this the
+    all-reduces are issued inside libbalm_hip.so on its own stream -- no hook, no host synchronisation."""
+    import torch
+    import torch.distributed as dist
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    box = [ctx.comm_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0, group=group)
+    ctx.comm_init_rank(world, rank, box[0])
+    torch.cuda.synchronize()
+    return "rccl-in-library"
 
 
 def allreduce_host_payload(H, g, r, group=None):

@@ -39,7 +39,9 @@ enum {
 
 /* balm_create flags */
 enum {
-  BALM_FLAG_TIMING = 1   /* record HIP events around every kernel class (balm_get_timing) */
+  BALM_FLAG_TIMING = 1,          /* record HIP events around every kernel class (balm_get_timing) */
+  BALM_FLAG_LOOPBACK_SHARDS = 2  /* balm_create_multi: all n_devices shards on the ONE device `first_device`, summed by
+                                    an in-library kernel instead of RCCL -- exercises the sharded path on a one-GPU box */
 };
 
 /* One row per LM iteration; the quantities the reference prints at bavoxel.hpp:1132. */
@@ -81,6 +83,13 @@ void balm_destroy(balm_ctx *ctx);
  * (benchmark_realworld.cpp:144-238, benchmark_virtual.cpp:505-524): this is how they reach 8 GPUs
  * (`BALM2_HIP::n_devices`).  n_devices == 1 is balm_create plus the collective path.  NULL on failure. */
 balm_ctx *balm_create_multi(int win_size, int first_device, int n_devices, int flags);
+
+/* The same stream-ordered RCCL transport for the one-process-per-GPU launch (torchrun): rank 0 draws an id
+ * (128 bytes, ncclUniqueId), the launcher hands it to every rank, every rank calls balm_comm_init_rank on its own
+ * balm_create context and installs ITS shard with balm_set_features.  From then on balm_evaluate /
+ * balm_only_residual / balm_damping_iter / balm_pose_covariance sum over the ranks inside the library. */
+int balm_comm_unique_id(void *id128);
+int balm_comm_init_rank(balm_ctx *ctx, int n_ranks, int rank, const void *id128);
 
 /* Replaces F calls of VOX_HESS::push_voxel (bavoxel.hpp:30-51): the shim flattens the borrowed
  * `const vector<PointCluster>*` / `const PointCluster* fix` pointers into these arrays.  Copies to
@@ -180,11 +189,10 @@ int balm_get_association(balm_ctx *ctx, double *fix, int *point_feature);
 int balm_pose_covariance(balm_ctx *ctx, const double *poses, const double *cluster_cov, double point_sigma,
                          double *Rcov, double *Rcov_raw);
 
-/* Multi-GPU: features are sharded across one-process-per-GPU ranks; each rank installs its shard
- * with balm_set_features and a hook that sums a device buffer of n doubles across ranks in place
- * (RCCL allreduce over xGMI; replaces the serial `Hess += hessians[i]` at bavoxel.hpp:1049-1056).
- * The hook is called with the library's stream already synchronised and must return after the
- * reduced data is visible on the device.  Return 0 on success. */
+/* A caller-supplied transport instead (any communication library): each rank installs its shard with
+ * balm_set_features and a hook that sums a device buffer of n doubles across ranks in place.  The hook is
+ * called with the library's stream already synchronised and must return after the reduced data is visible
+ * on the device.  Return 0 on success.  (balm_create_multi / balm_comm_init_rank need no hook.) */
 typedef int (*balm_allreduce_fn)(void *dev_buf, long n_doubles, void *user);
 int balm_set_allreduce(balm_ctx *ctx, balm_allreduce_fn fn, void *user);
 

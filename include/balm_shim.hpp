@@ -28,6 +28,8 @@ class BALM2_HIP {
   int min_planes_per_pose = 20;
   int form = BALM_FORM_LEFT;   // bavoxel.hpp:1109 (left) vs :1108 (right, commented out there)
   int device = 0;
+  int n_devices = 0;           // >= 1: balm_create_multi over devices device..device+n_devices-1 (features sharded, one RCCL
+                               // all-reduce per evaluation inside the library; replaces the thread sum at bavoxel.hpp:1049-1056)
   bool verbose = true;         // the reference always prints its per-iteration line (:1132)
   bool reanchor = true;        // bavoxel.hpp:1159-1164 (the consistency driver does not: BAs_left.hpp:1087)
   double abs_tol = 0;          // > 0: the consistency driver's stop rule |r1-r2| < 1e-9 (BAs_left.hpp:1083)
@@ -180,7 +182,7 @@ class BALM2_HIP {
   void ensure_ctx() {
     if (ctx_ && ctx_win_ == win_size) return;
     if (ctx_) balm_destroy(ctx_);
-    ctx_ = balm_create(win_size, device, 0);
+    ctx_ = n_devices >= 1 ? balm_create_multi(win_size, device, n_devices, 0) : balm_create(win_size, device, 0);
     ctx_win_ = win_size;
     loaded_ = nullptr;
     if (!ctx_) {

@@ -33,7 +33,8 @@ class BALM2_HIP {
   double rel_tol = 1e-6;
   int form = BALM_FORM_LEFT;   // :413 (left) vs :412 (right, commented out there)
   int device = 0;              // first device
-  int n_devices = 1;           // > 1: features sharded over devices device..device+n_devices-1, RCCL reduce inside the library
+  int n_devices = 0;           // >= 1: balm_create_multi over devices device..device+n_devices-1 (features sharded, RCCL
+                               // reduce inside the library); 0 = one device without a collective path
   bool verbose = true;         // the reference always prints its per-iteration line (:428)
   int winSize = 0;             // public member of the reference's class (:109), set by dampingIter (:381)
   std::vector<balm_iter_log> last_log;
@@ -51,7 +52,7 @@ class BALM2_HIP {
     const int W = winSize, F = (int)plSurfs.size();
     if (!ctx_ || ctx_win_ != W) {
       if (ctx_) balm_destroy(ctx_);
-      ctx_ = n_devices > 1 ? balm_create_multi(W, device, n_devices, 0) : balm_create(W, device, 0);
+      ctx_ = n_devices >= 1 ? balm_create_multi(W, device, n_devices, 0) : balm_create(W, device, 0);
       ctx_win_ = W;
       if (!ctx_) {
         fprintf(stderr, "balm_hip: balm_create(win_size=%d, device=%d, n_devices=%d) failed: no MI355X / libbalm_hip.so?\n",

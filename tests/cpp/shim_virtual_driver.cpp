@@ -71,7 +71,8 @@ int main(int argc, char **argv) {
   BALM2 bm;
   const double t_ref = bm.dampingIter(x_ref, plSurfs);
   BALM2_HIP bh;
-  bh.n_devices = ndev;
+  const bool multi = ndev > 1 || getenv("BALM_SHIM_FORCE_MULTI") != nullptr;      // one device through balm_create_multi + RCCL
+  bh.n_devices = multi ? ndev : 0;
   const double t_hip = bh.dampingIter(x_hip, plSurfs);
   double rot_ref, tr_ref, rot_hip, tr_hip;
   rsme(x_ref, rot_ref, tr_ref);
@@ -83,7 +84,7 @@ int main(int argc, char **argv) {
   }
   const bool anchored = (x_hip[0].R - Eigen::Matrix3d::Identity()).norm() == 0 && x_hip[0].p.norm() == 0;
   printf("SHIM_VIRTUAL W=%d F=%d pts=%d devices=%d iters_hip=%zu max_rot=%.3e max_trans=%.3e rsme_ref=%.6fdeg,%.6fm "
-         "rsme_hip=%.6fdeg,%.6fm seconds_ref=%.4f seconds_hip=%.4f anchored=%d\n", W, F, pts, ndev, bh.last_log.size(), max_rot,
-         max_tr, rot_ref * 57.3, tr_ref, rot_hip * 57.3, tr_hip, t_ref, t_hip, (int)anchored);
+         "rsme_hip=%.6fdeg,%.6fm seconds_ref=%.4f seconds_hip=%.4f anchored=%d multi=%d\n", W, F, pts, ndev, bh.last_log.size(), max_rot,
+         max_tr, rot_ref * 57.3, tr_ref, rot_hip * 57.3, tr_hip, t_ref, t_hip, (int)anchored, (int)multi);
   return (max_rot <= 1e-5 && max_tr <= 1e-4 && anchored) ? 0 : 1;
 }

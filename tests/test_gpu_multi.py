@@ -1,0 +1,124 @@
+"""Multi-GPU inside the library (balm_create_multi, balm_comm_init_rank) on the one GPU a test box has:
+
+  * n_devices = 1 and a single-rank communicator go through the real RCCL calls (ncclCommInitAll / ncclCommInitRank /
+    stream-ordered ncclAllReduce) and must reproduce the plain context bit for bit;
+  * BALM_FLAG_LOOPBACK_SHARDS runs 2..4 feature shards with their own streams, host threads and replicated solves
+    on the one device (in-library sum instead of RCCL -- a communicator cannot hold a device twice) and must
+    reproduce the single-context results: evaluation, sub-ranges, residual, the LM trajectory, the covariance, and the
+    stages that build the features on the device.
+RCCL over more than one physical GPU cannot run here (SCALE_*.json is the driver's to measure)."""
+import numpy as np
+import pytest
+
+from balm_amd import capi
+from util import make_scene, pose_errors, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def single(sc, fix=None):
+    c = capi.Context(sc.W)
+    c.set_features(sc.clusters, fix, sc.coeffs)
+    return c
+
+
+@pytest.mark.parametrize("how", ["create_multi", "comm_init_rank"])
+def test_one_rank_through_rccl_is_bit_identical(how):
+    sc, _ = make_scene(5, 24, 300, 8, drop=0.3)
+    a = single(sc)
+    if how == "create_multi":
+        b = capi.Context(sc.W, n_devices=1)
+    else:
+        b = capi.Context(sc.W)
+        b.comm_init_rank(1, 0, capi.Context.comm_unique_id())
+    b.set_features(sc.clusters, None, sc.coeffs)
+    Ha, ga, ra = a.evaluate(0, sc.poses_init)
+    Hb, gb, rb = b.evaluate(0, sc.poses_init)
+    assert np.array_equal(Ha, Hb) and np.array_equal(ga, gb) and ra == rb
+    pa, la = a.damping_iter(sc.poses_init, u0=0.1, max_iter=20, min_planes=20)
+    pb, lb = b.damping_iter(sc.poses_init, u0=0.1, max_iter=20, min_planes=20)
+    assert np.array_equal(la, lb) and np.array_equal(pa, pb)
+    a.close(); b.close()
+
+
+@pytest.mark.parametrize("n", [2, 3, 4])
+def test_loopback_shards_reproduce_single_context(n):
+    sc, fix = make_scene(6 + n, 33, 401, 8, drop=0.4, with_fix=True)
+    a = single(sc, fix)
+    b = capi.Context(sc.W, 0, capi.FLAG_LOOPBACK_SHARDS, n_devices=n)
+    b.set_features(sc.clusters, fix, sc.coeffs)
+    for form in (0, 1):
+        Ha, ga, ra = a.evaluate(form, sc.poses_init)
+        Hb, gb, rb = b.evaluate(form, sc.poses_init)
+        assert rel_err(Hb, Ha) < 1e-12 and rel_err(gb, ga) < 1e-12 and abs(ra - rb) / ra < 1e-13
+    # a sub-range that leaves one shard without work
+    lo, hi = 7, 401 // n - 3
+    Ha, ga, ra = a.evaluate(0, sc.poses_init, lo, hi)
+    Hb, gb, rb = b.evaluate(0, sc.poses_init, lo, hi)
+    assert rel_err(Hb, Ha) < 1e-12 and rel_err(gb, ga) < 1e-12 and abs(ra - rb) / ra < 1e-13
+    assert abs(a.only_residual(sc.poses_init) - b.only_residual(sc.poses_init)) / ra < 1e-13
+    pa, la = a.damping_iter(sc.poses_init, u0=0.01, max_iter=10, min_planes=20)
+    pb, lb = b.damping_iter(sc.poses_init, u0=0.01, max_iter=10, min_planes=20)
+    assert len(la) == len(lb) and np.array_equal(la[:, 6], lb[:, 6])
+    assert np.allclose(la[:, :2], lb[:, :2], rtol=1e-9, atol=0)
+    rot, tr = pose_errors(pa, pb)
+    assert rot.max() < 1e-9 and tr.max() < 1e-9
+    wa, wb = a.work_model(), b.work_model()
+    assert wa == wb
+    a.close(); b.close()
+
+
+def test_loopback_shards_too_few_planes_is_decided_on_global_counts():
+    sc, _ = make_scene(3, 12, 30, 8, drop=0.2)      # 30 features over 3 shards: no shard sees 20 planes per pose, the window does
+    assert (sc.clusters[..., 9] > 0).sum(0).min() >= 20
+    b = capi.Context(sc.W, 0, capi.FLAG_LOOPBACK_SHARDS, n_devices=3)
+    b.set_features(sc.clusters, None, sc.coeffs)
+    a = single(sc)
+    pa, la = a.damping_iter(sc.poses_init, min_planes=20)
+    pb, lb = b.damping_iter(sc.poses_init, min_planes=20)
+    assert len(la) == len(lb)
+    with pytest.raises(capi.BalmError) as e:
+        b.damping_iter(sc.poses_init, min_planes=29)
+    assert e.value.code == capi.ERR_TOO_FEW_PLANES
+    a.close(); b.close()
+
+
+def test_loopback_shards_device_built_features_and_covariance():
+    from balm_amd import scene
+    sc = scene.generate(9, 16, 120, 12, keep_points=True)
+    F, W, pts = sc.F, sc.W, sc.pts
+    feat = np.repeat(np.arange(F, dtype=np.int32), W * pts)
+    pose = np.tile(np.repeat(np.arange(W, dtype=np.int32), pts), F)
+    a = capi.Context(W)
+    b = capi.Context(W, 0, capi.FLAG_LOOPBACK_SHARDS, n_devices=2)
+    ca = a.build_clusters(F, sc.points.reshape(-1, 3), feat, pose, None, sc.coeffs)
+    cb = b.build_clusters(F, sc.points.reshape(-1, 3), feat, pose, None, sc.coeffs)
+    assert rel_err(cb, ca) < 1e-14
+    pa, la = a.damping_iter(sc.poses_init, u0=0.1, max_iter=20)
+    pb, lb = b.damping_iter(sc.poses_init, u0=0.1, max_iter=20)
+    assert len(la) == len(lb)
+    rot, tr = pose_errors(pa, pb)
+    assert rot.max() < 1e-9 and tr.max() < 1e-9
+    # covariance needs a gauge anchor: a fix cluster per feature
+    sc2, fix = make_scene(4, 10, 60, 10, with_fix=True)
+    a2, b2 = single(sc2, fix), capi.Context(sc2.W, 0, capi.FLAG_LOOPBACK_SHARDS, n_devices=3)
+    b2.set_features(sc2.clusters, fix, sc2.coeffs)
+    Ra, Rra = a2.pose_covariance(sc2.poses_gt, None, 0.02)
+    Rb, Rrb = b2.pose_covariance(sc2.poses_gt, None, 0.02)
+    assert rel_err(Rrb, Rra) < 1e-11 and rel_err(Rb, Ra) < 1e-8
+    for c in (a, b, a2, b2):
+        c.close()
+
+
+def test_cpp_virtual_driver_with_n_devices_goes_through_rccl():
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "oracle", "_ref", "shim_virtual_driver")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/shim_virtual_driver not built (needs /root/reference at build time)")
+    env = dict(os.environ, BALM_SHIM_FORCE_MULTI="1")
+    p = subprocess.run([exe, "3", "20", "150", "40", "1", os.path.join(root, "balm_amd", "lib", "libbalm_scene.so")],
+                       cwd=root, capture_output=True, text=True, timeout=600, env=env)
+    line = [l for l in p.stdout.splitlines() if l.startswith("SHIM_VIRTUAL")]
+    assert p.returncode == 0 and line and "multi=1" in line[0], (p.returncode, p.stdout[-800:], p.stderr[-800:])
