@@ -22,7 +22,7 @@ TIMING_NAMES = ["moments", "factors", "syrk", "assemble", "solve", "update", "bu
 EXPORTS = ["balm_create", "balm_create_multi", "balm_destroy", "balm_set_features", "balm_evaluate", "balm_only_residual",
            "balm_solve_damped", "balm_damping_iter", "balm_build_clusters", "balm_voxel_defaults", "balm_associate", "balm_get_features", "balm_get_association", "balm_pose_covariance",
            "balm_set_allreduce", "balm_comm_unique_id", "balm_comm_init_rank",
-           "balm_get_timing", "balm_reset_timing", "balm_work_model", "balm_last_error", "balm_version"]
+           "balm_get_timing", "balm_get_solve_trace", "balm_reset_timing", "balm_work_model", "balm_last_error", "balm_version"]
 
 
 class IterLog(C.Structure):
@@ -87,6 +87,7 @@ def lib():
         L.balm_comm_unique_id.argtypes = [C.c_void_p]
         L.balm_comm_init_rank.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.balm_get_timing.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.balm_get_solve_trace.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_void_p]
         L.balm_reset_timing.argtypes = [C.c_void_p]
         L.balm_work_model.argtypes = [C.c_void_p, C.c_void_p]
         L.balm_last_error.restype = C.c_char_p
@@ -279,6 +280,16 @@ class Context:
         cnt = np.zeros(T_COUNT, dtype=np.int64)
         self._check(self.L.balm_get_timing(self.h, _p(ms), _p(cnt)))
         return {TIMING_NAMES[k]: (float(ms[k]), int(cnt[k])) for k in range(T_COUNT)}
+
+    def solve_trace(self):
+        """[2P+1, P, 6] wall-clock ticks (100 MHz) of the last persistent factorisation (needs BALM_SOLVE_TRACE=1)"""
+        dims = (C.c_int * 3)()
+        self.L.balm_get_solve_trace(self.h, None, 0, dims)
+        n6 = dims[0] * dims[1] * dims[2]
+        out = np.zeros(n6 + 6 * dims[1], dtype=np.int64)
+        self._check(self.L.balm_get_solve_trace(self.h, _p(out), out.size, dims))
+        self.step_phases = out[n6:].reshape(dims[1], 6)      # per column: sums over the 12 steps of publish+barrier | pivot+rows | barrier | operands+MFMA
+        return out[:n6].reshape(dims[0], dims[1], dims[2])
 
     def reset_timing(self):
         self._check(self.L.balm_reset_timing(self.h))

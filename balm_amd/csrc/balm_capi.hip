@@ -5,6 +5,7 @@
 #include <array>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "balm_internal.h"
@@ -285,13 +286,18 @@ balm_ctx *balm_create(int win_size, int device, int flags) {
       dalloc(ctx, &ctx->d_H, (size_t)n * n) || dalloc(ctx, &ctx->d_g, (size_t)n) ||
       dalloc(ctx, &ctx->d_A, (size_t)(2 * nA + NB) * nA) || dalloc(ctx, &ctx->d_Wp, (size_t)NB * (2 * nA + NB)) ||
       dalloc(ctx, &ctx->d_dvec, (size_t)nA) || dalloc(ctx, &ctx->d_z, (size_t)nA) || dalloc(ctx, &ctx->d_x, (size_t)16 * nA) ||
-      dalloc(ctx, &ctx->d_perm, (size_t)nA) || dalloc(ctx, &ctx->d_dx, (size_t)n) ||
+      dalloc(ctx, &ctx->d_perm, (size_t)nA) || dalloc(ctx, &ctx->d_flags, (size_t)2 * (2 * (nA / NB) + 1) * (nA / NB)) || dalloc(ctx, &ctx->d_dx, (size_t)n) ||
       dalloc(ctx, &ctx->d_scal, (size_t)16) || dalloc(ctx, &ctx->d_pre, (size_t)W + 2))
     return fail();
   if (hipHostMalloc((void **)&ctx->h_scal, 16 * sizeof(double)) != hipSuccess) return fail();
   if (hipMemcpy(ctx->d_jobs, jobs.data(), jobs.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess ||
       hipMemcpy(ctx->d_sub, sub.data(), sub.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess)
     return fail();
+  if (getenv("BALM_SOLVE_TRACE")) {
+    const size_t cnt = (size_t)(2 * (nA / NB) + 1) * (nA / NB) * 6 + (size_t)(nA / NB) * 6;
+    if (hipMalloc((void **)&ctx->d_trace, cnt * sizeof(long long)) != hipSuccess) return fail();
+    hipMemset(ctx->d_trace, 0, cnt * sizeof(long long));
+  }
   {   // a valid permutation from the start (a NaN diagonal must not leave slots unwritten, see k_rank_diag)
     std::vector<int> ident(nA);
     for (int i = 0; i < nA; i++) ident[i] = i;
@@ -309,7 +315,7 @@ static void one_destroy(balm_ctx *ctx) {
   if (ctx->stream) hipStreamSynchronize(ctx->stream);
   void *ptrs[] = {ctx->d_cl, ctx->d_fix, ctx->d_coe, ctx->d_poses, ctx->d_poses_tmp, ctx->d_C, ctx->d_feat,
                   ctx->d_Gt, ctx->d_part, ctx->d_dpart, ctx->d_rpart, ctx->d_feat_tmp, ctx->d_rpart_tmp, ctx->d_red, ctx->d_jobs, ctx->d_sub, ctx->d_H,
-                  ctx->d_g, ctx->d_A, ctx->d_Wp, ctx->d_dvec, ctx->d_z, ctx->d_x, ctx->d_perm, ctx->d_dx, ctx->d_scal, ctx->d_arena, ctx->d_pre};
+                  ctx->d_g, ctx->d_A, ctx->d_Wp, ctx->d_dvec, ctx->d_z, ctx->d_x, ctx->d_perm, ctx->d_dx, ctx->d_scal, ctx->d_arena, ctx->d_pre, ctx->d_flags, ctx->d_trace};
   for (void *p : ptrs) if (p) hipFree(p);
   if (ctx->h_scal) hipHostFree(ctx->h_scal);
   for (auto &sp : ctx->timer.pending) { hipEventDestroy(sp.a); hipEventDestroy(sp.b); }
@@ -888,6 +894,18 @@ int balm_pose_covariance(balm_ctx *ctx, const double *poses, const double *clust
     return one_pose_covariance(m->sub[(size_t)k], poses, cluster_cov ? cluster_cov + f0 * W * 81 : nullptr, point_sigma,
                                k ? nullptr : Rcov, k ? nullptr : Rcov_raw);
   });
+}
+
+int balm_get_solve_trace(balm_ctx *ctx, long long *ticks, long capacity, int *dims3) {
+  if (!ctx || !dims3) return BALM_ERR_ARG;
+  const int P = ctx->nA / NB, RB = 2 * P + 1;
+  dims3[0] = RB; dims3[1] = P; dims3[2] = 6;          // + P x 6 step-phase sums of the right-hand-side block's workgroup
+  if (!ctx->d_trace) { ctx->err = "balm_get_solve_trace: create the context with BALM_SOLVE_TRACE=1 in the environment"; return BALM_ERR_STATE; }
+  if (!ticks || capacity < (long)RB * P * 6 + 6L * P) { ctx->err = "balm_get_solve_trace: buffer too small"; return BALM_ERR_ARG; }
+  HIP_TRY(hipSetDevice(ctx->device));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  HIP_TRY(hipMemcpy(ticks, ctx->d_trace, ((size_t)RB * P * 6 + 6 * (size_t)P) * sizeof(long long), hipMemcpyDeviceToHost));
+  return BALM_OK;
 }
 
 int balm_get_timing(balm_ctx *ctx, double *ms, long *count) {

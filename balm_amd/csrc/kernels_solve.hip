@@ -17,6 +17,8 @@
 //                     -- into ONE matrix-vector product  x = M (D z)  (k_ldl_apply).
 // Pose update kernels (bavoxel.hpp:1116-1126, 1159-1164) live here too.
 #include <cfloat>
+#include <cstdlib>
+#include <cstring>
 
 #include "balm_internal.h"
 
@@ -63,9 +65,10 @@ __global__ __launch_bounds__(256) void k_rank_diag(const double *__restrict__ H,
 
 __global__ __launch_bounds__(256) void k_build_A(const double *__restrict__ H, const double *__restrict__ g, int n,
                                                  int nA, const int *__restrict__ perm, double u,
-                                                 double *__restrict__ A) {
+                                                 double *__restrict__ A, int *__restrict__ flags, int nflags) {
   const int ldA = 2 * nA + NB;
   const long total = (long)ldA * nA;
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < nflags; t += (long)gridDim.x * blockDim.x) flags[t] = 0;
   for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
     const int c = (int)(t / ldA), r = (int)(t - (long)c * ldA);
     const int pc = perm[c];
@@ -119,6 +122,36 @@ __device__ __forceinline__ double rcp_nr(double d) {        // 1/d: v_rcp_f64 + 
   return (fabs(d) > DBL_MIN) ? x : 0.0;                      // Eigen's D^+ rule for a vanished pivot
 }
 
+// LDL^T of the 4x4 pivot block of a rank-4 step (D^+ rule per pivot).  Measured and rejected: the four pivots from
+// division-free leading minors with four independent reciprocals (dependency depth 14 instead of 33): 100 ns SLOWER per
+// step -- the phase is bound by the number of f64 VALU operations a lone wave issues (~3.3 ns each), not by their
+// dependencies, and the minor form has ~30 more of them.
+struct Pivot4 { double d0, d1, d2, d3, i0, i1, i2, i3, l10, l20, l30, l21, l31, l32; };
+
+__device__ __forceinline__ void pivot4(double a00, double a10, double a20, double a30, double a11, double a21, double a31,
+                                       double a22, double a32, double a33, Pivot4 &o) {
+  o.d0 = a00; o.i0 = rcp_nr(o.d0);
+  o.l10 = a10 * o.i0; o.l20 = a20 * o.i0; o.l30 = a30 * o.i0;
+  o.d1 = __builtin_fma(-o.l10, a10, a11); o.i1 = rcp_nr(o.d1);
+  const double w21 = __builtin_fma(-o.l20, a10, a21), w31 = __builtin_fma(-o.l30, a10, a31);
+  o.l21 = w21 * o.i1; o.l31 = w31 * o.i1;
+  o.d2 = __builtin_fma(-o.l21, w21, __builtin_fma(-o.l20, a20, a22)); o.i2 = rcp_nr(o.d2);
+  const double w32 = __builtin_fma(-o.l31, w21, __builtin_fma(-o.l30, a20, a32));
+  o.l32 = w32 * o.i2;
+  o.d3 = __builtin_fma(-o.l32, w32, __builtin_fma(-o.l31, w31, __builtin_fma(-o.l30, a30, a33)));
+  o.i3 = rcp_nr(o.d3);
+}
+
+// a row's rank-4 pieces: w = L4^-1 r (forward substitution), e = w D4^-1
+__device__ __forceinline__ void row4(const Pivot4 &v, double r0, double r1, double r2, double r3, double &w0, double &w1,
+                                     double &w2, double &w3, double &e0, double &e1, double &e2, double &e3) {
+  w0 = r0;
+  w1 = __builtin_fma(-v.l10, r0, r1);
+  w2 = __builtin_fma(-v.l21, w1, __builtin_fma(-v.l20, r0, r2));
+  w3 = __builtin_fma(-v.l32, w2, __builtin_fma(-v.l31, w1, __builtin_fma(-v.l30, r0, r3)));
+  e0 = w0 * v.i0; e1 = w1 * v.i1; e2 = w2 * v.i2; e3 = w3 * v.i3;
+}
+
 __global__ __launch_bounds__(256) void k_ldl_panel(double *__restrict__ A, int nA, int c0, int nR,
                                                    double *__restrict__ dvec, double *__restrict__ Wp,
                                                    double *__restrict__ zvec) {
@@ -160,33 +193,18 @@ __global__ __launch_bounds__(256) void k_ldl_panel(double *__restrict__ A, int n
     const double a00 = cur[0][p0], a10 = cur[0][p0 + 1], a20 = cur[0][p0 + 2], a30 = cur[0][p0 + 3];
     const double a11 = cur[1][p0 + 1], a21 = cur[1][p0 + 2], a31 = cur[1][p0 + 3];
     const double a22 = cur[2][p0 + 2], a32 = cur[2][p0 + 3], a33 = cur[3][p0 + 3];
-    const double d0 = a00, i0 = rcp_nr(d0);
-    const double l10 = a10 * i0, l20 = a20 * i0, l30 = a30 * i0;
-    const double d1 = __builtin_fma(-l10, a10, a11), i1 = rcp_nr(d1);
-    const double w21 = __builtin_fma(-l20, a10, a21), w31 = __builtin_fma(-l30, a10, a31);
-    const double l21 = w21 * i1, l31 = w31 * i1;
-    const double d2 = __builtin_fma(-l21, w21, __builtin_fma(-l20, a20, a22)), i2 = rcp_nr(d2);
-    const double w32 = __builtin_fma(-l31, w21, __builtin_fma(-l30, a20, a32));
-    const double l32 = w32 * i2;
-    const double d3 = __builtin_fma(-l32, w32, __builtin_fma(-l31, w31, __builtin_fma(-l30, a30, a33)));
-    const double i3 = rcp_nr(d3);
-    // M4 = L4^-1 (unit lower)
-    const double m10 = -l10, m21 = -l21, m32 = -l32;
-    const double m20 = __builtin_fma(l21, l10, -l20);
-    const double m31 = __builtin_fma(l32, l21, -l31);
-    const double m30 = -l30 - l31 * m10 - l32 * m20;
+    const int lrq = tid < PANEL_LR ? tid : PANEL_LR - 1;     // this thread's row, requested together with the pivot block
+    double r0 = cur[0][lrq], r1 = cur[1][lrq], r2 = cur[2][lrq], r3 = cur[3][lrq];
+    asm volatile("" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3));
+    Pivot4 pv;
+    pivot4(a00, a10, a20, a30, a11, a21, a31, a22, a32, a33, pv);
+    const double d0 = pv.d0, d1 = pv.d1, d2 = pv.d2, d3 = pv.d3;
+    const double l10 = pv.l10, l20 = pv.l20, l30 = pv.l30, l21 = pv.l21, l31 = pv.l31, l32 = pv.l32;
     if (tid < PANEL_LR) {
       const int lr = tid;
-      const double r0 = cur[0][lr], r1 = cur[1][lr], r2 = cur[2][lr], r3 = cur[3][lr];
       double w0 = 0, w1 = 0, w2 = 0, w3 = 0, e0 = 0, e1 = 0, e2 = 0, e3 = 0;
       const bool below = lr > p0 + 3;                      // rows still to be eliminated
-      if (below) {
-        w0 = r0;
-        w1 = __builtin_fma(m10, r0, r1);
-        w2 = __builtin_fma(m21, r1, __builtin_fma(m20, r0, r2));
-        w3 = __builtin_fma(m32, r2, __builtin_fma(m31, r1, __builtin_fma(m30, r0, r3)));
-        e0 = w0 * i0; e1 = w1 * i1; e2 = w2 * i2; e3 = w3 * i3;
-      }
+      if (below) row4(pv, r0, r1, r2, r3, w0, w1, w2, w3, e0, e1, e2, e3);
       Wop[0][lr] = -w0; Wop[1][lr] = -w1; Wop[2][lr] = -w2; Wop[3][lr] = -w3;
       Lop[0][lr] = e0; Lop[1][lr] = e1; Lop[2][lr] = e2; Lop[3][lr] = e3;
       // ---- stream the results out ----
@@ -277,6 +295,300 @@ __global__ __launch_bounds__(256) void k_ldl_trail(double *__restrict__ A, int n
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_ldl_fused: the whole blocked factorisation (every panel, every trailing update) in ONE persistent launch.
+//
+// The per-panel launch pair above is a chain of 2 P dependent kernels whose cost is launch + first-load latency
+// (~5 us each), not work.  Here the workgroups of one cooperative launch talk through flags in HBM instead
+// (0.7-0.8 us per hop on gfx950, profiles/r02a_ubench_sync.txt):
+//
+//   panel workgroup rb (one per 48-row block of the tall matrix [A ; rhs tile ; identity]) walks the column blocks p in
+//     which its tile (rb, p) is live.  Per column: it loads its tile and the diagonal tile (p, p) -- both carry the "far"
+//     updates of panels <= p-2, applied by the helpers -- subtracts the "near" update of panel p-1 itself (its own
+//     L[rb, p-1] is still in LDS, L[p, p-1] comes from workgroup p), then runs the twelve rank-4 steps of k_ldl_panel:
+//     the diagonal block redundantly, its own 48 rows riding along (TRSM for free).  No tile travels through memory
+//     between the near update and the factorisation, and nobody waits for a trailing-update kernel: the critical path
+//     per panel is   factor -> flag -> 18 KB of L[p+1, p] -> 180 MFMAs -> factor.
+//   helper workgroups own the tiles to the right of the next column: tile (rb, j) -= L[rb, q] D_q L[j, q]^T for every
+//     panel q <= j-2, in order, each as soon as the two L blocks are published.  One helper owns one tile for the whole
+//     factorisation (fixed owner = program order between its updates, no flags among helpers).
+//   done[rb][p]  set by panel workgroup rb when L[rb, p] (and, for rb == p, L11 and D) are in memory
+//   far[rb][j]   set by the owner of tile (rb, j) after its last far update (q == j-2)
+// Every wait is on a strictly earlier column, all workgroups are co-resident (cooperative launch): no deadlock.
+// Same elimination order, pivot-block code and D^+ rule as the launch pair; a tile's updates arrive in panel order.  The
+// one difference: W = L D is re-formed from L (one rounding) instead of being kept from the step that produced it, so
+// the two paths agree to ~1e-15, not bit for bit (tests/test_gpu_solve.py compares them and both with LAPACK).
+//
+// Measured (profiles/r02*_solve*.txt, n = 1200): 14 us per panel = 8.2 us for the twelve rank-4 steps (a step is
+// ~0.7 us: ~110 VALU instructions of ONE wavefront -- pivot recurrence, the rows' forward substitution, operand
+// staging -- issue-bound at ~3 ns each, plus two LDS round trips of ~100 ns; not flops, not barriers), 3.5 us near
+// update (18 KB of L[p, p-1] from the neighbour + 180 MFMAs on one CU), ~1.5 us flag hop / tile loads / write-out.
+// The launch pair spends ~20 us per panel.  Fused wins for 10 <= P <= 40 panels (0.42 vs 0.51 ms at n = 1200, 0.39 vs
+// 0.46 ms at the shipped window's n = 1062); below that its fixed cost (cooperative launch, idle helpers) shows, above
+// it the helpers (one CU per tile update, operands re-read per update) fall behind the trailing-update kernel.
+// ------------------------------------------------------------------------------------------------
+constexpr int FT = 576;                         // 9 wavefronts: one per 16x16 sub-tile of a 48x48 tile
+constexpr int FLR = 2 * NB;                     // local rows of a panel workgroup: 48 diagonal + 48 own
+
+__device__ __forceinline__ int flag_peek(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void flag_wait(const int *p) {
+  while (flag_peek(p) == 0) __builtin_amdgcn_s_sleep(1);
+}
+// Publishing without an L2 write-back: what other workgroups will read is stored write-through (agent-scope stores
+// carry sc1 on gfx950), so "all my stores have been acknowledged" (vmcnt 0) + workgroup barrier is a release, and the
+// flag itself is another write-through store.  (buffer_wbl2 per publish cost 3-5 us: it writes back every dirty line of
+// the XCD's L2, the helpers' tiles included.)
+__device__ __forceinline__ void st_wt(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void publish(int *flag) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+struct FusedArgs {
+  double *A; double *dvec; double *zvec; int *done; int *far;
+  int nA, P, RB, NH;
+  long long *trace;       // diagnostics (BALM_SOLVE_TRACE): [RB][P][6] wall-clock ticks of a panel workgroup's phases, or null
+};
+#define FUSED_TRACE(slot) do { if (a.trace && tid == 0) a.trace[((size_t)rb * P + p) * 6 + (slot)] = wall_clock64(); } while (0)
+
+// sub-tiles of a panel workgroup's 96 x 48 window (row tile rt: 0..2 diagonal block, 3..5 own rows; column tile ct),
+// the strictly upper ones of the diagonal block left out.  Slots 0..8 (one per wave) are the tiles with ct >= 1, which
+// stay live while the factorisation moves right; slots 9..14 (second slot of waves 0..5) are the ct == 0 tiles.
+__device__ __forceinline__ void fused_slot(int s, int &rt, int &ct) {
+  const int RT[15] = {1, 2, 3, 4, 5, 2, 3, 4, 5, 0, 1, 2, 3, 4, 5};
+  const int CT[15] = {1, 1, 1, 1, 1, 2, 2, 2, 2, 0, 0, 0, 0, 0, 0};
+  rt = RT[s]; ct = CT[s];
+}
+
+__device__ void fused_panel_role(const FusedArgs &a, int rb, double *lds) {
+  const int nA = a.nA, P = a.P, ldA = 2 * nA + NB;
+  double *__restrict__ A = a.A;
+  double (*cur)[FLR] = reinterpret_cast<double (*)[FLR]>(lds);             // [4][96] the four current columns
+  double (*Wop)[FLR] = reinterpret_cast<double (*)[FLR]>(lds + 4 * FLR);   // [4][96] -W
+  double (*Lop)[FLR] = reinterpret_cast<double (*)[FLR]>(lds + 8 * FLR);   // [4][96]  L
+  double (*Lsave)[NB] = reinterpret_cast<double (*)[NB]>(lds + 12 * FLR);              // [48 k][48 own rows]  L[rb, p]
+  double (*Lnext)[NB] = reinterpret_cast<double (*)[NB]>(lds + 12 * FLR + NB * NB);     // [48 k][48 rows]      L[p, p-1]
+  double *dsave = lds + 12 * FLR + 2 * NB * NB;                                          // [48] D of the last panel
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int l15 = lane & 15, l4 = lane >> 4;
+  const int tI = rb - P - 1;                                 // identity block index (rb > P)
+  const int c_first = rb <= P ? 0 : tI, c_last = rb < P ? rb : P - 1;
+  const int rowbase = rb < P ? NB * rb : (rb == P ? nA : nA + NB + NB * tI);
+  int srt[2], sct[2];
+  fused_slot(wv, srt[0], sct[0]);
+  const bool two = wv < 6;
+  if (two) fused_slot(9 + wv, srt[1], sct[1]); else { srt[1] = 5; sct[1] = 0; }
+
+  for (int p = c_first; p <= c_last; p++) {
+    const int c0 = NB * p;
+    const bool own = rb != p;                                // rb == p: the diagonal block's owner, no rows below
+    const bool had_prev = p > c_first;                       // L[rb, p-1] exists (still in Lsave)
+    FUSED_TRACE(0);
+    // ---- tiles with their far updates ----
+    if (tid == 0) {
+      if (own && p - c_first >= 2) flag_wait(a.far + (size_t)rb * P + p);
+      if (p >= 2) flag_wait(a.far + (size_t)p * P + p);
+      if (p >= 1 && rb != p) flag_wait(a.done + (size_t)p * P + (p - 1));            // L[p, p-1]
+      if (p >= 1 && !had_prev) flag_wait(a.done + (size_t)(p - 1) * P + (p - 1));    // D of panel p-1 from its owner
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+    FUSED_TRACE(1);
+    d4 acc[2];
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+      const int rt = srt[s], ct = sct[s];
+      const bool live = (s == 0 || two) && (rt < 3 || own);
+      const int gr = rt < 3 ? c0 + rt * 16 + l15 : rowbase + (rt - 3) * 16 + l15;
+#pragma unroll
+      for (int e = 0; e < 4; e++)
+        acc[s][e] = live ? A[(size_t)(c0 + ct * 16 + l4 + 4 * e) * ldA + gr] : 0.0;
+    }
+    FUSED_TRACE(2);
+    // ---- near update: panel p-1 on the diagonal tile (always) and on the own tile (if it was live there) ----
+    if (p >= 1) {
+      const int cp = c0 - NB;
+      if (rb == p) {                                         // own rows of the last column ARE block p
+        for (int i = tid; i < NB * NB; i += FT) (&Lnext[0][0])[i] = (&Lsave[0][0])[i];
+      } else {
+        for (int i = tid; i < NB * NB; i += FT) {
+          const int k = i / NB, r = i - k * NB;
+          Lnext[k][r] = A[(size_t)(cp + k) * ldA + c0 + r];
+        }
+      }
+      if (!had_prev && tid < NB) dsave[tid] = a.dvec[cp + tid];
+      __syncthreads();
+      // a dependent MFMA chain issues every ~81 ns, independent ones every ~60: the k range of every sub-tile goes to
+      // two accumulators, and the two sub-tiles of a wave alternate
+      d4 part[2] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
+      bool live[2];
+#pragma unroll
+      for (int s = 0; s < 2; s++) live[s] = (s == 0 || two) && (srt[s] < 3 || (own && had_prev));
+#pragma unroll
+      for (int kc = 0; kc < NB / 4; kc++) {
+        const int k = 4 * kc + l4;
+        const double dk = dsave[k];
+#pragma unroll
+        for (int s = 0; s < 2; s++) {
+          if (live[s]) {
+            const int rt = srt[s], ct = sct[s];
+            const double aop = Lnext[k][ct * 16 + l15];
+            const double lrow = rt < 3 ? Lnext[k][rt * 16 + l15] : Lsave[k][(rt - 3) * 16 + l15];
+            if (kc & 1) part[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, -(lrow * dk), part[s], 0, 0, 0);
+            else acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, -(lrow * dk), acc[s], 0, 0, 0);
+          }
+        }
+      }
+#pragma unroll
+      for (int s = 0; s < 2; s++)
+#pragma unroll
+        for (int e = 0; e < 4; e++) acc[s][e] += part[s][e];
+      __syncthreads();                                       // Lsave / dsave are rewritten by the steps below
+    }
+    FUSED_TRACE(3);
+    long long tph[6] = {0, 0, 0, 0, 0, 0};
+    const bool tracer = a.trace && rb == P && tid == 0;
+    // ---- twelve rank-4 steps (k_ldl_panel's arithmetic) ----
+#pragma unroll
+    for (int q = 0; q < NB / 4; q++) {
+      const int jt = q >> 2, qq = q & 3;
+      long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0;
+      if (tracer) ts0 = wall_clock64();
+#pragma unroll
+      for (int s = 0; s < 2; s++)
+        if ((s == 0 || two) && sct[s] == jt) cur[l4][srt[s] * 16 + l15] = acc[s][qq];
+      __syncthreads();
+      if (tracer) ts1 = wall_clock64();
+      const int p0 = 4 * q;
+      const double a00 = cur[0][p0], a10 = cur[0][p0 + 1], a20 = cur[0][p0 + 2], a30 = cur[0][p0 + 3];
+      const double a11 = cur[1][p0 + 1], a21 = cur[1][p0 + 2], a31 = cur[1][p0 + 3];
+      const double a22 = cur[2][p0 + 2], a32 = cur[2][p0 + 3], a33 = cur[3][p0 + 3];
+      // this thread's row, requested together with the pivot block (an LDS round trip is ~100 ns in this kernel: it must
+      // overlap with the pivot chain instead of following it)
+      const int lrq = tid < FLR ? tid : FLR - 1;
+      double r0 = cur[0][lrq], r1 = cur[1][lrq], r2 = cur[2][lrq], r3 = cur[3][lrq];
+      asm volatile("" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3));     // keep the loads up here
+      Pivot4 pv;
+      pivot4(a00, a10, a20, a30, a11, a21, a31, a22, a32, a33, pv);
+      const double d0 = pv.d0, d1 = pv.d1, d2 = pv.d2, d3 = pv.d3;
+      if (tid < FLR) {
+        const int lr = tid;
+        double w0 = 0, w1 = 0, w2 = 0, w3 = 0, e0 = 0, e1 = 0, e2 = 0, e3 = 0;
+        const bool below = lr > p0 + 3;
+        if (below) row4(pv, r0, r1, r2, r3, w0, w1, w2, w3, e0, e1, e2, e3);
+        Wop[0][lr] = -w0; Wop[1][lr] = -w1; Wop[2][lr] = -w2; Wop[3][lr] = -w3;
+        Lop[0][lr] = e0; Lop[1][lr] = e1; Lop[2][lr] = e2; Lop[3][lr] = e3;
+        if (lr >= NB) {                                      // own rows: L kept in LDS (next near update, write-out below)
+          const int orow = lr - NB;
+          Lsave[p0][orow] = e0; Lsave[p0 + 1][orow] = e1; Lsave[p0 + 2][orow] = e2; Lsave[p0 + 3][orow] = e3;
+        } else if (lr >= p0 && lr <= p0 + 3) {
+          dsave[lr] = lr == p0 ? d0 : (lr == p0 + 1 ? d1 : (lr == p0 + 2 ? d2 : d3));
+        }
+      }
+      if (tracer) ts2 = wall_clock64();
+      __syncthreads();
+      if (tracer) ts3 = wall_clock64();
+#pragma unroll
+      for (int s = 0; s < 2; s++) {
+        const int rt = srt[s], ct = sct[s];
+        if ((s == 0 || two) && ct >= jt) {
+          const double bop = Wop[l4][rt * 16 + l15];
+          const double aop = Lop[l4][ct * 16 + l15];
+          acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop, acc[s], 0, 0, 0);
+        }
+      }
+      if (tracer) {
+        const long long ts4 = wall_clock64() + (long long)(acc[0][0] * 0.0);      // after the MFMA result is readable
+        tph[0] += ts1 - ts0; tph[1] += ts2 - ts1; tph[2] += ts3 - ts2; tph[3] += ts4 - ts3;
+
+      }
+    }
+    if (tracer) for (int k = 0; k < 6; k++) a.trace[(size_t)a.RB * P * 6 + (size_t)p * 6 + k] = tph[k];
+    FUSED_TRACE(4);
+    // ---- write-out and publish: L[rb, p] in place (write-through: other workgroups read it), z from the right-hand
+    // side row, D from the diagonal block's owner.  (L11 stays on chip: nothing downstream reads it, and the other
+    // workgroups may still be loading the un-factored diagonal tile for their own copy of the factorisation.)
+    __syncthreads();
+    if (own) {
+      for (int i = tid; i < NB * NB; i += FT) {
+        const int k = i / NB, r = i - k * NB;
+        st_wt(A + (size_t)(c0 + k) * ldA + rowbase + r, Lsave[k][r]);
+      }
+      if (rb == P && tid < NB) a.zvec[c0 + tid] = Lsave[tid][0];
+    } else if (tid < NB) {
+      st_wt(a.dvec + c0 + tid, dsave[tid]);
+    }
+    publish(a.done + (size_t)rb * P + p);
+    FUSED_TRACE(5);
+  }
+}
+
+__device__ void fused_helper_role(const FusedArgs &a, int h, double *lds) {
+  const int nA = a.nA, P = a.P, ldA = 2 * nA + NB;
+  double *__restrict__ A = a.A;
+  double (*La)[NB] = reinterpret_cast<double (*)[NB]>(lds);                 // [48 k][48 rows]  L[rb, q]
+  double (*Lb)[NB] = reinterpret_cast<double (*)[NB]>(lds + NB * NB);       //                  L[j, q]
+  double *dq = lds + 2 * NB * NB;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int l15 = lane & 15, l4 = lane >> 4;
+  const int rt = wv / 3, ct = wv % 3;
+  // Column j >= 2 has exactly P tiles with far updates: matrix blocks j..P-1, the right-hand side tile, identity blocks
+  // 0..j-2.  Tile index = (j-2) P + idx; this workgroup owns the indices congruent to h modulo NH.
+  for (int q = 0; q + 2 < P; q++) {
+    const int cq = NB * q;
+    for (int j = q + 2; j < P; j++) {
+      const int first = (j - 2) * P;
+      int idx = ((h - first) % a.NH + a.NH) % a.NH;          // smallest idx >= 0 with (first + idx) % NH == h
+      for (; idx < P; idx += a.NH) {
+        int rb;
+        if (idx < P - j) rb = j + idx;                       // matrix block
+        else if (idx == P - j) rb = P;                       // right-hand side tile
+        else { rb = P + 1 + (idx - (P - j) - 1); if (rb - P - 1 > q) continue; }     // identity block t: live from panel t on
+        const int rowbase = rb < P ? NB * rb : (rb == P ? nA : nA + NB + NB * (rb - P - 1));
+        const int cj = NB * j;
+        if (tid == 0) {
+          flag_wait(a.done + (size_t)rb * P + q);
+          flag_wait(a.done + (size_t)j * P + q);
+          flag_wait(a.done + (size_t)q * P + q);
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        __syncthreads();
+        d4 acc;
+#pragma unroll
+        for (int e = 0; e < 4; e++) acc[e] = A[(size_t)(cj + ct * 16 + l4 + 4 * e) * ldA + rowbase + rt * 16 + l15];
+        for (int i = tid; i < NB * NB; i += FT) {
+          const int k = i / NB, r = i - k * NB;
+          La[k][r] = A[(size_t)(cq + k) * ldA + rowbase + r];
+          Lb[k][r] = A[(size_t)(cq + k) * ldA + cj + r];
+        }
+        if (tid < NB) dq[tid] = a.dvec[cq + tid];
+        __syncthreads();
+#pragma unroll
+        for (int kc = 0; kc < NB / 4; kc++) {
+          const int k = 4 * kc + l4;
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Lb[k][ct * 16 + l15], -(La[k][rt * 16 + l15] * dq[k]), acc, 0, 0, 0);
+        }
+        if (q == j - 2) {                                    // the tile's last far update: hand it to the panel workgroups
+#pragma unroll
+          for (int e = 0; e < 4; e++) st_wt(A + (size_t)(cj + ct * 16 + l4 + 4 * e) * ldA + rowbase + rt * 16 + l15, acc[e]);
+          publish(a.far + (size_t)rb * P + j);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; e++) A[(size_t)(cj + ct * 16 + l4 + 4 * e) * ldA + rowbase + rt * 16 + l15] = acc[e];
+          __syncthreads();                                   // La / Lb are reloaded for the next tile
+        }
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(FT) void k_ldl_fused(FusedArgs a) {
+  extern __shared__ __attribute__((aligned(16))) double fused_lds[];
+  if ((int)blockIdx.x < a.RB) fused_panel_role(a, blockIdx.x, fused_lds);
+  else fused_helper_role(a, blockIdx.x - a.RB, fused_lds);
+}
+
+// ------------------------------------------------------------------------------------------------
 // backward solve  L^T x = z  as one product with the factor's own by-product: the identity rows appended to the
 // matrix came out of the factorisation as M = L^-T D^+ (row r, columns c >= r), so x = M (D z).
 // 64 rows per workgroup, the column range split over its four waves; lanes of a wave read 512 contiguous bytes.
@@ -333,19 +645,42 @@ __global__ __launch_bounds__(1024) void k_ldl_finish(const double *__restrict__ 
   if (tid == 0) scal[2] = 0.5 * red[0];
 }
 
-void launch_solve(balm_ctx *c, double u, bool new_hessian) {
+// Co-resident workgroups of k_ldl_fused on the current device (0 = the cooperative launch is not available).
+static int fused_capacity(size_t lds_bytes) {
+  int dev = 0, coop = 0, cus = 0, per_cu = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 0;
+  if (hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, dev) != hipSuccess || !coop) return 0;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_ldl_fused, FT, lds_bytes) != hipSuccess) return 0;
+  return per_cu * cus;
+}
+
+// The factorisation proper: one persistent cooperative launch (k_ldl_fused) where it is the faster one (10..40 panels,
+// i.e. windows of 80..320 poses), the launch pair per panel otherwise (and on a device that refuses the cooperative
+// launch).  BALM_SOLVE=launches / fused forces one of them (A/B runs, tests).
+static void launch_factor(balm_ctx *c) {
   hipStream_t s = c->stream;
-  const int n = c->n, nA = c->nA;
-  if (new_hessian)
-    hipLaunchKernelGGL(k_rank_diag, dim3((nA + 15) / 16), dim3(256), (size_t)nA * sizeof(double) + 256 * sizeof(int),
-                       s, c->d_H, n, nA, c->d_perm);
-  {
-    long total = (long)(2 * nA + NB) * nA;
-    int grid = (int)((total + 255) / 256);
-    if (grid > 4096) grid = 4096;
-    hipLaunchKernelGGL(k_build_A, dim3(grid), dim3(256), 0, s, c->d_H, c->d_g, n, nA, c->d_perm, u, c->d_A);
+  const int nA = c->nA, P = nA / NB;
+  const char *mode = getenv("BALM_SOLVE");              // A/B: "launches" forces the per-panel launch pair
+  const bool forced = mode && !strcmp(mode, "fused");
+  const bool want_fused = !(mode && !strcmp(mode, "launches")) && P >= 2 && (forced || (P >= 10 && P <= 40));
+  if (want_fused) {
+    const size_t lds = (size_t)(12 * FLR + 2 * NB * NB + NB) * sizeof(double);
+    if (c->fused_cap < 0) c->fused_cap = fused_capacity(lds);
+    const int RB = 2 * P + 1;
+    int NH = c->fused_cap - RB;
+    const int most = (P - 2) * P;                        // tiles with far updates: more helpers than tiles idle
+    if (NH > most) NH = most;
+    if (P == 2) NH = 0;
+    if (NH >= (P > 2 ? 1 : 0)) {
+      FusedArgs fa{c->d_A, c->d_dvec, c->d_z, c->d_flags, c->d_flags + (size_t)RB * P, nA, P, RB, NH > 0 ? NH : 1, c->d_trace};
+      void *args[] = {(void *)&fa};
+      if (hipLaunchCooperativeKernel((const void *)k_ldl_fused, dim3(RB + (P > 2 ? NH : 0)), dim3(FT), args, (unsigned)lds, s) == hipSuccess)
+        return;
+      hipGetLastError();
+      c->fused_cap = 0;                                  // not again on this context
+    }
   }
-  const int P = nA / NB;
   for (int p = 0; p < P; p++) {
     const int c0 = p * NB;
     const int m = nA - c0 - NB;                 // square part still to factor
@@ -358,6 +693,23 @@ void launch_solve(balm_ctx *c, double u, bool new_hessian) {
       hipLaunchKernelGGL(k_ldl_trail, dim3((3 * mt + 3) / 4, mt + 1 + (p + 1)), dim3(256), 0, s, c->d_A, nA, c0, c->d_Wp, mt);
     }
   }
+}
+
+void launch_solve(balm_ctx *c, double u, bool new_hessian) {
+  hipStream_t s = c->stream;
+  const int n = c->n, nA = c->nA;
+  if (new_hessian)
+    hipLaunchKernelGGL(k_rank_diag, dim3((nA + 15) / 16), dim3(256), (size_t)nA * sizeof(double) + 256 * sizeof(int),
+                       s, c->d_H, n, nA, c->d_perm);
+  {
+    long total = (long)(2 * nA + NB) * nA;
+    int grid = (int)((total + 255) / 256);
+    if (grid > 4096) grid = 4096;
+    const int P = nA / NB;
+    hipLaunchKernelGGL(k_build_A, dim3(grid), dim3(256), 0, s, c->d_H, c->d_g, n, nA, c->d_perm, u, c->d_A, c->d_flags,
+                       2 * (2 * P + 1) * P);
+  }
+  launch_factor(c);
   hipLaunchKernelGGL(k_ldl_apply, dim3((nA + 63) / 64, APPLY_CHUNKS), dim3(256), 0, s, c->d_A, nA, c->d_dvec, c->d_z, c->d_x);
   hipLaunchKernelGGL(k_ldl_finish, dim3(1), dim3(1024), 0, s, c->d_x, nA, n, c->d_perm, c->d_H, c->d_g, u, c->d_dx,
                      c->d_scal);

@@ -211,6 +211,11 @@ enum {
   BALM_T_COUNT = 9
 };
 int balm_get_timing(balm_ctx *ctx, double *ms, long *count);
+
+/* Diagnostics of the persistent factorisation kernel: with BALM_SOLVE_TRACE=1 in the environment at balm_create, the
+ * panel workgroups of the last solve leave wall-clock ticks (100 MHz) per (row block, column block, phase):
+ * 0 arrive, 1 inputs ready, 2 tiles loaded, 3 near update done, 4 factorised, 5 published.  dims3 = {2P+1, P, 6}. */
+int balm_get_solve_trace(balm_ctx *ctx, long long *ticks, long capacity, int *dims3);
 int balm_reset_timing(balm_ctx *ctx);
 
 /* Work model of the last balm_set_features: out[0] = S = sum_a n_a, out[1] = sum_a n_a(n_a+1)/2,

@@ -1,0 +1,77 @@
+"""The damped solve's two factorisation paths -- the persistent cooperative kernel (k_ldl_fused) and the per-panel launch
+pair (k_ldl_panel + k_ldl_trail, kept for BALM_SOLVE=launches and as the path of devices without cooperative launch) --
+must agree to rounding (same elimination order, pivot-block code and D^+ rule; W = L D is re-formed in the fused path), and both must agree with LAPACK."""
+import os
+
+import numpy as np
+import pytest
+
+from balm_amd import capi
+from util import make_scene, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def both_paths(c, H, g, u):
+    os.environ["BALM_SOLVE"] = "launches"
+    dx0, q0 = c.solve_damped(H, g, u)
+    os.environ["BALM_SOLVE"] = "fused"
+    dx1, q1 = c.solve_damped(H, g, u)
+    os.environ.pop("BALM_SOLVE")
+    return (dx0, q0), (dx1, q1)
+
+
+@pytest.mark.parametrize("W", [8, 16, 17, 24, 33, 64, 100, 200])
+@pytest.mark.parametrize("kind", ["spd", "indefinite"])
+def test_fused_factorisation_matches_launch_pair(W, kind):
+    rng = np.random.default_rng(W * 7 + (kind == "spd"))
+    n = 6 * W
+    B = rng.standard_normal((n, n))
+    H = B @ B.T / n + np.diag(rng.uniform(0.5, 50.0, n))
+    if kind == "indefinite":
+        s = np.where(rng.uniform(size=n) < 0.2, -1.0, 1.0)
+        H = (H * s[:, None]) * s[None, :]
+        H[np.diag_indices(n)] *= s            # negative pivots on the diagonal, as the exact Hessian has away from the optimum
+    g = rng.standard_normal(n)
+    c = capi.Context(W)
+    (dx0, q0), (dx1, q1) = both_paths(c, H, g, 0.1)
+    assert rel_err(dx1, dx0) < 1e-11 and abs(q0 - q1) <= 1e-11 * abs(q0)
+    D = np.diag(np.diag(H))
+    ref = np.linalg.solve(H + 0.1 * D, -g)
+    assert rel_err(dx1, ref) < 1e-9
+    c.close()
+
+
+def test_fused_path_on_a_real_hessian_and_lm_run():
+    sc, _ = make_scene(21, 48, 500, 8, drop=0.3)
+    c = capi.Context(sc.W)
+    c.set_features(sc.clusters, None, sc.coeffs)
+    H, g, _ = c.evaluate(0, sc.poses_init)
+    for u in (0.01, 1.0):
+        (dx0, q0), (dx1, q1) = both_paths(c, H, g, u)
+        assert rel_err(dx1, dx0) < 1e-11 and abs(q0 - q1) <= 1e-11 * abs(q0)
+    os.environ["BALM_SOLVE"] = "launches"
+    pa, la = c.damping_iter(sc.poses_init, u0=0.01, max_iter=10)
+    os.environ["BALM_SOLVE"] = "fused"
+    pb, lb = c.damping_iter(sc.poses_init, u0=0.01, max_iter=10)
+    os.environ.pop("BALM_SOLVE")
+    assert len(la) == len(lb) and np.allclose(la[:, :3], lb[:, :3], rtol=1e-9, atol=0) and np.abs(pa - pb).max() < 1e-10
+    c.close()
+
+
+def test_fused_path_many_solves_in_a_row():
+    """flags are re-zeroed per solve; stale flags from the previous factorisation would let a workgroup run ahead"""
+    rng = np.random.default_rng(5)
+    W = 40
+    n = 6 * W
+    c = capi.Context(W)
+    os.environ["BALM_SOLVE"] = "fused"
+    for k in range(25):
+        B = rng.standard_normal((n, n))
+        H = B @ B.T / n + np.diag(rng.uniform(0.5, 5.0, n))
+        g = rng.standard_normal(n)
+        dx, _ = c.solve_damped(H, g, 0.05)
+        ref = np.linalg.solve(H + 0.05 * np.diag(np.diag(H)), -g)
+        assert rel_err(dx, ref) < 1e-9, k
+    os.environ.pop("BALM_SOLVE")
+    c.close()

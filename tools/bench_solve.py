@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""Times balm_solve_damped's device part (HIP events, BALM_FLAG_TIMING) for both factorisation paths at several window
+sizes: n = 6 W unknowns.  Usage: python tools/bench_solve.py [W ...]"""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from balm_amd import capi  # noqa: E402
+
+Ws = [int(a) for a in sys.argv[1:]] or [20, 64, 100, 177, 200, 300, 480, 700, 1024]
+for W in Ws:
+    n = 6 * W
+    rng = np.random.default_rng(W)
+    B = rng.standard_normal((n, 64))
+    H = B @ B.T / 64 + np.diag(rng.uniform(0.5, 50.0, n))
+    g = rng.standard_normal(n)
+    c = capi.Context(W, 0, capi.FLAG_TIMING)
+    row = []
+    for mode in ("launches", "fused"):
+        if mode == "launches":
+            os.environ["BALM_SOLVE"] = "launches"
+        else:
+            os.environ["BALM_SOLVE"] = "fused"
+        for _ in range(3):
+            dx, _ = c.solve_damped(H, g, 0.1)
+        c.reset_timing()
+        for _ in range(10):
+            dx, _ = c.solve_damped(H, g, 0.1)
+        ms, cnt = c.timing()["solve"]
+        row.append(ms / cnt)
+    ref = np.linalg.solve(H + 0.1 * np.diag(np.diag(H)), -g)
+    err = np.abs(dx - ref).max() / np.abs(ref).max()
+    print("W=%4d n=%5d  launches %.3f ms   fused %.3f ms   (x%.2f)  err %.1e" % (W, n, row[0], row[1], row[0] / row[1], err), flush=True)
+    c.close()
+
+if os.environ.get("BALM_SOLVE_TRACE"):
+    W = 200
+    os.environ["BALM_SOLVE"] = "fused"
+    n = 6 * W
+    rng = np.random.default_rng(W)
+    B = rng.standard_normal((n, 64))
+    H = B @ B.T / 64 + np.diag(rng.uniform(0.5, 50.0, n))
+    g = rng.standard_normal(n)
+    c = capi.Context(W, 0, capi.FLAG_TIMING)
+    for _ in range(3):
+        c.solve_damped(H, g, 0.1)
+    tr = c.solve_trace().astype(np.float64) * 0.01      # us
+    P = tr.shape[1]
+    t0 = tr[tr > 0].min()
+    rhs = tr[P] - t0                                     # the right-hand side block lives through every panel
+    print("RHS block, per column: arrive | +wait | +load | +near | +factor | +publish   (us)")
+    for p in range(P):
+        r = rhs[p]
+        print("p=%2d  %8.2f | %6.2f %6.2f %6.2f %6.2f %6.2f" % (p, r[0], r[1] - r[0], r[2] - r[1], r[3] - r[2], r[4] - r[3], r[5] - r[4]))
+    print("owner of block p+1 at column p (its L is what everyone waits for): factor end, publish end")
+    for p in range(P - 1):
+        r = tr[p + 1][p] - t0
+        print("p=%2d  wait %6.2f load %6.2f near %6.2f factor %6.2f publish %6.2f  (ends %8.2f)" % (p, r[1] - r[0], r[2] - r[1], r[3] - r[2], r[4] - r[3], r[5] - r[4], r[5]))
+    print("step phases (ns per step, RHS block): publish+barrier | pivot+rows | barrier | operands+MFMA || of pivot+rows: LDS arrival | chain")
+    print(np.round(c.step_phases[1:6] * 10.0 / 12.0, 1))
+    c.close()
