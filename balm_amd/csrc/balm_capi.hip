@@ -2,6 +2,7 @@
 // (per-feature SoA clusters, poses, Hessian), sequences the HIP kernels on one stream, and runs the
 // Levenberg-Marquardt loop of BALM2::damping_iter (src/benchmark/bavoxel.hpp:1069-1166) with every
 // matrix device-resident; only four scalars cross PCIe per iteration.
+#include <algorithm>
 #include <array>
 #include <cmath>
 #include <cstdio>
@@ -121,8 +122,13 @@ int prepare_evaluate(balm_ctx *ctx, int form, int nf) {
   if (nf <= 0) return BALM_OK;
   const SyrkPlan plan = plan_syrk(ctx->ntiles, 3L * nf);
   int rc;
-  if ((rc = ensure(ctx, &ctx->d_Gt, &ctx->cap_Gt, (size_t)(plan.Kpad + 64) * ctx->npad))) return rc;
-  if ((rc = ensure(ctx, &ctx->d_part, &ctx->cap_part, (size_t)plan.SG * ctx->ntiles * TILE_ELEMS))) return rc;
+  size_t gcols = (size_t)plan.Kpad + 64, parts = (size_t)plan.SG * ctx->ntiles;
+  if (ctx->sparse && nf == ctx->F) {
+    gcols = (size_t)ctx->sp_nchunks * ctx->sp_nsteps * 4 + 64;
+    parts = (size_t)ctx->sp_nitems;
+  }
+  if ((rc = ensure(ctx, &ctx->d_Gt, &ctx->cap_Gt, gcols * ctx->npad))) return rc;
+  if ((rc = ensure(ctx, &ctx->d_part, &ctx->cap_part, parts * TILE_ELEMS))) return rc;
   return ensure(ctx, &ctx->d_dpart, &ctx->cap_dpart, (size_t)factors_grid(ctx->W, nf, form) * DACC_MAX * ctx->W);
 }
 
@@ -150,25 +156,29 @@ int evaluate_device(balm_ctx *ctx, int form, const double *d_poses, int f0, int 
     ctx->feat_cur_valid = (f0 == 0 && f1 == ctx->F);
   }
   const int nr = ctx->nr_cur;
+  const bool sparse = ctx->sparse && f0 == 0 && f1 == ctx->F;       // sub-ranges keep the dense plan and column order
+  const size_t kpad = sparse ? (size_t)ctx->sp_nchunks * ctx->sp_nsteps * 4 : (size_t)plan.Kpad;
   {
     Span sp(ctx, BALM_T_FACTORS);
     // zero the Gt columns the factor kernel does not write: [3 nf, Kpad + 8) and the row padding
-    const size_t k0 = (size_t)3 * nf, k1 = (size_t)plan.Kpad + 64;   // + prefetch overrun of the k-ring
+    const size_t k0 = (size_t)3 * nf, k1 = kpad + 64;   // + prefetch overrun of the k-ring
     HIP_TRY(hipMemsetAsync(ctx->d_Gt + k0 * ctx->npad, 0, (k1 - k0) * ctx->npad * sizeof(double), s));
     if (ctx->npad > ctx->n)
       HIP_TRY(hipMemset2DAsync(ctx->d_Gt + ctx->n, (size_t)ctx->npad * sizeof(double), 0,
                                (size_t)(ctx->npad - ctx->n) * sizeof(double), k0 ? k0 : 1, s));
-    launch_factors(s, form, ctx->d_cl, d_poses, ctx->d_feat, W, ctx->npad, f0, f1, ctx->d_Gt, ctx->d_dpart, nblk);
+    launch_factors(s, form, ctx->d_cl, d_poses, ctx->d_feat, W, ctx->npad, f0, f1, ctx->d_Gt, ctx->d_dpart, nblk,
+                   sparse ? ctx->d_slot : nullptr);
   }
   {
     Span sp(ctx, BALM_T_SYRK);
-    launch_syrk(s, ctx->d_Gt, ctx->npad, ctx->ntiles, ctx->d_jobs, plan, ctx->d_part);
+    if (sparse) launch_syrk_sparse(s, ctx->d_Gt, ctx->npad, ctx->d_jobs, ctx->d_items, ctx->d_chunk_ids, ctx->sp_nsteps, ctx->sp_nitems, ctx->d_part);
+    else launch_syrk(s, ctx->d_Gt, ctx->npad, ctx->ntiles, ctx->d_jobs, plan, ctx->d_part);
   }
   {
     Span sp(ctx, BALM_T_ASSEMBLE);
     HIP_TRY(hipMemsetAsync(ctx->d_red + red_dacc_off(ctx), 0, (size_t)(DACC_MAX * W + 2) * sizeof(double), s));
     launch_reduce(s, ctx->d_part, plan.SG, (long)ctx->ntiles * TILE_ELEMS, ctx->d_dpart, nblk, dacc * W,
-                  ctx->d_rpart, nr, ctx->d_red, red_dacc_off(ctx), red_r_off(ctx));
+                  ctx->d_rpart, nr, ctx->d_red, red_dacc_off(ctx), red_r_off(ctx), sparse ? ctx->d_csr : nullptr);
   }
   if ((rc = hook_allreduce(ctx, ctx->d_red, (long)ctx->red_len))) return rc;
   {
@@ -278,6 +288,7 @@ balm_ctx *balm_create(int win_size, int device, int flags) {
     }
   }
   ctx->ntiles = (int)(jobs.size() / 4);
+  ctx->h_jobs = jobs;
   if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) return fail();
   const int W = ctx->W, n = ctx->n, nA = ctx->nA;
   ctx->red_len = (size_t)ctx->ntiles * TILE_ELEMS + (size_t)DACC_MAX * W + 2;
@@ -315,13 +326,106 @@ static void one_destroy(balm_ctx *ctx) {
   if (ctx->stream) hipStreamSynchronize(ctx->stream);
   void *ptrs[] = {ctx->d_cl, ctx->d_fix, ctx->d_coe, ctx->d_poses, ctx->d_poses_tmp, ctx->d_C, ctx->d_feat,
                   ctx->d_Gt, ctx->d_part, ctx->d_dpart, ctx->d_rpart, ctx->d_feat_tmp, ctx->d_rpart_tmp, ctx->d_red, ctx->d_jobs, ctx->d_sub, ctx->d_H,
-                  ctx->d_g, ctx->d_A, ctx->d_Wp, ctx->d_dvec, ctx->d_z, ctx->d_x, ctx->d_perm, ctx->d_dx, ctx->d_scal, ctx->d_arena, ctx->d_pre, ctx->d_flags, ctx->d_trace};
+                  ctx->d_g, ctx->d_A, ctx->d_Wp, ctx->d_dvec, ctx->d_z, ctx->d_x, ctx->d_perm, ctx->d_dx, ctx->d_scal, ctx->d_arena, ctx->d_pre, ctx->d_flags, ctx->d_trace, ctx->d_slot, ctx->d_items, ctx->d_csr, ctx->d_chunk_ids};
   for (void *p : ptrs) if (p) hipFree(p);
   if (ctx->h_scal) hipHostFree(ctx->h_scal);
   for (auto &sp : ctx->timer.pending) { hipEventDestroy(sp.a); hipEventDestroy(sp.b); }
   for (auto e : ctx->timer.pool) hipEventDestroy(e);
   if (ctx->stream) hipStreamDestroy(ctx->stream);
   delete ctx;
+}
+
+// Block-sparse plan of hessian_syrk for the installed features (real co-visibility; dense scenes keep the dense plan).
+// The reference's pair loop only visits observed poses (bavoxel.hpp:365,404-418); the dense SYRK multiplies the zero
+// rows of unobserved ones: 6.5x the algorithmic flops on the shipped window (15 % block fill).  Here the columns of Gt
+// (features) are ordered by which 80-row blocks they touch -- features that see the same stretch of the trajectory
+// become neighbours -- and cut into chunks of C features; an item (job, chunk) exists only where the chunk touches
+// the job's row blocks.  Chosen when it issues < 80 % of the dense plan's MFMAs (BALM_SYRK=dense|sparse forces).
+static int build_sparse_plan(balm_ctx *ctx, int F, const double *clusters) {
+  ctx->sparse = false;
+  const char *mode = getenv("BALM_SYRK");
+  if (mode && !strcmp(mode, "dense")) return BALM_OK;
+  const int W = ctx->W, T = ctx->T, ntiles = ctx->ntiles;
+  if (T > 128 || F < 64) return BALM_OK;
+  struct Key { uint64_t hi, lo; int a; };
+  std::vector<Key> keys((size_t)F);
+  for (int a = 0; a < F; a++) {
+    uint64_t hi = 0, lo = 0;
+    const double *ca = clusters + (size_t)a * W * 10;
+    for (int i = 0; i < W; i++)
+      if (ca[(size_t)i * 10 + 9] != 0)
+        for (int b = (6 * i) / TILE; b <= (6 * i + 5) / TILE; b++) {      // a pose's six rows may straddle two blocks
+          if (b < 64) hi |= 1ull << (63 - b); else lo |= 1ull << (127 - b);   // block 0 = most significant bit
+        }
+    keys[(size_t)a] = {hi, lo, a};
+  }
+  // order: first touched block, then last touched block, then the pattern itself (measured on the shipped window against a
+  // plain lexicographic order and a centre/span order: the tightest chunk unions)
+  auto first_of = [&](const Key &k) { for (int b = 0; b < T; b++) if (b < 64 ? (k.hi >> (63 - b)) & 1 : (k.lo >> (127 - b)) & 1) return b; return T; };
+  auto last_of = [&](const Key &k) { for (int b = T - 1; b >= 0; b--) if (b < 64 ? (k.hi >> (63 - b)) & 1 : (k.lo >> (127 - b)) & 1) return b; return -1; };
+  std::vector<int> fb((size_t)F), lb((size_t)F);
+  for (int a = 0; a < F; a++) { fb[(size_t)a] = first_of(keys[(size_t)a]); lb[(size_t)a] = last_of(keys[(size_t)a]); }
+  std::sort(keys.begin(), keys.end(), [&](const Key &x, const Key &y) {
+    if (fb[(size_t)x.a] != fb[(size_t)y.a]) return fb[(size_t)x.a] < fb[(size_t)y.a];
+    if (lb[(size_t)x.a] != lb[(size_t)y.a]) return lb[(size_t)x.a] < lb[(size_t)y.a];
+    return x.hi != y.hi ? x.hi > y.hi : (x.lo != y.lo ? x.lo > y.lo : x.a < y.a);
+  });
+  const int C = 16, nsteps = 3 * C / 4, nchunks = (F + C - 1) / C;       // 12 k-steps: three turns of the operand ring
+  auto touched = [](const Key &k, int b) { return b < 64 ? (k.hi >> (63 - b)) & 1 : (k.lo >> (127 - b)) & 1; };
+  std::vector<int> slot((size_t)F);
+  std::vector<std::vector<int>> chunks_of((size_t)ntiles);
+  long total = 0;
+  for (int c = 0; c < nchunks; c++) {
+    Key cm{0, 0, 0};
+    for (int k = c * C; k < F && k < (c + 1) * C; k++) { cm.hi |= keys[(size_t)k].hi; cm.lo |= keys[(size_t)k].lo; slot[(size_t)keys[(size_t)k].a] = k; }
+    for (int j = 0; j < ntiles; j++) {
+      const int type = ctx->h_jobs[(size_t)4 * j], I = ctx->h_jobs[(size_t)4 * j + 1], J = ctx->h_jobs[(size_t)4 * j + 2];
+      bool need;
+      if (type == 0) need = touched(cm, I) && touched(cm, J);
+      else if (type == 1) need = touched(cm, I) || touched(cm, I + 1);
+      else if (type == 2) need = touched(cm, I + 1) || touched(cm, I + 2) || touched(cm, I + 3);
+      else need = touched(cm, I + 3) || touched(cm, I + 4);
+      if (need) { chunks_of[(size_t)j].push_back(c); total++; }
+    }
+  }
+  const double dense_steps = (double)ntiles * ((3.0 * F + 3) / 4), sparse_steps = (double)total * nsteps;
+  const bool forced = mode && !strcmp(mode, "sparse");
+  if (total == 0 || (!forced && !(sparse_steps < 0.8 * dense_steps))) return BALM_OK;
+  // items: every job's chunk list cut into runs of about total / 2048 chunks (two rounds of the 1024 wave slots), at least 8
+  long per = total / 2048;
+  if (per < 8) per = 8;
+  std::vector<int> items, chunk_ids, csr((size_t)ntiles + 1, 0);
+  struct Order { int first_chunk, item; };
+  std::vector<Order> order;
+  int run = 0;
+  for (int j = 0; j < ntiles; j++) {
+    csr[(size_t)j] = run;
+    const std::vector<int> &L = chunks_of[(size_t)j];
+    const long pieces = ((long)L.size() + per - 1) / per;
+    for (long q = 0; q < pieces; q++) {
+      const size_t b = (size_t)((long)L.size() * q / pieces), e = (size_t)((long)L.size() * (q + 1) / pieces);
+      order.push_back({L[b], (int)(items.size() / 4)});
+      items.insert(items.end(), {j, (int)chunk_ids.size(), (int)(e - b), run++});
+      chunk_ids.insert(chunk_ids.end(), L.begin() + (long)b, L.begin() + (long)e);
+    }
+  }
+  csr[(size_t)ntiles] = run;
+  // launch order: by first chunk, so that waves running side by side walk the same stretch of Gt
+  std::stable_sort(order.begin(), order.end(), [](const Order &x, const Order &y) { return x.first_chunk < y.first_chunk; });
+  std::vector<int> sorted_items;
+  sorted_items.reserve(items.size());
+  for (const Order &o : order) sorted_items.insert(sorted_items.end(), items.begin() + 4L * o.item, items.begin() + 4L * o.item + 4);
+  if (chunk_ids.empty()) chunk_ids.push_back(0);
+  int rc;
+  if ((rc = dalloc(ctx, &ctx->d_slot, (size_t)F)) || (rc = dalloc(ctx, &ctx->d_items, sorted_items.size())) ||
+      (rc = dalloc(ctx, &ctx->d_chunk_ids, chunk_ids.size())) || (rc = dalloc(ctx, &ctx->d_csr, csr.size())))
+    return rc;
+  HIP_TRY(hipMemcpy(ctx->d_slot, slot.data(), slot.size() * sizeof(int), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(ctx->d_items, sorted_items.data(), sorted_items.size() * sizeof(int), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(ctx->d_chunk_ids, chunk_ids.data(), chunk_ids.size() * sizeof(int), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(ctx->d_csr, csr.data(), csr.size() * sizeof(int), hipMemcpyHostToDevice));
+  ctx->sparse = true; ctx->sp_nsteps = nsteps; ctx->sp_nchunks = nchunks; ctx->sp_nitems = run; ctx->sp_steps = sparse_steps;
+  return BALM_OK;
 }
 
 static int install_feature_buffers(balm_ctx *ctx, int F, const double *fix, const double *coeffs) {
@@ -364,6 +468,7 @@ static int one_set_features(balm_ctx *ctx, int F, const double *clusters, const 
   hipFree(d_aos);
   HIP_TRY(e);
   if (!ctx->multi && (rc = feature_bookkeeping(ctx, F, clusters, fix, coeffs))) return rc;    // sharded: done once on the whole table
+  if ((rc = build_sparse_plan(ctx, F, clusters))) return rc;
   if ((rc = install_feature_buffers(ctx, F, fix, coeffs))) return rc;
   return sync_stream(ctx);
 }
@@ -410,6 +515,7 @@ static int one_build_clusters(balm_ctx *ctx, int F, const float *xyz, const int 
   HIP_TRY(e);
   if (clusters_out) std::memcpy(clusters_out, host.data(), count * sizeof(double));
   if ((rc = feature_bookkeeping(ctx, F, host.data(), fix, coeffs))) return rc;
+  if ((rc = build_sparse_plan(ctx, F, host.data()))) return rc;
   if ((rc = install_feature_buffers(ctx, F, fix, coeffs))) return rc;
   return sync_stream(ctx);
 }
@@ -494,6 +600,7 @@ static int one_associate(balm_ctx *ctx, const balm_voxel_opts *opts, const float
   if ((rc = feature_bookkeeping(ctx, F, ctx->assoc_clusters.data(), opts->fix_frames > 0 ? ctx->assoc_fix.data() : nullptr,
                                 ctx->assoc_coeffs.data())))
     return rc;
+  if ((rc = build_sparse_plan(ctx, F, ctx->assoc_clusters.data()))) return rc;
   if ((rc = install_feature_buffers(ctx, F, opts->fix_frames > 0 ? ctx->assoc_fix.data() : nullptr, ctx->assoc_coeffs.data())))
     return rc;
   if ((rc = sync_stream(ctx))) return rc;
@@ -928,9 +1035,12 @@ int balm_work_model(balm_ctx *ctx, double *out4) {
   const double W = ctx->W, F = ctx->multi ? ctx->multi->F : ctx->F;
   out4[0] = ctx->work_S;
   out4[1] = ctx->work_B;
-  out4[2] = 108.0 * F * W * (W + 1.0);            // 108 FMA = 216 flop per unordered pair incl. diagonal -> x2/2
+  (void)W;
+  out4[2] = 216.0 * ctx->work_B;                  // 108 FMA = 216 flop per unordered OBSERVED pose pair incl. the diagonal
+                                                  // (dense scenes: 108 F W (W+1))
   SyrkPlan p = plan_syrk(ctx->ntiles, 3L * (long)F);
   out4[3] = (double)ctx->ntiles * 25.0 * 2048.0 * ((double)p.Kpad / 4.0);   // 25 MFMAs per k-step of every job
+  if (ctx->sparse && !ctx->multi) out4[3] = ctx->sp_steps * 25.0 * 2048.0;
   return BALM_OK;
 }
 

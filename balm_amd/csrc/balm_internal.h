@@ -73,6 +73,15 @@ struct balm_ctx {
   double *d_rpart = nullptr;        // residual partials at the current poses
   double *d_red = nullptr;          // [ntiles*6400 | DACC_MAX*W | r | pad]   all-reduce payload
   size_t red_len = 0;
+  // block-sparse SYRK plan of the installed features (empty = dense): column order, (job, chunk) items, per-job slots
+  std::vector<int> h_jobs;          // host copy of d_jobs
+  bool sparse = false;
+  int sp_nsteps = 0, sp_nchunks = 0, sp_nitems = 0;
+  int *d_slot = nullptr;            // [F] feature -> column slot of Gt
+  int *d_items = nullptr;           // [nitems][4] job, first entry of d_chunk_ids, entry count, output slot
+  int *d_chunk_ids = nullptr;       // the jobs' chunk lists, back to back
+  double sp_steps = 0;              // k-steps the plan issues over all items
+  int *d_csr = nullptr;             // [ntiles + 1]
   int *d_jobs = nullptr;            // [ntiles][4]  SYRK jobs per k-slice: type, block I (or first block of a group), block J
   int *d_sub = nullptr;             // [ntiles][25] (R << 16) | C: global 16-row sub-tile coordinates of each accumulator tile
   double *d_H = nullptr;            // [n][n] column-major
@@ -120,13 +129,16 @@ int launch_feature_eigen(hipStream_t s, const double *C, const double *fix, cons
                          double *feat, double *rpart);   // returns #partials
 int factors_grid(int W, int nfeat, int form);
 void launch_factors(hipStream_t s, int form, const double *cl, const double *poses, const double *feat, int W,
-                    int npad, int f0, int f1, double *Gt, double *dpart, int nblk);
+                    int npad, int f0, int f1, double *Gt, double *dpart, int nblk, const int *slot = nullptr);
 struct SyrkPlan { int SG; int nsteps; int Kpad; long nblocks; };   // k-slices, MFMA k-steps per wave, padded K, workgroups
 SyrkPlan plan_syrk(int ntiles, long K);
 void launch_syrk(hipStream_t s, const double *Gt, int npad, int ntiles, const int *tileIJ, const SyrkPlan &p,
                  double *part);
+void launch_syrk_sparse(hipStream_t s, const double *Gt, int npad, const int *jobs, const int *items, const int *chunk_ids,
+                        int nsteps, long nitems, double *part);
 void launch_reduce(hipStream_t s, const double *part, int SG, long tile_elems_total, const double *dpart, int nblk,
-                   int dacc_len, const double *rpart, int nr, double *red, long red_dacc_off, long red_r_off);
+                   int dacc_len, const double *rpart, int nr, double *red, long red_dacc_off, long red_r_off,
+                   const int *csr_ptr = nullptr);
 void launch_assemble(hipStream_t s, int form, const double *red, long red_dacc_off, const int *tileIJ, int ntiles,
                      int W, double *H, double *g);
 void launch_sum_scalar(hipStream_t s, const double *rpart, int nr, double *out);

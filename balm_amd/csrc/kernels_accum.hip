@@ -285,7 +285,7 @@ __global__ __launch_bounds__(256) void k_feature_factors(const double *__restric
                                                          const double *__restrict__ poses,
                                                          const double *__restrict__ feat, int W, int Wc, int npad, int f0,
                                                          int f1, double *__restrict__ Gt,
-                                                         double *__restrict__ dpart) {
+                                                         double *__restrict__ dpart, const int *__restrict__ slot) {
   constexpr int DACC = FORM == 0 ? DACC_LEFT : DACC_RIGHT;
   extern __shared__ __attribute__((aligned(16))) double sm[];
   // blockIdx.y = chunk of Wc poses (one chunk = the whole window up to MAX_W_LDS poses)
@@ -319,7 +319,7 @@ __global__ __launch_bounds__(256) void k_feature_factors(const double *__restric
     const double c0 = f[FT_C0], c1 = f[FT_C1], c2 = f[FT_C2], coe = f[FT_COE];
     const double iNN = 1.0 / NN;
     const double *ca = cl + (size_t)a * 10 * W;
-    double *g0 = Gt + (size_t)(3 * (a - f0)) * npad;
+    double *g0 = Gt + (size_t)(3 * (slot ? slot[a] : a - f0)) * npad;      // slot: the block-sparse plan's column order
 
     for (int il = threadIdx.x; il < wc; il += blockDim.x) {
       const int i = p0 + il;
@@ -555,15 +555,15 @@ hipError_t prepare_device_accum() {
 }
 
 void launch_factors(hipStream_t s, int form, const double *cl, const double *poses, const double *feat, int W,
-                    int npad, int f0, int f1, double *Gt, double *dpart, int nblk) {
+                    int npad, int f0, int f1, double *Gt, double *dpart, int nblk, const int *slot) {
   int dacc = form == 0 ? DACC_LEFT : DACC_RIGHT;
   const int Wc = factors_chunk(W), chunks = (W + Wc - 1) / Wc;
   size_t lds = (size_t)(12 + dacc) * Wc * sizeof(double);
   int bs = W <= 64 ? 64 : (W <= 128 ? 128 : 256);
   if (form == 0)
-    hipLaunchKernelGGL(k_feature_factors<0>, dim3(nblk, chunks), dim3(bs), lds, s, cl, poses, feat, W, Wc, npad, f0, f1, Gt, dpart);
+    hipLaunchKernelGGL(k_feature_factors<0>, dim3(nblk, chunks), dim3(bs), lds, s, cl, poses, feat, W, Wc, npad, f0, f1, Gt, dpart, slot);
   else
-    hipLaunchKernelGGL(k_feature_factors<1>, dim3(nblk, chunks), dim3(bs), lds, s, cl, poses, feat, W, Wc, npad, f0, f1, Gt, dpart);
+    hipLaunchKernelGGL(k_feature_factors<1>, dim3(nblk, chunks), dim3(bs), lds, s, cl, poses, feat, W, Wc, npad, f0, f1, Gt, dpart, slot);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -634,40 +634,26 @@ BALM_DEFINE_MIXED_SWEEP(2)
 BALM_DEFINE_MIXED_SWEEP(3)
 #undef BALM_DEFINE_MIXED_SWEEP
 
-__global__ __launch_bounds__(64) void k_hessian_syrk(const double *__restrict__ Gt, int npad, int njobs,
-                                                     const int *__restrict__ jobs, int nsteps, long nblocks,
-                                                     double *__restrict__ part) {
-  // One wavefront per (job, k-slice); a job = an off-diagonal 80x80 tile or 25 upper sub-tiles of the diagonal
-  // blocks (jobs[4 j] = type, block I or base block, block J).  XCD-aware remap: hardware places workgroup b on XCD
-  // b % 8; every XCD gets a contiguous run of logical workgroups = ALL jobs of one k-slice after the other.
-  // An XCD holds 128 of these one-wave workgroups (4 per CU), i.e. the jobs of a slice run side by side and sweep
-  // k in lockstep (they are all MFMA-paced, 25 MFMAs per k-step each), so each 128-byte line of Gt is pulled into
-  // that XCD's L2 once and serves the ~15 jobs that need it.
-  long bid = blockIdx.x;
-  {
-    const long q = nblocks >> 3, r = nblocks & 7, x = bid & 7;       // XCD x runs q (+1 if x < r) logical workgroups
-    bid = x * q + (x < r ? x : r) + (bid >> 3);
-  }
-  const int tile = (int)(bid % njobs);
-  const int sg = (int)(bid / njobs);
-  const int type = jobs[4 * tile], I = jobs[4 * tile + 1], J = jobs[4 * tile + 2];
+// One wavefront = one job (an off-diagonal 80x80 tile, or 25 upper sub-tiles of the diagonal blocks: jobs[4 j] = type,
+// block I or base block, block J).  syrk_accumulate adds nsteps k-steps from column k_begin on to the wave's pinned
+// accumulators; syrk_write_out stores the 80x80 partial tile.
+__device__ __forceinline__ void syrk_accumulate(const double *__restrict__ Gt, int npad, int type, int I, int J,
+                                                size_t k_begin, int nsteps) {
   const int lane = threadIdx.x;
-  const size_t k_begin = (size_t)sg * nsteps * 4;
   const double *base = Gt + (k_begin + (lane >> 4)) * (size_t)npad + (lane & 15);
   const double *pa = base + I * TILE;
   const double *pb = base + J * TILE;
   const size_t step = (size_t)4 * npad;
-  const int ntiles = njobs;
-
-  BALM_SYRK_ZERO_ACC();
   if (type == 0) syrk_sweep(pa, pb, step, nsteps);
   else if (type == 1) syrk_sweep_mixed1(pa, step, nsteps);
   else if (type == 2) syrk_sweep_mixed2(pa, step, nsteps);
   else syrk_sweep_mixed3(pa, step, nsteps);
+}
+
+__device__ __forceinline__ void syrk_write_out(double *__restrict__ out) {
   // MFMA (16 passes) -> v_accvgpr_read needs wait states the assembler will not insert for asm
   asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
-
-  double *out = part + ((size_t)sg * ntiles + tile) * TILE_ELEMS + lane;     // register-major: coalesced
+  out += threadIdx.x;                                                        // register-major: coalesced
 #define BALM_X(T)                                                                             \
   {                                                                                           \
     unsigned U[8];                                                                            \
@@ -676,6 +662,46 @@ __global__ __launch_bounds__(64) void k_hessian_syrk(const double *__restrict__ 
   }
   BALM_SYRK_FOR_TILES(BALM_X)
 #undef BALM_X
+}
+
+// XCD-aware remap: hardware places workgroup b on XCD b % 8; every XCD gets a contiguous run of logical workgroups.
+__device__ __forceinline__ long xcd_remap(long bid, long nblocks) {
+  const long q = nblocks >> 3, r = nblocks & 7, x = bid & 7;       // XCD x runs q (+1 if x < r) logical workgroups
+  return x * q + (x < r ? x : r) + (bid >> 3);
+}
+
+__global__ __launch_bounds__(64) void k_hessian_syrk(const double *__restrict__ Gt, int npad, int njobs,
+                                                     const int *__restrict__ jobs, int nsteps, long nblocks,
+                                                     double *__restrict__ part) {
+  // Dense plan: one wavefront per (job, k-slice).  The remap gives an XCD ALL jobs of one k-slice after the other:
+  // an XCD holds 128 of these one-wave workgroups (4 per CU), i.e. the jobs of a slice run side by side and sweep
+  // k in lockstep (they are all MFMA-paced, 25 MFMAs per k-step each), so each 128-byte line of Gt is pulled into
+  // that XCD's L2 once and serves the ~15 jobs that need it.
+  const long bid = xcd_remap(blockIdx.x, nblocks);
+  const int tile = (int)(bid % njobs);
+  const int sg = (int)(bid / njobs);
+  BALM_SYRK_ZERO_ACC();
+  syrk_accumulate(Gt, npad, jobs[4 * tile], jobs[4 * tile + 1], jobs[4 * tile + 2], (size_t)sg * nsteps * 4, nsteps);
+  syrk_write_out(part + ((size_t)sg * njobs + tile) * TILE_ELEMS);
+}
+
+// Block-sparse plan (real co-visibility: the reference only visits observed pose pairs, bavoxel.hpp:365,404-418 `N != 0`
+// guards).  The columns of Gt are ordered so that features observing the same stretch of the trajectory are neighbours
+// and cut into chunks of nsteps k-steps; a job only needs the chunks whose features touch both of its row blocks.  An
+// item = (job, a run of that job's chunk list): the wave walks its chunks and keeps accumulating in the same registers,
+// so the number of partial tiles (51 KB each, written here and read by the reduction) does not grow with the sparsity
+// granularity.  items[4 i] = job, first entry of chunk_ids, entry count, output slot (slots are grouped by job).
+__global__ __launch_bounds__(64) void k_hessian_syrk_sparse(const double *__restrict__ Gt, int npad,
+                                                            const int *__restrict__ jobs, const int *__restrict__ items,
+                                                            const int *__restrict__ chunk_ids, int nsteps, long nitems,
+                                                            double *__restrict__ part) {
+  const long bid = xcd_remap(blockIdx.x, nitems);
+  const int tile = items[4 * bid], first = items[4 * bid + 1], count = items[4 * bid + 2], slot = items[4 * bid + 3];
+  const int type = jobs[4 * tile], I = jobs[4 * tile + 1], J = jobs[4 * tile + 2];
+  BALM_SYRK_ZERO_ACC();
+  for (int c = 0; c < count; c++)
+    syrk_accumulate(Gt, npad, type, I, J, (size_t)chunk_ids[first + c] * nsteps * 4, nsteps);
+  syrk_write_out(part + (size_t)slot * TILE_ELEMS);
 }
 
 SyrkPlan plan_syrk(int ntiles, long K) {
@@ -696,6 +722,13 @@ SyrkPlan plan_syrk(int ntiles, long K) {
     if (eff > best + 1e-9) { best = eff; sg = c; }
   }
   if (sg > max_sg) sg = max_sg;
+  // small problems (the shipped window: 1 700 k-steps): four rounds of short waves would mostly write and re-read partial
+  // tiles (51 KB each); one round of longer waves does the same MFMAs with a quarter of that traffic
+  if (steps / sg < 128 && sg > 1) {
+    long one_round = 1024 / ntiles;
+    if (one_round < 1) one_round = 1;
+    if (one_round < sg) sg = one_round;
+  }
   long nst = (steps + sg - 1) / sg;
   nst = (nst + SYRK_NBUF - 1) / SYRK_NBUF * SYRK_NBUF;      // whole turns of the prefetch ring
   p.SG = (int)sg;
@@ -703,6 +736,12 @@ SyrkPlan plan_syrk(int ntiles, long K) {
   p.Kpad = (int)(sg * nst * 4);
   p.nblocks = sg * ntiles;
   return p;
+}
+
+void launch_syrk_sparse(hipStream_t s, const double *Gt, int npad, const int *jobs, const int *items, const int *chunk_ids,
+                        int nsteps, long nitems, double *part) {
+  hipLaunchKernelGGL(k_hessian_syrk_sparse, dim3((unsigned)nitems), dim3(64), 0, s, Gt, npad, jobs, items, chunk_ids, nsteps,
+                     nitems, part);
 }
 
 void launch_syrk(hipStream_t s, const double *Gt, int npad, int ntiles, const int *tileIJ, const SyrkPlan &p,
@@ -729,6 +768,26 @@ __global__ __launch_bounds__(256) void k_reduce_tiles(const double *__restrict__
     }
     for (; g < SG; g++) s0 += pp[(size_t)g * tile_total];
     red[t] = (s0 + s1) + (s2 + s3);
+  }
+}
+
+// block-sparse plan: the partial tiles of job j are slots ptr[j] .. ptr[j+1]-1 (chunk order: deterministic)
+__global__ __launch_bounds__(256) void k_reduce_tiles_csr(const double *__restrict__ part, const int *__restrict__ ptr,
+                                                          long tile_total, double *__restrict__ red) {
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < tile_total; t += (long)gridDim.x * blockDim.x) {
+    const int job = (int)(t / TILE_ELEMS);
+    const long e = t - (long)job * TILE_ELEMS;
+    const int s0 = ptr[job], s1 = ptr[job + 1];
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    int g = s0;
+    for (; g + 3 < s1; g += 4) {
+      a0 += part[(size_t)g * TILE_ELEMS + e];
+      a1 += part[(size_t)(g + 1) * TILE_ELEMS + e];
+      a2 += part[(size_t)(g + 2) * TILE_ELEMS + e];
+      a3 += part[(size_t)(g + 3) * TILE_ELEMS + e];
+    }
+    for (; g < s1; g++) a0 += part[(size_t)g * TILE_ELEMS + e];
+    red[t] = (a0 + a1) + (a2 + a3);
   }
 }
 
@@ -773,10 +832,11 @@ __global__ __launch_bounds__(256) void k_reduce_dacc(const double *__restrict__ 
 }
 
 void launch_reduce(hipStream_t s, const double *part, int SG, long tile_total, const double *dpart, int nblk,
-                   int dacc_len, const double *rpart, int nr, double *red, long dacc_off, long r_off) {
+                   int dacc_len, const double *rpart, int nr, double *red, long dacc_off, long r_off, const int *csr_ptr) {
   int grid = (int)((tile_total + 255) / 256);
   if (grid > 8192) grid = 8192;
-  hipLaunchKernelGGL(k_reduce_tiles, dim3(grid), dim3(256), 0, s, part, SG, tile_total, red);
+  if (csr_ptr) hipLaunchKernelGGL(k_reduce_tiles_csr, dim3(grid), dim3(256), 0, s, part, csr_ptr, tile_total, red);
+  else hipLaunchKernelGGL(k_reduce_tiles, dim3(grid), dim3(256), 0, s, part, SG, tile_total, red);
   hipLaunchKernelGGL(k_reduce_dacc, dim3((dacc_len + 63) / 64), dim3(256), 0, s, dpart, nblk, dacc_len, rpart, nr,
                      red + dacc_off, red + r_off);
 }

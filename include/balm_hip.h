@@ -219,8 +219,9 @@ int balm_get_solve_trace(balm_ctx *ctx, long long *ticks, long capacity, int *di
 int balm_reset_timing(balm_ctx *ctx);
 
 /* Work model of the last balm_set_features: out[0] = S = sum_a n_a, out[1] = sum_a n_a(n_a+1)/2,
- * out[2] = algorithmic FLOPs of one hessian_syrk launch (dense, upper triangle incl. diagonal
- * blocks: 108*F*W*(W+1) flops), out[3] = FLOPs the launch actually issues (tile padding incl.). */
+ * out[2] = algorithmic FLOPs of one hessian_syrk launch = 216 * out[1] (three 6x6 rank-1 updates per observed
+ * unordered pose pair incl. the diagonal; 108*F*W*(W+1) when every pose sees every feature), out[3] = FLOPs the
+ * launch actually issues (dense plan: tile padding incl.; block-sparse plan: its (job, chunk) items). */
 int balm_work_model(balm_ctx *ctx, double *out4);
 
 const char *balm_last_error(balm_ctx *ctx);

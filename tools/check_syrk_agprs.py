@@ -6,7 +6,7 @@ park a spill or a copy in an AGPR inside the k-loop (after a ROCm upgrade, or if
 would silently corrupt the Hessian; the cross-compiled, GPU-less build could not notice.
 
 This script disassembles the built object (balm_amd/lib/kernels_accum.o, gfx950 code object) and FAILS unless,
-inside k_hessian_syrk:
+inside k_hessian_syrk and k_hessian_syrk_sparse (the same inlined body):
   * the kernel uses exactly 200 AGPRs, no scratch and no spills (code-object metadata), and
   * every instruction that names an AGPR is one of the generator's three forms:
         v_mfma_f64_16x16x4_f64 a[x:x+7], v.., v.., a[x:x+7]      (accumulate in place)
@@ -24,7 +24,7 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LLVM = "/opt/rocm/lib/llvm/bin"
-KERNEL = "k_hessian_syrk"
+KERNELS = ["k_hessian_syrkEPK", "k_hessian_syrk_sparse"]      # dense and block-sparse entry (same inlined body)
 
 
 def device_elf(obj, tmp):
@@ -37,22 +37,18 @@ def device_elf(obj, tmp):
     raise RuntimeError("no gfx950 code object in " + obj)
 
 
-def check(obj=None, verbose=True):
-    obj = obj or os.path.join(ROOT, "balm_amd", "lib", "kernels_accum.o")
+def check_kernel(kernel, notes, dis, verbose):
     problems = []
-    with tempfile.TemporaryDirectory() as tmp:
-        elf = device_elf(obj, tmp)
-        notes = subprocess.run([os.path.join(LLVM, "llvm-readelf"), "--notes", elf], capture_output=True, text=True).stdout
-        dis = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", "--no-show-raw-insn", elf], capture_output=True, text=True).stdout
     # ---- metadata: the kernel's record is the "- .agpr_count ... .name: <mangled>" block containing its name
     recs = re.split(r"\n\s+- \.agpr_count:", notes)
     meta = None
     for r in recs[1:]:
-        if re.search(r"\.name:\s+\S*%s\S*" % KERNEL, r):
+        if re.search(r"\.name:\s+\S*%s\S*" % kernel, r):
             meta = ".agpr_count:" + r
             break
     if meta is None:
-        return ["%s not found in the code-object metadata" % KERNEL]
+        return ["%s not found in the code-object metadata" % kernel]
+
     def field(k):
         m = re.search(r"\.%s:\s+(\d+)" % k, meta)
         return int(m.group(1)) if m else None
@@ -62,9 +58,9 @@ def check(obj=None, verbose=True):
     if scratch or vspill or sspill:
         problems.append("scratch %s B, vgpr spills %s, sgpr spills %s (must all be 0)" % (scratch, vspill, sspill))
     # ---- disassembly of the kernel
-    m = re.search(r"\n[0-9a-f]+ <(\S*%s\S*)>:\n(.*?)(?=\n[0-9a-f]+ <|\Z)" % KERNEL, dis, re.S)
+    m = re.search(r"\n[0-9a-f]+ <(\S*%s\S*)>:\n(.*?)(?=\n[0-9a-f]+ <|\Z)" % kernel, dis, re.S)
     if not m:
-        return problems + ["%s not found in the disassembly" % KERNEL]
+        return problems + ["%s not found in the disassembly" % kernel]
     ins = [l.strip() for l in m.group(2).splitlines() if l.strip()]
     ins = [re.sub(r"\s*//.*$", "", l) for l in ins]
     n_mfma = n_zero = n_read = 0
@@ -97,10 +93,22 @@ def check(obj=None, verbose=True):
     if first_read is not None and last_mfma is not None and first_read < last_mfma:
         problems.append("an accumulator is read before the last MFMA (instruction %d < %d): the k-loop moves accumulators" % (first_read, last_mfma))
     if verbose:
-        print("k_hessian_syrk: %d AGPRs, scratch %s, %d MFMAs, %d zeroing writes, %d read-outs -> %s"
-              % (agprs or -1, scratch, n_mfma, n_zero, n_read, "OK" if not problems else "FAILED"))
+        print("%s: %d AGPRs, scratch %s, %d MFMAs, %d zeroing writes, %d read-outs -> %s"
+              % (kernel, agprs or -1, scratch, n_mfma, n_zero, n_read, "OK" if not problems else "FAILED"))
         for p in problems:
             print("  " + p)
+    return ["%s: %s" % (kernel, p) for p in problems]
+
+
+def check(obj=None, verbose=True):
+    obj = obj or os.path.join(ROOT, "balm_amd", "lib", "kernels_accum.o")
+    with tempfile.TemporaryDirectory() as tmp:
+        elf = device_elf(obj, tmp)
+        notes = subprocess.run([os.path.join(LLVM, "llvm-readelf"), "--notes", elf], capture_output=True, text=True).stdout
+        dis = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", "--no-show-raw-insn", elf], capture_output=True, text=True).stdout
+    problems = []
+    for kernel in KERNELS:
+        problems += check_kernel(kernel, notes, dis, verbose)
     return problems
 
 
