@@ -493,12 +493,24 @@ static int one_build_clusters(balm_ctx *ctx, int F, const float *xyz, const int 
   if (e == hipSuccess) e = hipMemcpyAsync(d_f, feat_id, (size_t)n_pts * sizeof(int), hipMemcpyHostToDevice, ctx->stream);
   if (e == hipSuccess) e = hipMemcpyAsync(d_p, pose_id, (size_t)n_pts * sizeof(int), hipMemcpyHostToDevice, ctx->stream);
   if (e == hipSuccess) e = hipMemsetAsync(ctx->d_cl, 0, count * sizeof(double), ctx->stream);
+  int *d_flag = reinterpret_cast<int *>(ctx->d_scal + 8);           // a spare device scalar slot
+  if (e == hipSuccess) e = hipMemsetAsync(d_flag, 0, sizeof(int), ctx->stream);
   if (e == hipSuccess) {
     {
       Span sp(ctx, BALM_T_BUILD);
-      launch_build_clusters(ctx->stream, d_xyz, d_f, d_p, n_pts, F, W, ctx->d_cl);
+      launch_build_clusters(ctx->stream, d_xyz, d_f, d_p, n_pts, F, W, ctx->d_cl, d_flag);
     }
-    e = hipStreamSynchronize(ctx->stream);
+    int unsorted = 0;
+    e = hipMemcpyAsync(&unsorted, d_flag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess && unsorted) {       // points not grouped by (feature, pose): the order-free build
+      e = hipMemsetAsync(ctx->d_cl, 0, count * sizeof(double), ctx->stream);
+      if (e == hipSuccess) {
+        Span sp(ctx, BALM_T_BUILD);
+        launch_build_clusters_any(ctx->stream, d_xyz, d_f, d_p, n_pts, F, W, ctx->d_cl);
+      }
+      if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    }
   }
   if (d_xyz) hipFree(d_xyz);
   if (d_f) hipFree(d_f);

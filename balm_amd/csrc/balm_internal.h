@@ -216,7 +216,9 @@ void launch_congruence_inverse(balm_ctx *c, const double *Rraw, double *T0, doub
 
 // launchers (kernels_build.hip)
 void launch_build_clusters(hipStream_t s, const float *xyz, const int *feat_id, const int *pose_id, long n_pts,
-                           int F, int W, double *soa);
+                           int F, int W, double *soa, int *unsorted_flag);      // grouped points: no atomics, bit-exact pushes
+void launch_build_clusters_any(hipStream_t s, const float *xyz, const int *feat_id, const int *pose_id, long n_pts,
+                               int F, int W, double *soa);                       // any order: atomics
 void launch_soa_to_aos(hipStream_t s, const double *soa, double *aos, int F, int W);
 
 }  // namespace balm

@@ -200,9 +200,18 @@ def test_build_clusters_matches_push():
     pid = np.tile(np.repeat(np.arange(W, dtype=np.int32), pts), F)
     c = capi.Context(W)
     got = c.build_clusters(F, xyz, fid, pid, None, sc.coeffs)
-    assert np.array_equal(got[..., 9], sc.clusters[..., 9])       # counts: bit-exact
-    assert rel_err(got, sc.clusters) < 1e-14
-    # shuffled input (runs broken up) must give the same clusters
+    # grouped points: every cluster is pushed point by point in order by one lane with the reference's operation
+    # sequence -> bit-identical to the host's PointCluster::push, every entry (and run to run)
+    assert np.array_equal(got, sc.clusters)
+    assert np.array_equal(c.build_clusters(F, xyz, fid, pid, None, sc.coeffs), got)
+    # runs longer than a wavefront's 64 points and runs that straddle its windows
+    sc2 = scene.generate(51, 5, 7, 150, keep_points=True)
+    fid2 = np.repeat(np.arange(7, dtype=np.int32), 5 * 150)
+    pid2 = np.tile(np.repeat(np.arange(5, dtype=np.int32), 150), 7)
+    c2 = capi.Context(5)
+    assert np.array_equal(c2.build_clusters(7, sc2.points.reshape(-1, 3), fid2, pid2, None, sc2.coeffs), sc2.clusters)
+    c2.close()
+    # shuffled input (runs broken up: the order-free build takes over) must give the same clusters
     perm = np.random.default_rng(0).permutation(xyz.shape[0])
     got2 = c.build_clusters(F, xyz[perm], fid[perm], pid[perm], None, sc.coeffs)
     assert np.array_equal(got2[..., 9], sc.clusters[..., 9])

@@ -32,6 +32,6 @@ kern = ms / n * 1e-3
 got = ctx.build_clusters(F, xyz, fid, pid, None, sc.coeffs)
 err = float(np.abs(got - sc.clusters).max() / np.abs(sc.clusters).max())
 print(json.dumps({"kernel": "k_build_clusters", "points": n_pts, "W": W, "F": F, "kernel_ms": kern * 1e3,
-                  "algorithmic_bytes": alg_bytes, "achieved_GBps": alg_bytes / kern / 1e9, "peak_GBps": 8000.0,
+                  "algorithmic_bytes": alg_bytes, "achieved_GBps": alg_bytes / kern / 1e9, "peak_GBps": 8000.0, "deterministic": True, "atomics": 0,
                   "frac_of_8TBps": alg_bytes / kern / 8e12, "points_per_s": n_pts / kern,
                   "call_wall_ms_incl_pcie": wall * 1e3, "max_rel_err_vs_host_push": err}))
