@@ -69,6 +69,25 @@ int ensure(balm_ctx *ctx, T **p, size_t *cap, size_t count) {
   return BALM_OK;
 }
 
+// staging arena: stage_begin(total) once per call (may reallocate: nothing staged may be live), then stage_take pieces
+int stage_begin(balm_ctx *ctx, size_t total_bytes) {
+  total_bytes += 16 * 256;                                 // alignment slack for up to 16 pieces
+  ctx->stage_off = 0;
+  if (ctx->stage_cap >= total_bytes) return BALM_OK;
+  if (ctx->d_stage) { hipStreamSynchronize(ctx->stream); hipFree(ctx->d_stage); ctx->d_stage = nullptr; ctx->stage_cap = 0; }
+  const size_t want = total_bytes + total_bytes / 8;
+  HIP_TRY(hipMalloc((void **)&ctx->d_stage, want));
+  ctx->stage_cap = want;
+  return BALM_OK;
+}
+
+template <class T>
+T *stage_take(balm_ctx *ctx, size_t count) {
+  const size_t off = (ctx->stage_off + 255) & ~(size_t)255;
+  ctx->stage_off = off + count * sizeof(T);
+  return reinterpret_cast<T *>(ctx->d_stage + off);
+}
+
 int sync_stream(balm_ctx *ctx) {
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   HIP_TRY(hipGetLastError());
@@ -226,7 +245,7 @@ int feature_bookkeeping(balm_ctx *ctx, int F, const double *clusters, const doub
 
 extern "C" {
 
-const char *balm_version(void) { return "balm_hip 0.1.0 (gfx950)"; }
+const char *balm_version(void) { return "balm_hip 0.2.0 (gfx950)"; }
 
 const char *balm_last_error(balm_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 
@@ -326,7 +345,7 @@ static void one_destroy(balm_ctx *ctx) {
   if (ctx->stream) hipStreamSynchronize(ctx->stream);
   void *ptrs[] = {ctx->d_cl, ctx->d_fix, ctx->d_coe, ctx->d_poses, ctx->d_poses_tmp, ctx->d_C, ctx->d_feat,
                   ctx->d_Gt, ctx->d_part, ctx->d_dpart, ctx->d_rpart, ctx->d_feat_tmp, ctx->d_rpart_tmp, ctx->d_red, ctx->d_jobs, ctx->d_sub, ctx->d_H,
-                  ctx->d_g, ctx->d_A, ctx->d_Wp, ctx->d_dvec, ctx->d_z, ctx->d_x, ctx->d_perm, ctx->d_dx, ctx->d_scal, ctx->d_arena, ctx->d_pre, ctx->d_flags, ctx->d_trace, ctx->d_slot, ctx->d_items, ctx->d_csr, ctx->d_chunk_ids};
+                  ctx->d_g, ctx->d_A, ctx->d_Wp, ctx->d_dvec, ctx->d_z, ctx->d_x, ctx->d_perm, ctx->d_dx, ctx->d_scal, ctx->d_arena, ctx->d_pre, ctx->d_flags, ctx->d_trace, ctx->d_slot, ctx->d_items, ctx->d_csr, ctx->d_chunk_ids, ctx->d_stage};
   for (void *p : ptrs) if (p) hipFree(p);
   if (ctx->h_scal) hipHostFree(ctx->h_scal);
   for (auto &sp : ctx->timer.pending) { hipEventDestroy(sp.a); hipEventDestroy(sp.b); }
@@ -458,14 +477,13 @@ static int one_set_features(balm_ctx *ctx, int F, const double *clusters, const 
   int rc;
   ctx->F = 0;
   if ((rc = dalloc(ctx, &ctx->d_cl, count))) return rc;
-  double *d_aos = nullptr;
-  HIP_TRY(hipMalloc((void **)&d_aos, count * sizeof(double)));
+  if ((rc = stage_begin(ctx, count * sizeof(double)))) return rc;
+  double *d_aos = stage_take<double>(ctx, count);
   hipError_t e = hipMemcpyAsync(d_aos, clusters, count * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
   if (e == hipSuccess) {
     launch_transpose_clusters(ctx->stream, d_aos, ctx->d_cl, F, W);
     e = hipStreamSynchronize(ctx->stream);
   }
-  hipFree(d_aos);
   HIP_TRY(e);
   if (!ctx->multi && (rc = feature_bookkeeping(ctx, F, clusters, fix, coeffs))) return rc;    // sharded: done once on the whole table
   if ((rc = build_sparse_plan(ctx, F, clusters))) return rc;
@@ -485,10 +503,12 @@ static int one_build_clusters(balm_ctx *ctx, int F, const float *xyz, const int 
   int rc;
   ctx->F = 0;
   if ((rc = dalloc(ctx, &ctx->d_cl, count))) return rc;
-  float *d_xyz = nullptr; int *d_f = nullptr, *d_p = nullptr;
-  HIP_TRY(hipMalloc((void **)&d_xyz, (size_t)(n_pts ? n_pts : 1) * 3 * sizeof(float)));
-  hipError_t e = hipMalloc((void **)&d_f, (size_t)(n_pts ? n_pts : 1) * sizeof(int));
-  if (e == hipSuccess) e = hipMalloc((void **)&d_p, (size_t)(n_pts ? n_pts : 1) * sizeof(int));
+  const size_t np1 = (size_t)(n_pts ? n_pts : 1);
+  if ((rc = stage_begin(ctx, np1 * 20 + count * sizeof(double)))) return rc;
+  float *d_xyz = stage_take<float>(ctx, np1 * 3);
+  int *d_f = stage_take<int>(ctx, np1), *d_p = stage_take<int>(ctx, np1);
+  double *d_aos = stage_take<double>(ctx, count);
+  hipError_t e = hipSuccess;
   if (e == hipSuccess) e = hipMemcpyAsync(d_xyz, xyz, (size_t)n_pts * 3 * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
   if (e == hipSuccess) e = hipMemcpyAsync(d_f, feat_id, (size_t)n_pts * sizeof(int), hipMemcpyHostToDevice, ctx->stream);
   if (e == hipSuccess) e = hipMemcpyAsync(d_p, pose_id, (size_t)n_pts * sizeof(int), hipMemcpyHostToDevice, ctx->stream);
@@ -512,18 +532,12 @@ static int one_build_clusters(balm_ctx *ctx, int F, const float *xyz, const int 
       if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     }
   }
-  if (d_xyz) hipFree(d_xyz);
-  if (d_f) hipFree(d_f);
-  if (d_p) hipFree(d_p);
   HIP_TRY(e);
   // host copy of the cluster table (also feeds the planes-per-pose precheck)
   std::vector<double> host(count);
-  double *d_aos = nullptr;
-  HIP_TRY(hipMalloc((void **)&d_aos, count * sizeof(double)));
   launch_soa_to_aos(ctx->stream, ctx->d_cl, d_aos, F, W);
   e = hipMemcpyAsync(host.data(), d_aos, count * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-  hipFree(d_aos);
   HIP_TRY(e);
   if (clusters_out) std::memcpy(clusters_out, host.data(), count * sizeof(double));
   if ((rc = feature_bookkeeping(ctx, F, host.data(), fix, coeffs))) return rc;
@@ -563,9 +577,14 @@ static int one_associate(balm_ctx *ctx, const balm_voxel_opts *opts, const float
     const size_t want = (size_t)n_pts * 100 + (64u << 20);
     if (hipMalloc(&ctx->d_arena, want) == hipSuccess) ctx->arena_cap = want; else { ctx->d_arena = nullptr; hipGetLastError(); }
   }
-  HIP_TRY(hipMalloc((void **)&d_xyz, (size_t)n_pts * 3 * sizeof(float)));
-  hipError_t e = hipMalloc((void **)&d_f, (size_t)n_pts * sizeof(int));
-  if (e == hipSuccess) e = hipMalloc((void **)&d_pos, (size_t)12 * WT * sizeof(double));
+  {
+    int rcs = stage_begin(ctx, (size_t)n_pts * 16 + (size_t)12 * WT * sizeof(double));
+    if (rcs) return rcs;
+  }
+  d_xyz = stage_take<float>(ctx, (size_t)n_pts * 3);
+  d_f = stage_take<int>(ctx, (size_t)n_pts);
+  d_pos = stage_take<double>(ctx, (size_t)12 * WT);
+  hipError_t e = hipSuccess;
   if (e == hipSuccess) e = hipMemcpyAsync(d_xyz, xyz, (size_t)n_pts * 3 * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
   if (e == hipSuccess) e = hipMemcpyAsync(d_f, frame_id, (size_t)n_pts * sizeof(int), hipMemcpyHostToDevice, ctx->stream);
   if (e == hipSuccess) e = hipMemcpyAsync(d_pos, poses, (size_t)12 * WT * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
@@ -583,9 +602,6 @@ static int one_associate(balm_ctx *ctx, const balm_voxel_opts *opts, const float
     ctx->arena_cap = need + need / 8;
     if (hipMalloc(&ctx->d_arena, ctx->arena_cap) != hipSuccess) { ctx->d_arena = nullptr; ctx->arena_cap = 0; hipGetLastError(); }
   }
-  if (d_xyz) hipFree(d_xyz);
-  if (d_f) hipFree(d_f);
-  if (d_pos) hipFree(d_pos);
   HIP_TRY(e);
   if (arc == -3) { ctx->err = "balm_associate: frame_id out of range or non-finite point"; return BALM_ERR_ARG; }
   if (arc) { ctx->err = arc == -2 ? "balm_associate: unsupported size" : "balm_associate: device failure"; return BALM_ERR_HIP; }
@@ -662,13 +678,14 @@ static int one_pose_covariance(balm_ctx *ctx, const double *poses, const double 
   if ((rc = ensure(ctx, &ctx->d_dpart, &ctx->cap_dpart, (size_t)nblk * DACC_MAX * W))) return rc;
   // scratch: [redX | redY | S (21 W)] (one all-reduce payload) | Rraw | Rcov | T0, T1 (nA x nA each)
   const size_t pay = 2 * tiles + (size_t)21 * W, nn = (size_t)n * n;
-  double *buf = nullptr, *d_cc = nullptr;
-  HIP_TRY(hipMalloc((void **)&buf, (pay + 2 * nn + 2 * (size_t)nA * nA) * sizeof(double)));
+  const size_t ncc = (cluster_cov && F > 0) ? (size_t)F * W * 81 : 0;
+  if ((rc = stage_begin(ctx, (pay + 2 * nn + 2 * (size_t)nA * nA + ncc) * sizeof(double)))) return rc;
+  double *buf = stage_take<double>(ctx, pay + 2 * nn + 2 * (size_t)nA * nA), *d_cc = nullptr;
   double *redx = buf, *redy = buf + tiles, *sdiag = buf + 2 * tiles, *Rraw = buf + pay, *Rc = Rraw + nn,
          *T0 = Rc + nn, *T1 = T0 + (size_t)nA * nA;
   hipError_t e = hipSuccess;
-  if (cluster_cov && F > 0) {
-    e = hipMalloc((void **)&d_cc, (size_t)F * W * 81 * sizeof(double));
+  if (ncc) {
+    d_cc = stage_take<double>(ctx, ncc);
     if (e == hipSuccess) e = hipMemcpyAsync(d_cc, cluster_cov, (size_t)F * W * 81 * sizeof(double), hipMemcpyHostToDevice, s);
   }
   double *Gx = ctx->d_Gt, *Gy = ctx->d_Gt + gcols * ctx->npad;
@@ -698,8 +715,6 @@ static int one_pose_covariance(balm_ctx *ctx, const double *poses, const double 
   }
   if (e == hipSuccess) e = hipStreamSynchronize(s);
   if (e == hipSuccess) e = hipGetLastError();
-  hipFree(buf);
-  if (d_cc) hipFree(d_cc);
   if (rc) return rc;
   HIP_TRY(e);
   collect_timing(ctx);

@@ -107,6 +107,8 @@ struct balm_ctx {
   std::vector<double> assoc_fix;
   void *d_arena = nullptr;          // balm_associate scratch, grown to what the last call needed
   size_t arena_cap = 0;
+  char *d_stage = nullptr;          // per-call staging (uploads, layout changes, covariance work matrices): grown, never
+  size_t stage_cap = 0, stage_off = 0;   // shrunk, carved by a bump pointer -- no hipMalloc / hipFree per call
   balm_allreduce_fn allreduce = nullptr;
   void *allreduce_user = nullptr;
   balm::Timer timer;

@@ -199,7 +199,6 @@ __global__ __launch_bounds__(256) void k_ldl_panel(double *__restrict__ A, int n
     Pivot4 pv;
     pivot4(a00, a10, a20, a30, a11, a21, a31, a22, a32, a33, pv);
     const double d0 = pv.d0, d1 = pv.d1, d2 = pv.d2, d3 = pv.d3;
-    const double l10 = pv.l10, l20 = pv.l20, l30 = pv.l30, l21 = pv.l21, l31 = pv.l31, l32 = pv.l32;
     if (tid < PANEL_LR) {
       const int lr = tid;
       double w0 = 0, w1 = 0, w2 = 0, w3 = 0, e0 = 0, e1 = 0, e2 = 0, e3 = 0;
@@ -219,16 +218,13 @@ __global__ __launch_bounds__(256) void k_ldl_panel(double *__restrict__ A, int n
             zvec[c0 + p0] = e0; zvec[c0 + p0 + 1] = e1; zvec[c0 + p0 + 2] = e2; zvec[c0 + p0 + 3] = e3;
           }
         }
-      } else if (blockIdx.x == 0) {                         // diagonal block: L11 and D, once
-        if (below) {
-          A[cA] = e0; A[cA + ldA] = e1; A[cA + 2 * (size_t)ldA] = e2; A[cA + 3 * (size_t)ldA] = e3;
-        } else if (lr >= p0) {                              // the pivot rows themselves: unit lower L4, D
-          const int e = lr - p0;
-          if (e >= 1) A[cA] = e == 1 ? l10 : (e == 2 ? l20 : l30);
-          if (e >= 2) A[cA + ldA] = e == 2 ? l21 : l31;
-          if (e >= 3) A[cA + 2 * (size_t)ldA] = l32;
-          dvec[c0 + lr] = e == 0 ? d0 : (e == 1 ? d1 : (e == 2 ? d2 : d3));
-        }
+      } else if (blockIdx.x == 0 && lr >= p0 && lr <= p0 + 3) {
+        // the diagonal block's D, once.  L11 is NOT written back: nothing downstream reads it, and the other
+        // workgroups of this launch may not have loaded the un-factored diagonal block yet (they start late when
+        // other streams share the device: a sharded context's replicated solves) -- an in-place L11 would race
+        // with their loads.
+        const int e = lr - p0;
+        dvec[c0 + lr] = e == 0 ? d0 : (e == 1 ? d1 : (e == 2 ? d2 : d3));
       }
     }
     __syncthreads();

@@ -504,3 +504,43 @@ def test_virtual_driver_prints_the_reference_lines(capfd):
     assert "winSize: 20" in out and "RSME:" in out and "iter0:" in out
     deg, m = [float(x.rstrip("degm,")) for x in out.split("RSME:")[1].split()[:2]]
     assert deg < 0.5 and m < 0.02           # 5 cm point noise: the reference lands in the same range
+
+
+@pytest.mark.parametrize("gap", [1e-2, 1e-6, 1e-10, 1e-14, 0.0])
+def test_device_eigen_matches_lapack_near_degenerate(gap):
+    """The 3x3 symmetric eigen-decomposition on the device (Jacobi, k_feature_eigen; the stand-in for Eigen's
+    SelfAdjointEigenSolver, bavoxel.hpp:345-351) against LAPACK (oracle/numpy_oracle.py uses numpy.linalg.eigh) on
+    planes whose two in-plane eigenvalues are nearly or exactly equal: lambda_1 = lambda_2 (1 + gap).  The residual is
+    coe * lambda_0 itself; H and g depend on u_1, u_2 only through the symmetric sum over k = 1, 2, which is well
+    conditioned at the degeneracy although the individual eigenvectors are not."""
+    from oracle import numpy_oracle as npo
+    rng = np.random.default_rng(12)
+    W, F, npt = 5, 24, 64
+    sc = scene.generate(9, W, F, 8)
+    clusters = np.zeros((F, W, 10))
+    for a in range(F):
+        # an isotropic disc (lambda_1 == lambda_2 by construction) stretched by (1 + gap) along one in-plane axis, a thin
+        # normal direction, random orientation and offset; every pose sees the same world-frame points
+        Q, _ = np.linalg.qr(rng.standard_normal((3, 3)))
+        ang = rng.uniform(0, 2 * np.pi, npt)
+        rad = np.sqrt(rng.uniform(0, 1, npt))
+        loc = np.stack([rad * np.cos(ang), rad * np.sin(ang), 1e-3 * rng.standard_normal(npt)], 1)
+        loc -= loc.mean(0)
+        C = loc[:, :2].T @ loc[:, :2] / npt
+        w, V = np.linalg.eigh(C)
+        loc[:, :2] = (loc[:, :2] @ V) / np.sqrt(w) * np.sqrt([1.0, 1.0 + gap])      # exact in-plane covariance diag(1, 1+gap)
+        pw = loc @ Q.T + rng.uniform(-2, 2, 3)
+        for i in range(W):
+            R, p = npo.pose_R(sc.poses_gt)[i], npo.pose_p(sc.poses_gt)[i]
+            pb = (pw[i::W] - p) @ R                                                   # body frame of pose i: R^T (q - p)
+            clusters[a, i] = orc.cluster_push(pb.astype(np.float64))
+    coeffs = clusters[..., 9].sum(1)
+    c = capi.Context(W)
+    c.set_features(clusters, None, coeffs)
+    for poses in (sc.poses_gt, sc.poses_init):
+        H, g, r = c.evaluate(0, poses)
+        Hn, gn, rn = npo.left_evaluate(clusters, None, coeffs, poses)
+        # lambda_0 ~ 1e-6 of lambda_1: an absolute error of one ulp of the matrix norm is ~1e-10 of the residual
+        assert abs(r - rn) <= 1e-9 * abs(rn)
+        assert rel_err(g, gn) < 1e-10 and rel_err(H, Hn) < 1e-12
+    c.close()

@@ -81,19 +81,26 @@ int main() {
   hipDeviceProp_t p; hipGetDeviceProperties(&p, 0);
   printf("device: %s  CUs=%d  clock=%d MHz\n", p.name, p.multiProcessorCount, p.clockRate / 1000);
   const int CU = p.multiProcessorCount;
-  double *out; hipMalloc(&out, sizeof(double) * 512 * CU * 8);
+  double *out; hipMalloc(&out, sizeof(double) * 512 * CU * 8 * 4);
   const int iters = 20000;
-  for (int wpb : {4, 8}) {       // waves per block = waves per CU (1 block/CU)
+  // blocks of 4 wavefronts (the kernels' launch bound); k blocks per CU = 4 k wavefronts per CU = k per SIMD.
+  // One wavefront per SIMD cannot keep the f64 MFMA pipe full (dependent-issue latency), two or more can.
+  auto launched = [](const char *what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { printf("%s: launch failed: %s\n", what, hipGetErrorString(e)); exit(1); }
+  };
+  for (int per_simd : {1, 2, 4}) {
+    const int wpc = 4 * per_simd;
     {
-      float ms = time_ms([&] { hipLaunchKernelGGL(k_mfma<8>, dim3(CU), dim3(64 * wpb), 0, 0, out, iters, 1.0); });
-      double fl = (double)CU * wpb * iters * 8 * 2048.0;
-      printf("mfma_f64_16x16x4  %d waves/CU: %8.3f ms  %7.2f TFLOP/s  (%.1f cycles/MFMA/SIMD @2.4GHz)\n", wpb, ms, fl / ms / 1e9,
-             ms * 1e-3 * 2.4e9 / ((double)iters * 8 * wpb / 4));
+      float ms = time_ms([&] { hipLaunchKernelGGL(k_mfma<8>, dim3(CU * per_simd), dim3(256), 0, 0, out, iters, 1.0); launched("k_mfma"); });
+      double fl = (double)CU * wpc * iters * 8 * 2048.0;
+      printf("mfma_f64_16x16x4  %2d waves/CU: %8.3f ms  %7.2f TFLOP/s  (%.1f cycles/MFMA/SIMD @2.4GHz)\n", wpc, ms, fl / ms / 1e9,
+             ms * 1e-3 * 2.4e9 / ((double)iters * 8 * per_simd));
     }
     {
-      float ms = time_ms([&] { hipLaunchKernelGGL(k_fma<16>, dim3(CU), dim3(64 * wpb), 0, 0, out, iters, 1.0); });
-      double fl = (double)CU * wpb * 64 * iters * 16 * 2.0;
-      printf("v_fma_f64         %d waves/CU: %8.3f ms  %7.2f TFLOP/s\n", wpb, ms, fl / ms / 1e9);
+      float ms = time_ms([&] { hipLaunchKernelGGL(k_fma<16>, dim3(CU * per_simd), dim3(256), 0, 0, out, iters, 1.0); launched("k_fma"); });
+      double fl = (double)CU * wpc * 64 * iters * 16 * 2.0;
+      printf("v_fma_f64         %2d waves/CU: %8.3f ms  %7.2f TFLOP/s\n", wpc, ms, fl / ms / 1e9);
     }
   }
   {  // 8 waves/CU: 4 MFMA + 4 VALU, sized to take about equally long alone
