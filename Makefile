@@ -1,6 +1,6 @@
 # Builds the native libraries without Python (same commands as `python -m balm_amd.build`):
 #   balm_amd/lib/libbalm_hip.so    HIP kernels + C ABI (include/balm_hip.h), gfx950 only
-#   balm_amd/lib/libbalm_scene.so  host-only: synthetic scene generator, readers, host association
+#   balm_amd/lib/libbalm_scene.so  host-only: synthetic scene generator, readers of the shipped data formats
 HIPCC    ?= /opt/rocm/bin/hipcc
 CXX      ?= g++
 HIPFLAGS  = --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=on -Wall -Wno-unused-value -Wno-unused-result -Wno-unused-function
@@ -18,7 +18,7 @@ $(LIB)/%.o: $(CSRC)/%.hip $(HIP_DEPS)
 $(LIB)/libbalm_hip.so: $(HIP_OBJS)
 	$(HIPCC) --offload-arch=gfx950 -shared -fPIC -o $@ $(HIP_OBJS) -ldl -pthread
 
-$(LIB)/libbalm_scene.so: $(CSRC)/virtual_scene.cpp $(CSRC)/association.cpp
+$(LIB)/libbalm_scene.so: $(CSRC)/virtual_scene.cpp $(CSRC)/readers.cpp
 	@mkdir -p $(LIB)
 	$(CXX) -O3 -std=c++14 -fPIC -shared -pthread -o $@ $^
 

@@ -43,20 +43,21 @@ def load_window(data_dir, n_poses=101):
     return poses, frames
 
 
-def monte_carlo(ctx, frames, poses, pnoise=0.02, runs=1, seed=0, verbose=False, gpu_assoc=True):
+def monte_carlo(ctx, frames, poses, pnoise=0.02, runs=1, seed=0, verbose=False, association=None):
     """consistency.cpp:96-170 around the GPU path: associate the noise-free scans (first scan marginalised into
     fix clusters), then per run corrupt every feature point with N(0, pnoise^2) (OCTO_TREE_NODE::corrupt,
     BAs_left.hpp:886-906), rebuild the clusters on the device, optimise from the true poses, predict the covariance
-    and score the error.  ctx: a capi.Context for len(frames) - 1 poses.  -> list of NEES, number of features"""
+    and score the error.  ctx: a capi.Context for len(frames) - 1 poses.  `association` (tests): a precomputed
+    (clusters, coeffs, layer, fix, (xyz, feature, scan)) instead of the device association.  -> list of NEES, number of features"""
     from . import realworld as rw
-    if gpu_assoc:
+    if association is None:
         F, _, (cl, co, layer, fix, pf) = rw.associate_gpu(ctx, frames, poses, want_points=True, **rw.SIM_RULES)
         allxyz = np.concatenate(frames)
         scan = np.concatenate([np.full(f.shape[0], i, np.int32) for i, f in enumerate(frames)]) - rw.SIM_RULES["fix_frames"]
         keep = (pf >= 0) & (scan >= 0)
         xyz, fid, sid = allxyz[keep], pf[keep], scan[keep]
     else:
-        cl, co, layer, fix, (xyz, fid, sid) = rw.associate(frames, poses, want_points=True, **rw.SIM_RULES)
+        cl, co, layer, fix, (xyz, fid, sid) = association
     F, W = cl.shape[0], cl.shape[1]
     gt = poses[rw.SIM_RULES["fix_frames"]:]
     out = []
@@ -82,7 +83,6 @@ def main(argv=None):
     ap.add_argument("--runs", type=int, default=1)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--device", type=int, default=0)
-    ap.add_argument("--host-assoc", action="store_true", help="associate on the host (csrc/association.cpp) instead of the GPU")
     a = ap.parse_args(argv)
     from . import capi
     poses, frames = load_window(a.data_dir)
@@ -90,7 +90,7 @@ def main(argv=None):
     print("The size of poses: %d" % W)                                                  # consistency.cpp:138
     ctx = capi.Context(W, a.device)
     t = time.time()
-    vals, F = monte_carlo(ctx, frames, poses, a.pnoise, a.runs, a.seed, verbose=a.runs == 1, gpu_assoc=not a.host_assoc)
+    vals, F = monte_carlo(ctx, frames, poses, a.pnoise, a.runs, a.seed, verbose=a.runs == 1)
     print("%d plane features, %d run(s) in %.2f s" % (F, a.runs, time.time() - t))
     print("The expected NEES is 6*%d = %d." % (W, 6 * W))                              # :169
     for v in vals:

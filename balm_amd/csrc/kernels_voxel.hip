@@ -1,5 +1,5 @@
 // Adaptive-voxel point association on gfx950 ("next" row N3 of SURVEY.md 8f): the last CPU stage of
-// the real-world pipeline.  Same decisions as the host restatement (csrc/association.cpp), i.e. as the
+// the real-world pipeline.  Same decisions as the host restatement the tests compare it with, i.e. as the
 // reference's cut_voxel / recut / tras_opt (src/benchmark/bavoxel.hpp:1170-1223, :654-776, :908-929):
 // a point's root voxel, octants and every plane test are evaluated with the reference's float/double
 // types and WITHOUT fused multiply-adds (this file is compiled -ffp-contract=off; the reference is built
@@ -346,7 +346,7 @@ __global__ __launch_bounds__(256) void k_node_totals(const double *__restrict__ 
   }
 }
 
-// eigenvalues of a symmetric 3x3 (cyclic Jacobi, same rotation order as csrc/association.cpp)
+// eigenvalues of a symmetric 3x3 (cyclic Jacobi, same rotation order as the host restatement the tests compare it with)
 __device__ void eigvals3(double a00, double a01, double a02, double a11, double a12, double a22, double lam[3]) {
   for (int sweep = 0; sweep < 60; sweep++) {
     const double off = a01 * a01 + a02 * a02 + a12 * a12, dia = a00 * a00 + a11 * a11 + a22 * a22;

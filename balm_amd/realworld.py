@@ -1,11 +1,10 @@
 """ROS/PCL-free real-world pipeline: what the reference's benchmark_realworld driver
 does around the optimizer (src/benchmark/benchmark_realworld.cpp:144-218) -- read alidarPose.csv and the
 binary PCD scans, express poses relative to pose 0, associate points to plane features by adaptive
-voxelisation (csrc/association.cpp restating bavoxel.hpp's cut_voxel / recut / tras_opt) -- feeding the
-GPU path through the C ABI.  `associate` is the host C++ association; `associate_gpu` (--gpu-assoc) runs the
-same decisions on the device (balm_associate, csrc/kernels_voxel.hip).
+voxelisation (bavoxel.hpp's cut_voxel / recut / tras_opt, on the device: balm_associate, csrc/kernels_voxel.hip;
+SURVEY.md 8f N3) -- feeding the GPU path through the C ABI.  Nothing runs on the CPU between the files and the result.
 
-    python -m balm_amd.realworld /path/to/datas/benchmark_realworld [--voxel 2.0] [--gpu-assoc]
+    python -m balm_amd.realworld /path/to/datas/benchmark_realworld [--voxel 2.0]
 """
 import ctypes as C
 import os
@@ -23,7 +22,6 @@ def _p(a):
 
 def _lib():
     L = scene.host_lib()
-    L.balm_assoc_create.restype = C.c_void_p
     L.balm_read_pcd_xyz.restype = C.c_long
     return L
 
@@ -66,52 +64,11 @@ SIM_RULES = dict(voxel_size=1.0, eigen_thresholds=(1.0 / 64, 1.0 / 64, 1.0 / 64)
                  strict=(0.001, 25.0, 1e-10), fix_frames=1, min_observers=0)
 
 
-def associate(frames_xyz, poses, voxel_size=2.0, eigen_thresholds=(1.0 / 16, 1.0 / 16, 1.0 / 9), layer_limit=2,
-              min_ps=15, strict=None, fix_frames=0, min_observers=2, want_points=False):
-    """frames_xyz: list of [n_i,3] float32 body-frame scans; poses [W,12].  Returns (clusters [F,W,10],
-    coeffs [F], layer [F]).  Defaults = benchmark_realworld.cpp:183-185 + launch/benchmark_realworld.launch:4.
-    With fix_frames / strict / want_points (the consistency driver, `**SIM_RULES`): W counts the scans after the
-    marginalised ones and the result is (clusters, coeffs, layer, fix [F,10], points) with points = (xyz [n,3]
-    float32, feature [n], scan [n]) of every feature, or None."""
-    L = _lib()
-    L.balm_assoc_export_points.restype = C.c_long
-    W = len(frames_xyz)
-    thr = np.asarray(eigen_thresholds, dtype=np.float32)
-    h = C.c_void_p(L.balm_assoc_create(W, C.c_double(voxel_size), _p(thr), layer_limit, min_ps))
-    extended = strict is not None or fix_frames or want_points or min_observers != 2
-    try:
-        if extended:
-            st = strict or (0.0, 0.0, 0.0)
-            L.balm_assoc_set_rules(h, C.c_double(st[0]), C.c_double(st[1]), C.c_double(st[2]), fix_frames, min_observers)
-        poses = np.ascontiguousarray(poses, dtype=np.float64)
-        for i, xyz in enumerate(frames_xyz):
-            xyz = np.ascontiguousarray(xyz, dtype=np.float32)
-            rc = L.balm_assoc_add_frame(h, i, _p(xyz), C.c_long(xyz.shape[0]), _p(poses[i]))
-            assert rc == 0
-        F = L.balm_assoc_finish(h)
-        cl = np.zeros((F, W - fix_frames, 10))
-        co = np.zeros(F)
-        layer = np.zeros(F, dtype=np.int32)
-        L.balm_assoc_export(h, _p(cl), _p(co), _p(layer))
-        if extended:
-            fix = np.zeros((F, 10))
-            L.balm_assoc_export_fix(h, _p(fix))
-            pts = None
-            if want_points:
-                n = L.balm_assoc_export_points(h, None, None, None)
-                xyz, fid, sid = np.zeros((n, 3), np.float32), np.zeros(n, np.int32), np.zeros(n, np.int32)
-                L.balm_assoc_export_points(h, _p(xyz), _p(fid), _p(sid))
-                pts = (xyz, fid, sid)
-    finally:
-        L.balm_assoc_destroy(h)
-    if extended:
-        return cl, co, layer, fix, pts
-    return cl, co, layer
-
-
 def associate_gpu(ctx, frames_xyz, poses, voxel_size=2.0, eigen_thresholds=(1.0 / 16, 1.0 / 16, 1.0 / 9), layer_limit=2,
                   min_ps=15, strict=None, fix_frames=0, min_observers=2, want_points=False, want_features=True):
-    """Same contract and rule set as `associate` (e.g. `**SIM_RULES`), on the device through balm_associate; the
+    """frames_xyz: list of [n_i,3] float32 body-frame scans; poses [W,12].  Defaults = benchmark_realworld.cpp:183-185 +
+    launch/benchmark_realworld.launch:4; `**SIM_RULES` = the consistency driver's rules (W then counts the scans after
+    the marginalised ones).  The association runs on the device through balm_associate; the
     features are installed in `ctx` (a context for len(frames_xyz) - fix_frames poses).  -> (F, n_root_voxels,
     feature tuple or None); the point -> feature map refers to the concatenation of the scans."""
     xyz = np.concatenate([np.ascontiguousarray(f, dtype=np.float32).reshape(-1, 3) for f in frames_xyz])
@@ -141,7 +98,7 @@ def main(argv=None):
     ap.add_argument("data_dir")
     ap.add_argument("--voxel", type=float, default=2.0)
     ap.add_argument("--device", type=int, default=0)
-    ap.add_argument("--gpu-assoc", action="store_true", help="adaptive voxelisation on the GPU (balm_associate)")
+    ap.add_argument("--gpu-assoc", action="store_true", help="(default since round 2; accepted for old command lines)")
     ap.add_argument("--out", default=None, help="write optimised poses (W x 12) here as .npy")
     a = ap.parse_args(argv)
     from . import capi
@@ -151,11 +108,7 @@ def main(argv=None):
     W = poses.shape[0]
     ctx = capi.Context(W, a.device)
     t = time.time()
-    if a.gpu_assoc:
-        F = associate_gpu(ctx, frames, poses, a.voxel, want_features=False)[0]
-    else:
-        cl, co, _ = associate(frames, poses, a.voxel)
-        F = cl.shape[0]
+    F = associate_gpu(ctx, frames, poses, a.voxel, want_features=False)[0]
     t_assoc = time.time() - t
     print("The size of poses: %d" % W)                                   # benchmark_realworld.cpp:171
     print("read %d points in %.1f s; %d plane features in %.1f s" % (sum(f.shape[0] for f in frames), t_read, F, t_assoc))
@@ -163,8 +116,6 @@ def main(argv=None):
         print("Initial error too large.\nPlease loose plane determination criteria for more planes.\n"
               "The optimization is terminated.")
         return 1
-    if not a.gpu_assoc:
-        ctx.set_features(cl, None, co)
     t = time.time()
     out, lg = ctx.damping_iter(poses, form=capi.FORM_LEFT, u0=0.01, max_iter=10, min_planes=20, verbose=True)
     print("optimised in %d LM iterations, %.2f ms" % (len(lg), (time.time() - t) * 1e3))

@@ -1,7 +1,7 @@
 """Synthetic plane-cloud scenes: the ROS-free restatement of the reference's benchmark_virtual
 generator (csrc/virtual_scene.cpp; /root/reference/src/benchmark/benchmark_virtual.cpp:547-606,
 :486-503).  Host-only input generation; nothing here is on the GPU hot path.  The same host library
-(libbalm_scene.so) carries the real-world input pipeline (csrc/association.cpp, see realworld.py).
+(libbalm_scene.so) carries the readers of the shipped data formats (csrc/readers.cpp, see realworld.py).
 """
 import ctypes as C
 import os
@@ -12,7 +12,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "lib", "libbalm_scene.so")
-_SRCS = [os.path.join(_HERE, "csrc", "virtual_scene.cpp"), os.path.join(_HERE, "csrc", "association.cpp")]
+_SRCS = [os.path.join(_HERE, "csrc", "virtual_scene.cpp"), os.path.join(_HERE, "csrc", "readers.cpp")]
 _LIB = None
 
 

@@ -1,10 +1,6 @@
-// Host side of the path's caller ("next" row N2 of SURVEY.md 8f): ROS/PCL-free input pipeline of
-// the reference's real-world driver -- pose CSV + binary PCD readers and the adaptive-voxel point
-// association that produces the plane features the optimizer consumes.  CPU C++ by design (SURVEY 8:
-// the association stays on the host and calls the GPU path through the C ABI); no GPU code here.
-//
-// Restates (same decisions, same float/double types where they decide voxel membership):
-//   src/benchmark/benchmark_realworld.cpp:31-106  read_pose / read_file (formats of the shipped data)
+// ORACLE -- TEST INFRASTRUCTURE ONLY: the comparator of the device association (balm_associate, csrc/kernels_voxel.hip).
+// A host restatement of the reference's adaptive-voxel association state machine, decision for decision (same
+// float/double types where they decide voxel membership), as SURVEY.md Appendix D sanctions for this off-GPU code:
 //   src/benchmark/bavoxel.hpp:1170-1223           cut_voxel      (world point -> root voxel key)
 //   src/benchmark/bavoxel.hpp:654-699             judge_eigen    (lambda0/lambda1 < threshold[layer])
 //   src/benchmark/bavoxel.hpp:701-776             cut_func / recut (<= 2 subdivisions into octants)
@@ -14,6 +10,9 @@
 // (max point-to-plane distance, lambda2/lambda1 and lambda0 bounds, :674), the marginalisation of the window's
 // first scan(s) into world-frame fix clusters (to_margi, bavoxel.hpp:778-816 == BAs_left.hpp:754-792; batch form:
 // the tree is built once, so `fix_point` starts empty), and no minimum number of observers (:38).
+// It is itself pinned, bit for bit, to both compiled copies of the reference's state machine (tests/test_association.py).
+// Built into oracle/libassoc_host.so (oracle/Makefile); loaded by oracle/assoc_host.py.  The product package never uses it:
+// python -m balm_amd.realworld / .consistency associate on the device.
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
@@ -371,65 +370,6 @@ void balm_assoc_export(void *h, double *clusters, double *coeffs, int *layer) {
     coeffs[f] = coe;
     if (layer) layer[f] = nd->layer;
   }
-}
-
-// alidarPose.csv (benchmark_realworld.cpp:31-73): 4 text lines per pose, rows of [R|t], element (3,3) is the
-// timestamp.  poses: up to max_poses * 12 doubles (R column-major, p); stamps optional.  Returns #poses, <0 on error.
-int balm_read_pose_csv(const char *path, int max_poses, double *poses, double *stamps) {
-  FILE *f = fopen(path, "r");
-  if (!f) return -1;
-  std::vector<double> nums;
-  double v;
-  int ch;
-  while (fscanf(f, "%lf", &v) == 1) {
-    nums.push_back(v);
-    do { ch = fgetc(f); } while (ch == ',' || ch == ' ' || ch == '\r' || ch == '\n');
-    if (ch != EOF) ungetc(ch, f);
-  }
-  fclose(f);
-  int W = (int)(nums.size() / 16);
-  if (W > max_poses) W = max_poses;
-  for (int m = 0; m < W; m++) {
-    double *q = poses + 12 * m;
-    for (int r = 0; r < 3; r++) {
-      for (int c = 0; c < 3; c++) q[3 * c + r] = nums[16 * m + 4 * r + c];
-      q[9 + r] = nums[16 * m + 4 * r + 3];
-    }
-    if (stamps) stamps[m] = nums[16 * m + 15];
-  }
-  return W;
-}
-
-// binary PCD with FIELDS x y z ... (all 4-byte floats; the shipped files have 8 fields = 32-byte records).
-// Pass xyz = NULL to query the point count.  Returns #points written, <0 on error.
-long balm_read_pcd_xyz(const char *path, float *xyz, long max_points) {
-  FILE *f = fopen(path, "rb");
-  if (!f) return -1;
-  char line[512];
-  long npts = -1;
-  int nfields = 0;
-  bool binary = false;
-  while (fgets(line, sizeof line, f)) {
-    if (!strncmp(line, "FIELDS", 6)) { for (char *p = line + 6; *p; p++) if (*p == ' ' && p[1] != ' ' && p[1] != '\n') nfields++; }
-    if (!strncmp(line, "POINTS", 6)) npts = atol(line + 7);
-    if (!strncmp(line, "DATA", 4)) { binary = !strncmp(line + 5, "binary", 6) && strncmp(line + 5, "binary_compressed", 17); break; }
-  }
-  if (npts < 0 || nfields < 3 || !binary) { fclose(f); return -2; }
-  if (!xyz) { fclose(f); return npts; }
-  if (npts > max_points) npts = max_points;
-  std::vector<float> rec((size_t)nfields * 4096);
-  long done = 0;
-  while (done < npts) {
-    const long want = std::min<long>(4096, npts - done);
-    const size_t got = fread(rec.data(), sizeof(float) * nfields, (size_t)want, f);
-    for (size_t k = 0; k < got; k++) {
-      xyz[3 * (done + k)] = rec[k * nfields]; xyz[3 * (done + k) + 1] = rec[k * nfields + 1]; xyz[3 * (done + k) + 2] = rec[k * nfields + 2];
-    }
-    done += (long)got;
-    if ((long)got < want) break;
-  }
-  fclose(f);
-  return done;
 }
 
 }  // extern "C"

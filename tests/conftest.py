@@ -30,6 +30,8 @@ def _build_native():
     from oracle import orc
     from balm_amd import scene
     orc.build()
+    from oracle import assoc_host
+    assoc_host.build()
     scene.build()
     yield
 

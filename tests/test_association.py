@@ -1,5 +1,5 @@
 """N2: the product's ROS-free real-world input pipeline -- pose CSV / binary PCD readers
-and the adaptive-voxel association (balm_amd/csrc/association.cpp) -- against the reference's own
+and the adaptive-voxel association (oracle/host_association.cpp) -- against the reference's own
 cut_voxel / recut / tras_opt compiled in oracle/_ref.  Integer/index work: bit-exact (as feature sets;
 the reference's feature ORDER is its unordered_map's iteration order)."""
 import os
@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 
 from balm_amd import realworld as rw
+from oracle import assoc_host as ah
 from balm_amd import scene
 from oracle import numpy_oracle as npo
 from oracle import ref
@@ -82,7 +83,7 @@ def test_association_matches_reference_on_synthetic_scans(tmp_path, seed, W, F, 
     poses_p, frames_p = rw.load_window(str(tmp_path))
     assert npts == sum(f.shape[0] for f in frames_p)
     assert np.abs(poses_p - poses_r).max() < 1e-14
-    cl_p, co_p, layer = rw.associate(frames_p, poses_r, voxel)      # same poses bit for bit -> same voxel keys
+    cl_p, co_p, layer = ah.associate(frames_p, poses_r, voxel)      # same poses bit for bit -> same voxel keys
     assert cl_p.shape == cl_r.shape and cl_p.shape[0] > 0
     assert np.array_equal(canon(cl_p), canon(cl_r))                 # bit-exact feature set
     assert np.array_equal(np.sort(co_p), np.sort(co_r))
@@ -99,7 +100,7 @@ def test_association_matches_reference_on_shipped_data():
     g = dict(np.load(fix))
     poses, frames = rw.load_window(data)
     assert np.abs(poses - g["poses"]).max() < 1e-13
-    cl, co, layer = rw.associate(frames, g["poses"], 2.0)
+    cl, co, layer = ah.associate(frames, g["poses"], 2.0)
     assert cl.shape == g["clusters"].shape == (2281, 177, 10)
     assert np.array_equal(canon(cl), canon(g["clusters"]))
     assert list(np.bincount(layer)) == [797, 449, 1035]
@@ -139,7 +140,7 @@ def test_consistency_rules_match_reference_association(tmp_path):
     if not ref_sim.available():
         pytest.skip("oracle/_ref/libbalm_ref_sim.so not built (needs /root/reference)")
     poses, frames = exact_plane_scans(4, 9, 40, 60)
-    cl, co, layer, fix, pts = rw.associate(frames, poses, want_points=True, **rw.SIM_RULES)
+    cl, co, layer, fix, pts = ah.associate(frames, poses, want_points=True, **rw.SIM_RULES)
     clr, fxr = ref_sim.associate(frames, poses, 1, 1.0)
     assert cl.shape == clr.shape and cl.shape[0] >= 10 and cl.shape[1] == 8
     assert np.array_equal(_canon_with_fix(cl, fix), _canon_with_fix(clr, fxr))      # bit-exact feature set, fix included
@@ -162,7 +163,7 @@ def test_consistency_rules_on_shipped_scans():
         pytest.skip("oracle/_ref/consistency_scans.npz or libbalm_ref_sim.so not built")
     d = np.load(path)
     frames = np.split(d["xyz"], np.cumsum(d["counts"])[:-1])
-    cl, co, layer, fix, _ = rw.associate(frames, d["poses"], **rw.SIM_RULES)
+    cl, co, layer, fix, _ = ah.associate(frames, d["poses"], **rw.SIM_RULES)
     clr, fxr = ref_sim.associate(frames, d["poses"], 1, 1.0)
     assert cl.shape == clr.shape == (1096, 100, 10)
     assert np.array_equal(_canon_with_fix(cl, fix), _canon_with_fix(clr, fxr))
@@ -178,13 +179,13 @@ def _golden(name):
 
 def test_host_association_matches_golden_benchmark_rules():
     g = _golden("assoc_bench_w8.npz")
-    cl, co, layer = rw.associate(g["frames"], g["poses"], 1.0)
+    cl, co, layer = ah.associate(g["frames"], g["poses"], 1.0)
     assert cl.shape == g["clusters"].shape and np.array_equal(canon(cl), canon(g["clusters"]))
     assert np.array_equal(np.sort(co), np.sort(g["coeffs"])) and len(set(layer.tolist())) == 3
 
 
 def test_host_association_matches_golden_consistency_rules():
     g = _golden("assoc_sim_w8.npz")
-    cl, co, layer, fix, _ = rw.associate(g["frames"], g["poses"], **rw.SIM_RULES)
+    cl, co, layer, fix, _ = ah.associate(g["frames"], g["poses"], **rw.SIM_RULES)
     assert cl.shape == g["clusters"].shape
     assert np.array_equal(_canon_with_fix(cl, fix), _canon_with_fix(g["clusters"], g["fix"]))

@@ -172,7 +172,10 @@ def test_consistency_experiment_on_shipped_scans():
     frames = np.split(d["xyz"], np.cumsum(d["counts"])[:-1])
     c = capi.Context(100)
     vals, F = consistency.monte_carlo(c, frames, d["poses"], pnoise=0.02, runs=4, seed=7)          # association on the GPU too
-    vals_h, F_h = consistency.monte_carlo(c, frames, d["poses"], pnoise=0.02, runs=1, seed=7, gpu_assoc=False)
+    from oracle import assoc_host as ah
+    from balm_amd import realworld as rw
+    vals_h, F_h = consistency.monte_carlo(c, frames, d["poses"], pnoise=0.02, runs=1, seed=7,
+                                          association=ah.associate(frames, d["poses"], want_points=True, **rw.SIM_RULES))
     assert F_h == F and abs(vals_h[0] - 600) < 6 * np.sqrt(1200)         # same features; the noise lands on the points in another order
     c.close()
     vals = np.array(vals)

@@ -452,11 +452,12 @@ def test_realworld_driver_end_to_end(tmp_path):
     """N2 product pipeline on the GPU box: scans + pose CSV in the shipped formats -> readers ->
     association (host C++) -> C ABI -> HIP LM loop; the oracle optimises the same features on the CPU."""
     from balm_amd import realworld as rw
+    from oracle import assoc_host as ah
     from test_association import synthetic_window, write_window
     poses, frames = synthetic_window(1, 20, 150, 40)
     write_window(str(tmp_path), poses, frames)
     P, fr = rw.load_window(str(tmp_path))
-    cl, co, layer = rw.associate(fr, P, 1.0)
+    cl, co, layer = ah.associate(fr, P, 1.0)
     assert cl.shape[0] >= 3 * 20                                     # benchmark_realworld.cpp:209
     c = capi.Context(20)
     c.set_features(cl, None, co)

@@ -1,5 +1,5 @@
 """N3: adaptive-voxel association on the GPU (balm_associate, csrc/kernels_voxel.hip) against
-the host association (csrc/association.cpp, itself pinned bit-exact to the reference's cut_voxel / recut /
+the host association (oracle/host_association.cpp, itself pinned bit-exact to the reference's cut_voxel / recut /
 tras_opt in test_association.py) and against a fixture made by the reference's own code from the shipped
 scans.  Index / integer work: the feature SET is compared bit for bit (every cluster, every N); the order
 differs by design (hash-map order vs key order)."""
@@ -10,6 +10,7 @@ import pytest
 
 from balm_amd import capi
 from balm_amd import realworld as rw
+from oracle import assoc_host as ah
 from conftest import ROOT
 from oracle import numpy_oracle as npo
 from test_association import canon, synthetic_window
@@ -44,7 +45,7 @@ def cluttered_window(seed, W, n_planes, pts_per_plane, n_clutter):
 
 
 def check_same_features(ctx, frames, poses, voxel, thr=(1.0 / 16, 1.0 / 16, 1.0 / 9), min_ps=15):
-    cl_h, co_h, layer_h = rw.associate(frames, poses, voxel, thr, 2, min_ps)
+    cl_h, co_h, layer_h = ah.associate(frames, poses, voxel, thr, 2, min_ps)
     F, nroots, feats = rw.associate_gpu(ctx, frames, poses, voxel, thr, min_ps=min_ps)
     assert F == cl_h.shape[0]
     if F == 0:
@@ -74,7 +75,7 @@ def test_device_association_feeds_the_optimizer():
     c = capi.Context(20)
     cl, _ = check_same_features(c, frames, poses, 1.0)
     out_g, lg_g = c.damping_iter(poses, form=0, u0=0.01, max_iter=10, min_planes=20)
-    cl_h, co_h, _ = rw.associate(frames, poses, 1.0)
+    cl_h, co_h, _ = ah.associate(frames, poses, 1.0)
     c2 = capi.Context(20)
     c2.set_features(cl_h, None, co_h)
     out_h, lg_h = c2.damping_iter(poses, form=0, u0=0.01, max_iter=10, min_planes=20)
@@ -99,7 +100,7 @@ def test_device_association_edge_cases():
     uv = rng.uniform(-0.4, 0.4, (200, 2))
     plane = np.column_stack([uv[:, 0] - 5.5, uv[:, 1] - 7.5, np.full(200, -2.5) + 0.002 * rng.standard_normal(200)])
     frames = [plane.astype(np.float32), np.zeros((0, 3), np.float32), np.zeros((0, 3), np.float32), np.zeros((0, 3), np.float32)]
-    assert rw.associate_gpu(c, frames, poses, 1.0)[0] == 0 == rw.associate(frames, poses, 1.0)[0].shape[0]
+    assert rw.associate_gpu(c, frames, poses, 1.0)[0] == 0 == ah.associate(frames, poses, 1.0)[0].shape[0]
     frames[2] = plane[::-1].astype(np.float32).copy()
     check_same_features(c, frames, poses, 1.0)
     assert c.F >= 1
@@ -197,7 +198,7 @@ def test_device_association_rule_options(layer_limit, min_observers, fix_frames)
     W = 10
     poses, frames = cluttered_window(9, W + fix_frames, 50, 100, 2500)
     kw = dict(voxel_size=1.0, layer_limit=layer_limit, min_observers=min_observers, fix_frames=fix_frames)
-    cl_h, co_h, lay_h, fix_h, _ = rw.associate(frames, poses, want_points=True, **kw)
+    cl_h, co_h, lay_h, fix_h, _ = ah.associate(frames, poses, want_points=True, **kw)
     c = capi.Context(W)
     F, nroots, (cl, co, layer, fix, pf) = rw.associate_gpu(c, frames, poses, want_points=True, **kw)
     assert F == cl_h.shape[0] and F > 5 and cl.shape == (F, W, 10)
@@ -222,7 +223,7 @@ def test_device_association_consistency_rules():
     compiled copy"""
     from test_association import exact_plane_scans
     poses, frames = exact_plane_scans(4, 9, 40, 60)
-    cl_h, co_h, lay_h, fix_h, _ = rw.associate(frames, poses, **rw.SIM_RULES)
+    cl_h, co_h, lay_h, fix_h, _ = ah.associate(frames, poses, **rw.SIM_RULES)
     c = capi.Context(8)
     F, nroots, (cl, co, layer, fix, pf) = rw.associate_gpu(c, frames, poses, want_points=True, **rw.SIM_RULES)
     assert F == cl_h.shape[0] >= 10

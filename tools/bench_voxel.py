@@ -7,6 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 from balm_amd import capi, realworld as rw
+from oracle import assoc_host as ah
 from test_gpu_voxel import cluttered_window
 
 W = int(os.environ.get("W", 177))
@@ -30,5 +31,5 @@ for rep in range(3):
 print("points %d  roots %d  features %d  device %.2f ms (%.2f Gpoints/s)  wall %.1f ms" % (npts, nroots, F, ms, npts / ms / 1e6, wall))
 if "--no-cpu" not in sys.argv:
     t = time.time()
-    cl, co, _ = rw.associate(frames, poses, 2.0)
+    cl, co, _ = ah.associate(frames, poses, 2.0)
     print("host C++ association: %d features in %.2f s" % (cl.shape[0], time.time() - t))

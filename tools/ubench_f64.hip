@@ -6,18 +6,32 @@
 #include <vector>
 typedef double d4 __attribute__((ext_vector_type(4)));
 
+// f64 MFMA rate with the accumulators pinned to physical AGPRs (what k_hessian_syrk does): the builtin form keeps
+// loop-carried accumulators in arch VGPRs and copies them to and from AGPRs around every MFMA, which
+// measures the copies, not the matrix pipe.  NACC = 8 accumulator tiles a[0:7] .. a[56:63].
+#define UB_CLOB "a0","a1","a2","a3","a4","a5","a6","a7","a8","a9","a10","a11","a12","a13","a14","a15","a16","a17","a18","a19","a20","a21","a22","a23","a24","a25","a26","a27","a28","a29","a30","a31","a32","a33","a34","a35","a36","a37","a38","a39","a40","a41","a42","a43","a44","a45","a46","a47","a48","a49","a50","a51","a52","a53","a54","a55","a56","a57","a58","a59","a60","a61","a62","a63"
 template <int NACC>
 __global__ __launch_bounds__(256) void k_mfma(double *out, int iters, double seed) {
-  d4 acc[NACC];
-  for (int i = 0; i < NACC; i++) acc[i] = (d4){0, 0, 0, 0};
+  static_assert(NACC == 8, "eight pinned accumulator tiles");
   double a = seed + threadIdx.x * 1e-3, b = seed - threadIdx.x * 1e-3;
-  for (int it = 0; it < iters; it++) {
 #pragma unroll
-    for (int i = 0; i < NACC; i++) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+  for (int r = 0; r < 64; r += 8)
+    asm volatile("v_accvgpr_write_b32 a0, 0" ::: UB_CLOB);        // (zero start values do not matter for the rate)
+  for (int it = 0; it < iters; it++) {
+    asm volatile(
+        "v_mfma_f64_16x16x4_f64 a[0:7], %0, %1, a[0:7]\n\t"
+        "v_mfma_f64_16x16x4_f64 a[8:15], %0, %1, a[8:15]\n\t"
+        "v_mfma_f64_16x16x4_f64 a[16:23], %0, %1, a[16:23]\n\t"
+        "v_mfma_f64_16x16x4_f64 a[24:31], %0, %1, a[24:31]\n\t"
+        "v_mfma_f64_16x16x4_f64 a[32:39], %0, %1, a[32:39]\n\t"
+        "v_mfma_f64_16x16x4_f64 a[40:47], %0, %1, a[40:47]\n\t"
+        "v_mfma_f64_16x16x4_f64 a[48:55], %0, %1, a[48:55]\n\t"
+        "v_mfma_f64_16x16x4_f64 a[56:63], %0, %1, a[56:63]"
+        :: "v"(a), "v"(b) : UB_CLOB);
   }
-  double s = 0;
-  for (int i = 0; i < NACC; i++) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
-  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+  unsigned lo, hi;
+  asm volatile("s_nop 15\n\ts_nop 15\n\tv_accvgpr_read_b32 %0, a0\n\tv_accvgpr_read_b32 %1, a1" : "=v"(lo), "=v"(hi) :: UB_CLOB);
+  out[blockIdx.x * blockDim.x + threadIdx.x] = __hiloint2double(hi, lo);
 }
 
 template <int NCH>
