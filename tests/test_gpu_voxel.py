@@ -247,3 +247,20 @@ def test_device_association_matches_reference_golden_vectors():
     F, _, (cl, co, layer, fix, _) = rw.associate_gpu(c, g["frames"], g["poses"], **rw.SIM_RULES)
     assert np.array_equal(_canon_with_fix(cl, fix), _canon_with_fix(g["clusters"], g["fix"]))
     c.close()
+
+
+def test_device_association_points_not_in_scan_order():
+    """the level sorts drop the scan bits only when the points arrive scan by scan; a shuffled input must take the full
+    sorts and still give the same FEATURE SET (sums inside a cluster follow the input order of its points, so values
+    agree to rounding, counts and layers exactly)"""
+    poses, frames = cluttered_window(5, 9, 40, 120, 400)
+    c = capi.Context(9)
+    F0, _, (cl0, co0, lay0) = rw.associate_gpu(c, frames, poses, 1.0)
+    xyz = np.concatenate(frames)
+    fid = np.concatenate([np.full(f.shape[0], i, dtype=np.int32) for i, f in enumerate(frames)])
+    perm = np.random.default_rng(1).permutation(xyz.shape[0])
+    F1, _, (cl1, co1, lay1) = c.associate(xyz[perm], fid[perm], poses, 1.0)
+    assert F0 == F1 and np.array_equal(lay0, lay1) and np.array_equal(co0, co1)
+    assert np.array_equal(cl0[..., 9], cl1[..., 9])
+    assert np.abs(cl0 - cl1).max() <= 1e-12 * np.abs(cl0).max()
+    c.close()
