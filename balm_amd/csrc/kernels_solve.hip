@@ -318,9 +318,11 @@ __global__ __launch_bounds__(256) void k_ldl_trail(double *__restrict__ A, int n
 // ~0.7 us: ~110 VALU instructions of ONE wavefront -- pivot recurrence, the rows' forward substitution, operand
 // staging -- issue-bound at ~3 ns each, plus two LDS round trips of ~100 ns; not flops, not barriers), 3.5 us near
 // update (18 KB of L[p, p-1] from the neighbour + 180 MFMAs on one CU), ~1.5 us flag hop / tile loads / write-out.
-// The launch pair spends ~20 us per panel.  Fused wins for 10 <= P <= 40 panels (0.42 vs 0.51 ms at n = 1200, 0.39 vs
-// 0.46 ms at the shipped window's n = 1062); below that its fixed cost (cooperative launch, idle helpers) shows, above
-// it the helpers (one CU per tile update, operands re-read per update) fall behind the trailing-update kernel.
+// The launch pair spends ~18.6 us per panel (since its panel kernel lost the in-place L11 store and got the row reads
+// hoisted: 0.47 ms at n = 1200, 0.51 before).  Fused wins for 18 <= P <= 44 panels (0.42 vs 0.47 ms at n = 1200, 0.39 vs
+// 0.42 at the shipped window's n = 1062, 0.56 vs 0.67 at n = 1536); below that its fixed cost (cooperative launch, idle
+// helpers) shows, above it the helpers (one CU per tile update, operands re-read per update) fall behind the
+// trailing-update kernel.
 // ------------------------------------------------------------------------------------------------
 constexpr int FT = 576;                         // 9 wavefronts: one per 16x16 sub-tile of a 48x48 tile
 constexpr int FLR = 2 * NB;                     // local rows of a panel workgroup: 48 diagonal + 48 own
@@ -382,10 +384,16 @@ __device__ void fused_panel_role(const FusedArgs &a, int rb, double *lds) {
     FUSED_TRACE(0);
     // ---- tiles with their far updates ----
     if (tid == 0) {
-      if (own && p - c_first >= 2) flag_wait(a.far + (size_t)rb * P + p);
-      if (p >= 2) flag_wait(a.far + (size_t)p * P + p);
-      if (p >= 1 && rb != p) flag_wait(a.done + (size_t)p * P + (p - 1));            // L[p, p-1]
-      if (p >= 1 && !had_prev) flag_wait(a.done + (size_t)(p - 1) * P + (p - 1));    // D of panel p-1 from its owner
+      // the (up to four) flags of a column are polled together: a flag read is a round trip to memory
+      const int *f0 = (own && p - c_first >= 2) ? a.far + (size_t)rb * P + p : nullptr;
+      const int *f1 = p >= 2 ? a.far + (size_t)p * P + p : nullptr;
+      const int *f2 = (p >= 1 && rb != p) ? a.done + (size_t)p * P + (p - 1) : nullptr;             // L[p, p-1]
+      const int *f3 = (p >= 1 && !had_prev) ? a.done + (size_t)(p - 1) * P + (p - 1) : nullptr;     // D of panel p-1 from its owner
+      for (;;) {
+        const int v0 = f0 ? flag_peek(f0) : 1, v1 = f1 ? flag_peek(f1) : 1, v2 = f2 ? flag_peek(f2) : 1, v3 = f3 ? flag_peek(f3) : 1;
+        if (v0 & v1 & v2 & v3) break;
+        __builtin_amdgcn_s_sleep(1);
+      }
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
     __syncthreads();
@@ -519,6 +527,11 @@ __device__ void fused_panel_role(const FusedArgs &a, int rb, double *lds) {
   }
 }
 
+// Measured and rejected (round 2): a software-pipelined helper (next job's tile and operands prefetched into registers
+// while the current MFMAs run out of a second LDS buffer, flags peeked without blocking): 0.448 vs 0.422 ms at n = 1200,
+// 0.754 vs 0.564 at n = 1536, 2.47 vs 2.68 at n = 2880 -- the twelve MFMAs of a job (0.5 us) cannot cover a 1.5 us
+// load, and the extra flag round trip and barriers per job make the helpers the bottleneck where they were not.  What a
+// helper needs is more jobs in flight per CU, not a deeper pipeline inside one workgroup.
 __device__ void fused_helper_role(const FusedArgs &a, int h, double *lds) {
   const int nA = a.nA, P = a.P, ldA = 2 * nA + NB;
   double *__restrict__ A = a.A;
@@ -542,10 +555,13 @@ __device__ void fused_helper_role(const FusedArgs &a, int h, double *lds) {
         else { rb = P + 1 + (idx - (P - j) - 1); if (rb - P - 1 > q) continue; }     // identity block t: live from panel t on
         const int rowbase = rb < P ? NB * rb : (rb == P ? nA : nA + NB + NB * (rb - P - 1));
         const int cj = NB * j;
-        if (tid == 0) {
-          flag_wait(a.done + (size_t)rb * P + q);
-          flag_wait(a.done + (size_t)j * P + q);
-          flag_wait(a.done + (size_t)q * P + q);
+        if (tid == 0) {      // a flag read is a ~1 us round trip to memory: the three of a job are polled together
+          for (;;) {
+            const int f0 = flag_peek(a.done + (size_t)rb * P + q), f1 = flag_peek(a.done + (size_t)j * P + q),
+                      f2 = flag_peek(a.done + (size_t)q * P + q);
+            if (f0 & f1 & f2) break;
+            __builtin_amdgcn_s_sleep(1);
+          }
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         }
         __syncthreads();
@@ -647,19 +663,20 @@ static int fused_capacity(size_t lds_bytes) {
   if (hipGetDevice(&dev) != hipSuccess) return 0;
   if (hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, dev) != hipSuccess || !coop) return 0;
   if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+  if (hipFuncSetAttribute((const void *)k_ldl_fused, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) return 0;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_ldl_fused, FT, lds_bytes) != hipSuccess) return 0;
   return per_cu * cus;
 }
 
-// The factorisation proper: one persistent cooperative launch (k_ldl_fused) where it is the faster one (10..40 panels,
-// i.e. windows of 80..320 poses), the launch pair per panel otherwise (and on a device that refuses the cooperative
+// The factorisation proper: one persistent cooperative launch (k_ldl_fused) where it is the faster one (18..44 panels,
+// i.e. windows of ~140..350 poses: profiles/r02h_solve_paths_by_window.txt), the launch pair per panel otherwise (and on a device that refuses the cooperative
 // launch).  BALM_SOLVE=launches / fused forces one of them (A/B runs, tests).
 static void launch_factor(balm_ctx *c) {
   hipStream_t s = c->stream;
   const int nA = c->nA, P = nA / NB;
   const char *mode = getenv("BALM_SOLVE");              // A/B: "launches" forces the per-panel launch pair
   const bool forced = mode && !strcmp(mode, "fused");
-  const bool want_fused = !(mode && !strcmp(mode, "launches")) && P >= 2 && (forced || (P >= 10 && P <= 40));
+  const bool want_fused = !(mode && !strcmp(mode, "launches")) && P >= 2 && (forced || (P >= 18 && P <= 44));
   if (want_fused) {
     const size_t lds = (size_t)(12 * FLR + 2 * NB * NB + NB) * sizeof(double);
     if (c->fused_cap < 0) c->fused_cap = fused_capacity(lds);
