@@ -932,7 +932,28 @@ static int multi_set_features(balm_ctx *ctx, balm_multi *m, int F, const double 
   m->F = 0;
   int rc = feature_bookkeeping(ctx, F, clusters, fix, coeffs);
   if (rc) return rc;
-  for (int k = 0; k <= m->n; k++) m->fbeg[(size_t)k] = (int)((long)F * k / m->n);   // every feature costs the same (dense K3)
+  // contiguous shards of equal COST: a feature costs its observed pose pairs n_a (n_a + 1) / 2 (the block-sparse SYRK
+  // plan skips what it does not observe; with dense co-visibility every feature costs the same and this is an equal split)
+  // plus a constant for its moments / factor passes
+  {
+    const int W = ctx->W;
+    std::vector<double> cum((size_t)F + 1, 0.0);
+    for (int a = 0; a < F; a++) {
+      int na = 0;
+      const double *ca = clusters + (size_t)a * W * 10;
+      for (int i = 0; i < W; i++) na += ca[(size_t)i * 10 + 9] != 0;
+      cum[(size_t)a + 1] = cum[(size_t)a] + 0.5 * na * (na + 1.0) + 4.0 * na + 1.0;
+    }
+    m->fbeg[0] = 0;
+    for (int k = 1; k < m->n; k++) {
+      const double target = cum[(size_t)F] * k / m->n;
+      int f = (int)(std::lower_bound(cum.begin(), cum.end(), target) - cum.begin());
+      if (f < m->fbeg[(size_t)k - 1]) f = m->fbeg[(size_t)k - 1];
+      if (f > F) f = F;
+      m->fbeg[(size_t)k] = f;
+    }
+    m->fbeg[(size_t)m->n] = F;
+  }
   const size_t W = (size_t)ctx->W;
   rc = multi_run(m, [&](int k) {
     const int f0 = m->fbeg[(size_t)k], nf = m->fbeg[(size_t)k + 1] - f0;

@@ -4,7 +4,7 @@
 // HBM-bound: 20 bytes per point in (3 f32 + two i32 keys), one 80-byte cluster out per (a,i).
 //
 // k_build_clusters_runs (points grouped by (feature, pose), keys non-decreasing -- the order every driver of the
-// reference produces): a wavefront takes 512 consecutive points, parks their xyz and keys in LDS (coalesced loads, all in flight at once), compacts the
+// reference produces): a wavefront takes 512 consecutive points, parks their xyz in LDS (coalesced loads, all in flight at once), compacts the
 // heads of the runs of equal keys, and then ONE LANE PER RUN pushes the run's points one by one in order with the
 // reference's own operation sequence (P += v v^T as a rounded product and a rounded add per entry, v += p, N += 1:
 // tools.hpp:311-316 compiled without FMA) -- so a cluster is bit-identical to PointCluster::push, and lanes r, r+1 hold
@@ -25,7 +25,6 @@ __global__ __launch_bounds__(256) void k_build_clusters_runs(const float *__rest
                                                              const int *__restrict__ pid, long n_pts, int F, int W,
                                                              double *__restrict__ soa, int *__restrict__ unsorted) {
   __shared__ f3 pts[4][BUILD_BP];
-  __shared__ int2 keys[4][BUILD_BP];
   __shared__ short rstart[4][BUILD_BP + 2];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const long nblk = (n_pts + BUILD_BP - 1) / BUILD_BP;
@@ -57,7 +56,6 @@ __global__ __launch_bounds__(256) void k_build_clusters_runs(const float *__rest
       const long t = t0 + p;
       const long key = t < n_pts ? key_of(fa[j], fi[j]) : key_end;
       pts[wv][p] = q[j];
-      keys[wv][p] = make_int2(fa[j], fi[j]);
       long prev = __shfl_up(key, 1, 64);
       if (lane == 0) prev = carry;
       carry = __shfl(key, 63, 64);
@@ -71,7 +69,7 @@ __global__ __launch_bounds__(256) void k_build_clusters_runs(const float *__rest
     // ---- one lane per run: the reference's push, point by point in order (tools.hpp:311-316, one rounding per operation)
     for (int r = lane; r < runs; r += 64) {
       const int s0 = rstart[wv][r], s1 = rstart[wv][r + 1];
-      const int2 ai = keys[wv][s0];
+      const int2 ai = make_int2(fid[t0 + s0], pid[t0 + s0]);       // read a moment ago by this wave: a cache hit
       const long key = key_of(ai.x, ai.y);
       double pxx = 0, pxy = 0, pxz = 0, pyy = 0, pyz = 0, pzz = 0, vx = 0, vy = 0, vz = 0, cnt = 0;
       auto push = [&](const f3 v) {

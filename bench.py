@@ -115,8 +115,8 @@ def cpu_baseline(sc, ctx, target_seconds=20.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--win", type=int, default=200, help="W poses")
     ap.add_argument("--features", type=int, default=0, help="plane features per GPU (default: configs[2] / configs[3])")
     ap.add_argument("--weak", action="store_true", help="N > 1: 50 000 features per GPU instead of 200 000 in total")
