@@ -181,15 +181,24 @@ def main():
     barrier()
     t_nat = time.perf_counter() - t0
 
-    poses = sc.poses_init
+    def run_steps(k):
+        """exactly k LM iterations, in runs of at most 20 from the noisy start (a run that sat at the optimum for hundreds
+        of iterations would only multiply the damping after rounding-level rejections)"""
+        logs = []
+        while k > 0:
+            m = min(20, k)
+            _, lg_ = ctx.damping_iter(sc.poses_init, form=0, u0=0.1, max_iter=m, force_hess=True, no_stop=True, reanchor=False)
+            assert len(lg_) == m
+            logs.append(lg_)
+            k -= m
+        return np.concatenate(logs)
+
     if args.warmup > 0:
-        poses, _ = ctx.damping_iter(poses, form=0, u0=0.1, max_iter=args.warmup, force_hess=True, no_stop=True,
-                                    reanchor=False)
+        run_steps(args.warmup)
     ctx.reset_timing()
     barrier()
     t0 = time.perf_counter()
-    poses, lg = ctx.damping_iter(poses, form=0, u0=0.1, max_iter=args.steps, force_hess=True, no_stop=True,
-                                 reanchor=False)
+    lg = run_steps(args.steps)
     barrier()
     dt = time.perf_counter() - t0
     assert len(lg) == args.steps
