@@ -63,6 +63,8 @@ int dalloc(balm_ctx *ctx, T **p, size_t count) {
 template <class T>
 int ensure(balm_ctx *ctx, T **p, size_t *cap, size_t count) {
   if (*p && *cap >= count) return BALM_OK;
+  for (int k = 0; k < 4; k++)           // captured LM graphs hold the old pointer
+    if (ctx->lm_graph[k]) { hipGraphExecDestroy(ctx->lm_graph[k]); ctx->lm_graph[k] = nullptr; ctx->lm_graph_form[k] = -1; }
   int rc = dalloc(ctx, p, count);
   if (rc) return rc;
   *cap = count;
@@ -115,6 +117,21 @@ int hook_allreduce(balm_ctx *ctx, double *buf, long n) {
     return BALM_ERR_STATE;
   }
   return BALM_OK;
+}
+
+// the damping u of the next solve: through a pinned ring (the copy is asynchronous; 64 solves can be in flight)
+int set_damping(balm_ctx *ctx, double u) {
+  double *slot = ctx->h_scal + 16 + (ctx->u_ring++ & 63);
+  *slot = u;
+  HIP_TRY(hipMemcpyAsync(ctx->d_scal + SCAL_U, slot, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  return BALM_OK;
+}
+
+void drop_lm_graphs(balm_ctx *ctx) {
+  for (int k = 0; k < 4; k++) {
+    if (ctx->lm_graph[k]) hipGraphExecDestroy(ctx->lm_graph[k]);
+    ctx->lm_graph[k] = nullptr; ctx->lm_graph_form[k] = -1;
+  }
 }
 
 // residual-only evaluation of features [f0,f1) at the TRIAL poses -> d_scal[slot] (summed over
@@ -319,7 +336,7 @@ balm_ctx *balm_create(int win_size, int device, int flags) {
       dalloc(ctx, &ctx->d_perm, (size_t)nA) || dalloc(ctx, &ctx->d_flags, (size_t)2 * (2 * (nA / NB) + 1) * (nA / NB)) || dalloc(ctx, &ctx->d_dx, (size_t)n) ||
       dalloc(ctx, &ctx->d_scal, (size_t)16) || dalloc(ctx, &ctx->d_pre, (size_t)W + 2))
     return fail();
-  if (hipHostMalloc((void **)&ctx->h_scal, 16 * sizeof(double)) != hipSuccess) return fail();
+  if (hipHostMalloc((void **)&ctx->h_scal, (16 + 64) * sizeof(double)) != hipSuccess) return fail();
   if (hipMemcpy(ctx->d_jobs, jobs.data(), jobs.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess ||
       hipMemcpy(ctx->d_sub, sub.data(), sub.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess)
     return fail();
@@ -341,6 +358,7 @@ balm_ctx *balm_create(int win_size, int device, int flags) {
 static void one_destroy(balm_ctx *ctx) {
   if (!ctx) return;
   comm_destroy(ctx);
+  drop_lm_graphs(ctx);
   hipSetDevice(ctx->device);
   if (ctx->stream) hipStreamSynchronize(ctx->stream);
   void *ptrs[] = {ctx->d_cl, ctx->d_fix, ctx->d_coe, ctx->d_poses, ctx->d_poses_tmp, ctx->d_C, ctx->d_feat,
@@ -449,6 +467,7 @@ static int build_sparse_plan(balm_ctx *ctx, int F, const double *clusters) {
 
 static int install_feature_buffers(balm_ctx *ctx, int F, const double *fix, const double *coeffs) {
   int rc;
+  drop_lm_graphs(ctx);
   if (fix) {
     if ((rc = dalloc(ctx, &ctx->d_fix, (size_t)F * 10))) return rc;
     HIP_TRY(hipMemcpyAsync(ctx->d_fix, fix, (size_t)F * 10 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
@@ -708,7 +727,8 @@ static int one_pose_covariance(balm_ctx *ctx, const double *poses, const double 
     Span sp(ctx, BALM_T_COV);
     launch_cov_assemble(s, redx, redy, sdiag, ctx->d_sub, ctx->ntiles, W, Rraw);
     hipMemsetAsync(ctx->d_g, 0, (size_t)n * sizeof(double), s);
-    launch_solve(ctx, 0.0, true);                        // P H P^T = L D L^T stays in d_A / d_dvec / d_perm
+    set_damping(ctx, 0.0);
+    launch_solve(ctx, true);                             // P H P^T = L D L^T stays in d_A / d_dvec / d_perm
     launch_congruence_inverse(ctx, Rraw, T0, T1, Rc);
     if (Rcov) e = hipMemcpyAsync(Rcov, Rc, nn * sizeof(double), hipMemcpyDeviceToHost, s);
     if (e == hipSuccess && Rcov_raw) e = hipMemcpyAsync(Rcov_raw, Rraw, nn * sizeof(double), hipMemcpyDeviceToHost, s);
@@ -776,13 +796,82 @@ int balm_solve_damped(balm_ctx *ctx, const double *Hess, const double *JacT, dou
   HIP_TRY(hipMemcpyAsync(ctx->d_g, JacT, (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
   {
     Span sp(ctx, BALM_T_SOLVE);
-    launch_solve(ctx, u, true);
+    int rcu = set_damping(ctx, u);
+    if (rcu) return rcu;
+    launch_solve(ctx, true);
   }
   HIP_TRY(hipMemcpyAsync(dxi, ctx->d_dx, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   int rc = read_scalars(ctx);
   if (rc) return rc;
   if (q1) *q1 = ctx->h_scal[2];
   return BALM_OK;
+}
+
+// One LM iteration on the stream: [Hessian evaluation] -> damped solve -> trial poses -> residual at the trial poses ->
+// the scalars to the pinned mirror; returns after the stream has drained.  From the second iteration on the launch
+// sequence depends only on (evaluated, which pose buffer is current): it is captured once per combination and replayed
+// as a hipGraph (a window of 20 poses is ~26 launches for ~0.1 ms of device work).  Not with a
+// collective transport (the all-reduce is not ours to capture), not with kernel timing (events), not if a capture ever
+// failed on this context (e.g. a runtime that will not capture the cooperative launch of k_ldl_fused).
+static int lm_enqueue(balm_ctx *ctx, int form, bool evaluated) {
+  int rc;
+  if (evaluated && (rc = evaluate_device(ctx, form, ctx->d_poses, 0, ctx->F, 0))) return rc;
+  {
+    Span sp(ctx, BALM_T_SOLVE);
+    launch_solve(ctx, evaluated);
+  }
+  {
+    Span sp(ctx, BALM_T_UPDATE);
+    launch_update_poses(ctx->stream, form, ctx->W, ctx->d_poses, ctx->d_dx, ctx->d_poses_tmp);
+  }
+  if ((rc = residual_device(ctx, ctx->d_poses_tmp, 0, ctx->F, 1))) return rc;
+  HIP_TRY(hipMemcpyAsync(ctx->h_scal, ctx->d_scal, 16 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  return BALM_OK;
+}
+
+static int lm_iteration(balm_ctx *ctx, int form, bool evaluated, int it) {
+  // Opt-in (BALM_GRAPH=1, or "debug" for a line per capture).  Measured on the box (tools/bench_small.py,
+  // profiles/r02i_small_windows_graph.txt): 0.130 -> 0.125 ms per iteration at W=20/F=20, 0.302 -> 0.301 at W=64/F=5000 --
+  // the iteration is bound by the dependency latency between its ~26 short kernels on the device, not by the host's launch
+  // calls, so a replayed graph buys 0-4 % and is not worth being the default.
+  const char *genv = getenv("BALM_GRAPH");
+  const bool disabled = !(genv && (!strcmp(genv, "1") || !strcmp(genv, "debug")));
+  // windows whose factorisation is the persistent cooperative kernel are left alone: their iterations are not
+  // launch-bound, and a cooperative launch inside a capture is not something every runtime takes
+  const bool graphable = !disabled && ctx->graphs_ok && it >= 1 && !ctx->timer.on && !has_transport(ctx) && !ctx->multi &&
+                         ctx->feat_cur_valid && ctx->F > 0 && !solve_is_persistent(ctx);
+  if (graphable) {
+    const int slot = (evaluated ? 2 : 0) | ctx->parity;
+    if (ctx->lm_graph[slot] && ctx->lm_graph_form[slot] != form) {
+      hipGraphExecDestroy(ctx->lm_graph[slot]); ctx->lm_graph[slot] = nullptr;
+    }
+    if (!ctx->lm_graph[slot]) {
+      hipGraph_t g = nullptr;
+      bool ok = hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
+      if (ok) {
+        const int rc = lm_enqueue(ctx, form, evaluated);
+        const hipError_t e = hipStreamEndCapture(ctx->stream, &g);
+        ok = rc == BALM_OK && e == hipSuccess && g != nullptr;
+      }
+      if (ok) ok = hipGraphInstantiate(&ctx->lm_graph[slot], g, nullptr, nullptr, 0) == hipSuccess;
+      if (g) hipGraphDestroy(g);
+      if (genv && !strcmp(genv, "debug")) fprintf(stderr, "balm_hip: LM graph slot %d capture %s\n", slot, ok ? "ok" : "FAILED");
+      if (!ok) {
+        hipGetLastError();
+        ctx->lm_graph[slot] = nullptr;
+        ctx->graphs_ok = false;
+      } else {
+        ctx->lm_graph_form[slot] = form;
+      }
+    }
+    if (ctx->lm_graph[slot]) {
+      HIP_TRY(hipGraphLaunch(ctx->lm_graph[slot], ctx->stream));
+      return sync_stream(ctx);
+    }
+  }
+  int rc = lm_enqueue(ctx, form, evaluated);
+  if (rc) return rc;
+  return sync_stream(ctx);
 }
 
 static int one_damping_iter(balm_ctx *ctx, const balm_lm_opts *o, double *poses, balm_iter_log *log, int *n_iters) {
@@ -827,17 +916,8 @@ static int one_damping_iter(balm_ctx *ctx, const balm_lm_opts *o, double *poses,
   int it = 0;
   while (it < o->max_iter) {
     const bool evaluated = calc || o->force_hess;
-    if (evaluated && (rc = evaluate_device(ctx, o->form, ctx->d_poses, 0, F, 0))) return rc;
-    {
-      Span sp(ctx, BALM_T_SOLVE);
-      launch_solve(ctx, u, evaluated);
-    }
-    {
-      Span sp(ctx, BALM_T_UPDATE);
-      launch_update_poses(s, o->form, W, ctx->d_poses, ctx->d_dx, ctx->d_poses_tmp);
-    }
-    if ((rc = residual_device(ctx, ctx->d_poses_tmp, 0, F, 1))) return rc;
-    if ((rc = read_scalars(ctx))) return rc;
+    if ((rc = set_damping(ctx, u))) return rc;
+    if ((rc = lm_iteration(ctx, o->form, evaluated, it))) return rc;
     double sc[3] = {ctx->h_scal[0], ctx->h_scal[1], ctx->h_scal[2]};
     multi_share_scalars(ctx, it, sc, 3);         // device 0's scalars decide on every device thread
     r1 = sc[0]; r2 = sc[1];
@@ -861,6 +941,7 @@ static int one_damping_iter(balm_ctx *ctx, const balm_lm_opts *o, double *poses,
       t = ctx->d_rpart; ctx->d_rpart = ctx->d_rpart_tmp; ctx->d_rpart_tmp = t;
       ctx->nr_cur = ctx->nr_tmp;
       ctx->feat_cur_valid = true;
+      ctx->parity ^= 1;
       q = q / q1; v = 2; q = 1 - std::pow(2 * q - 1, 3);
       u *= (q < 1.0 / 3.0 ? 1.0 / 3.0 : q);
       calc = true;

@@ -98,7 +98,13 @@ struct balm_ctx {
   int fused_cap = -1;               // co-resident workgroups of k_ldl_fused on this device (-1 = not asked yet, 0 = unavailable)
   double *d_dx = nullptr;           // [n]
   double *d_scal = nullptr;         // [16] device scalars: 0 r1, 1 r2, 2 q1, 3 flags
-  double *h_scal = nullptr;         // pinned mirror
+  double *h_scal = nullptr;         // pinned mirror (16) + a ring of damping values on their way to d_scal[SCAL_U] (64)
+  int u_ring = 0;
+  // one LM iteration as a replayable hipGraph, per (Hessian evaluated?, which pose buffer is current): [4]
+  hipGraphExec_t lm_graph[4] = {nullptr, nullptr, nullptr, nullptr};
+  int lm_graph_form[4] = {-1, -1, -1, -1};
+  bool graphs_ok = true;            // false after a failed capture: never tried again on this context
+  int parity = 0;                   // toggles with every accepted step (pointer swap of current / trial buffers)
   // host bookkeeping
   std::vector<int> planes_per_pose;
   double work_S = 0, work_B = 0;
@@ -190,7 +196,9 @@ void multi_share_scalars(balm_ctx *ctx, int it, double *vals, int count);   // r
 int multi_host_barrier_rc(balm_ctx *ctx, int rc);             // all device threads meet; returns the first non-zero rc
 
 // launchers (kernels_solve.hip)
-void launch_solve(balm_ctx *c, double u, bool new_hessian);      // (H + u diag H) dx = -g ; q1 -> d_scal[2]
+constexpr int SCAL_U = 5;            // d_scal slot of the damping u
+bool solve_is_persistent(const balm_ctx *c);      // the factorisation of this window runs as k_ldl_fused
+void launch_solve(balm_ctx *c, bool new_hessian);      // (H + u diag H) dx = -g, u = d_scal[SCAL_U]; q1 -> d_scal[2]
 void launch_update_poses(hipStream_t s, int form, int W, const double *poses, const double *dx, double *out);
 void launch_reanchor(hipStream_t s, int W, double *poses);
 

@@ -64,8 +64,10 @@ __global__ __launch_bounds__(256) void k_rank_diag(const double *__restrict__ H,
 }
 
 __global__ __launch_bounds__(256) void k_build_A(const double *__restrict__ H, const double *__restrict__ g, int n,
-                                                 int nA, const int *__restrict__ perm, double u,
+                                                 int nA, const int *__restrict__ perm, const double *__restrict__ pu,
                                                  double *__restrict__ A, int *__restrict__ flags, int nflags) {
+  const double u = *pu;                 // the damping lives in device memory: the launch sequence of an LM iteration
+                                        // is then the same for every iteration and can be replayed as a hipGraph
   const int ldA = 2 * nA + NB;
   const long total = (long)ldA * nA;
   for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < nflags; t += (long)gridDim.x * blockDim.x) flags[t] = 0;
@@ -633,8 +635,9 @@ __global__ __launch_bounds__(256) void k_ldl_apply(const double *__restrict__ A,
 // un-permute, q1 = 0.5 dx.(u D dx - g)    (bavoxel.hpp:1127)
 __global__ __launch_bounds__(1024) void k_ldl_finish(const double *__restrict__ x, int nA, int n,
                                                      const int *__restrict__ perm, const double *__restrict__ H,
-                                                     const double *__restrict__ g, double u,
+                                                     const double *__restrict__ g, const double *__restrict__ pu,
                                                      double *__restrict__ dx, double *__restrict__ scal) {
+  const double u = *pu;
   __shared__ double red[1024];
   const int tid = threadIdx.x;
   double q = 0.0;
@@ -671,12 +674,17 @@ static int fused_capacity(size_t lds_bytes) {
 // The factorisation proper: one persistent cooperative launch (k_ldl_fused) where it is the faster one (18..44 panels,
 // i.e. windows of ~140..350 poses: profiles/r02h_solve_paths_by_window.txt), the launch pair per panel otherwise (and on a device that refuses the cooperative
 // launch).  BALM_SOLVE=launches / fused forces one of them (A/B runs, tests).
+bool solve_is_persistent(const balm_ctx *c) {
+  const int P = c->nA / NB;
+  const char *mode = getenv("BALM_SOLVE");              // A/B: "launches" / "fused" force one path
+  const bool forced = mode && !strcmp(mode, "fused");
+  return !(mode && !strcmp(mode, "launches")) && P >= 2 && (forced || (P >= 18 && P <= 44)) && c->fused_cap != 0;
+}
+
 static void launch_factor(balm_ctx *c) {
   hipStream_t s = c->stream;
   const int nA = c->nA, P = nA / NB;
-  const char *mode = getenv("BALM_SOLVE");              // A/B: "launches" forces the per-panel launch pair
-  const bool forced = mode && !strcmp(mode, "fused");
-  const bool want_fused = !(mode && !strcmp(mode, "launches")) && P >= 2 && (forced || (P >= 18 && P <= 44));
+  const bool want_fused = solve_is_persistent(c);
   if (want_fused) {
     const size_t lds = (size_t)(12 * FLR + 2 * NB * NB + NB) * sizeof(double);
     if (c->fused_cap < 0) c->fused_cap = fused_capacity(lds);
@@ -708,7 +716,7 @@ static void launch_factor(balm_ctx *c) {
   }
 }
 
-void launch_solve(balm_ctx *c, double u, bool new_hessian) {
+void launch_solve(balm_ctx *c, bool new_hessian) {      // damping u = c->d_scal[SCAL_U], set by the caller on the stream
   hipStream_t s = c->stream;
   const int n = c->n, nA = c->nA;
   if (new_hessian)
@@ -719,12 +727,12 @@ void launch_solve(balm_ctx *c, double u, bool new_hessian) {
     int grid = (int)((total + 255) / 256);
     if (grid > 4096) grid = 4096;
     const int P = nA / NB;
-    hipLaunchKernelGGL(k_build_A, dim3(grid), dim3(256), 0, s, c->d_H, c->d_g, n, nA, c->d_perm, u, c->d_A, c->d_flags,
+    hipLaunchKernelGGL(k_build_A, dim3(grid), dim3(256), 0, s, c->d_H, c->d_g, n, nA, c->d_perm, c->d_scal + SCAL_U, c->d_A, c->d_flags,
                        2 * (2 * P + 1) * P);
   }
   launch_factor(c);
   hipLaunchKernelGGL(k_ldl_apply, dim3((nA + 63) / 64, APPLY_CHUNKS), dim3(256), 0, s, c->d_A, nA, c->d_dvec, c->d_z, c->d_x);
-  hipLaunchKernelGGL(k_ldl_finish, dim3(1), dim3(1024), 0, s, c->d_x, nA, n, c->d_perm, c->d_H, c->d_g, u, c->d_dx,
+  hipLaunchKernelGGL(k_ldl_finish, dim3(1), dim3(1024), 0, s, c->d_x, nA, n, c->d_perm, c->d_H, c->d_g, c->d_scal + SCAL_U, c->d_dx,
                      c->d_scal);
 }
 
