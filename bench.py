@@ -122,8 +122,10 @@ def main():
     ap.add_argument("--weak", action="store_true", help="N > 1: 50 000 features per GPU instead of 200 000 in total")
     ap.add_argument("--pts", type=int, default=6, help="points per (feature, pose)")
     ap.add_argument("--seed", type=int, default=2024)
-    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the extra legs (cpu_baseline, strong-scaling reference): profiling runs")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    ap.add_argument("--no-strong-ref", action="store_true",
+                    help="N = 1: skip the extra untimed-contract leg that runs configs[3]'s 200 000 features on the one GPU")
     ap.add_argument("--transport", default="rccl", choices=["rccl", "hook"],
                     help="N > 1: RCCL inside the library (stream-ordered) or the torch.distributed hook")
     args = ap.parse_args()
@@ -283,6 +285,30 @@ def main():
                            "iterations_per_sec": len(lg_nat) / t_nat, "final_residual": float(lg_nat[-1, 1])},
         "final_residual": float(lg[-1, 1]),
     }
+    if world == 1 and not multi and not args.no_strong_ref and not args.no_cpu and args.features == 0 and W == 200:      # (--no-cpu: no extra legs at all)
+        # the problem the N > 1 runs shard (BASELINE configs[3]: 200 000 features in total) on ONE GPU: the N = 1 point of the
+        # strong-scaling curve (`value` above is configs[2], a 4x smaller problem, and not comparable with the N > 1 values)
+        try:
+            ctx.close()
+            sc4 = scene.generate(args.seed, W, F_SHARDED_TOTAL, args.pts, mode=1)
+            ctx4 = capi.Context(W, local_rank)
+            ctx4.set_features(sc4.clusters, None, sc4.coeffs)
+            ctx4.damping_iter(sc4.poses_init, form=0, u0=0.1, max_iter=3, force_hess=True, no_stop=True, reanchor=False)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            k4 = 0
+            for _ in range(2):
+                ctx4.damping_iter(sc4.poses_init, form=0, u0=0.1, max_iter=20, force_hess=True, no_stop=True, reanchor=False)
+                k4 += 20
+            d4 = time.perf_counter() - t0
+            out["strong_scaling_reference"] = {"what": "BASELINE configs[3] (W=200, 200 000 features) on one GPU: the N=1 point for the N>1 values",
+                                               "features_total": F_SHARDED_TOTAL, "iterations_per_sec": k4 / d4, "ms_per_step": d4 / k4 * 1e3}
+            ctx4.close()
+            del sc4
+            ctx = capi.Context(W, local_rank, capi.FLAG_TIMING)          # the CPU leg evaluates once on the device
+            ctx.set_features(sc.clusters, None, sc.coeffs)
+        except Exception as e:
+            out["strong_scaling_reference"] = {"error": repr(e)}
     if world == 1 and not args.no_cpu:
         try:
             out["cpu_baseline"] = cpu_baseline(sc, ctx, args.cpu_seconds)
