@@ -21,6 +21,7 @@ TIMING_NAMES = ["moments", "factors", "syrk", "assemble", "solve", "update", "bu
 # every symbol include/balm_hip.h declares
 EXPORTS = ["balm_create", "balm_create_multi", "balm_destroy", "balm_set_features", "balm_evaluate", "balm_only_residual",
            "balm_solve_damped", "balm_damping_iter", "balm_build_clusters", "balm_voxel_defaults", "balm_associate", "balm_get_features", "balm_get_association", "balm_pose_covariance",
+           "balm_window_open", "balm_window_add_scan", "balm_window_features", "balm_window_marginalize", "balm_window_info", "balm_window_close",
            "balm_set_allreduce", "balm_comm_unique_id", "balm_comm_init_rank",
            "balm_get_timing", "balm_get_solve_trace", "balm_reset_timing", "balm_work_model", "balm_last_error", "balm_version"]
 
@@ -76,6 +77,12 @@ def lib():
                                         C.POINTER(C.c_int)]
         L.balm_build_clusters.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long,
                                           C.c_void_p, C.c_void_p, C.c_void_p]
+        L.balm_window_open.argtypes = [C.c_void_p, C.POINTER(VoxelOpts)]
+        L.balm_window_add_scan.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_void_p]
+        L.balm_window_features.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+        L.balm_window_marginalize.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.balm_window_info.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_long), C.POINTER(C.c_long)]
+        L.balm_window_close.argtypes = [C.c_void_p]
         L.balm_associate.argtypes = [C.c_void_p, C.POINTER(VoxelOpts), C.c_void_p, C.c_void_p, C.c_long, C.c_void_p,
                                      C.POINTER(C.c_int), C.POINTER(C.c_long)]
         L.balm_get_features.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -191,6 +198,49 @@ class Context:
                 self._check(self.L.balm_get_association(self.h, _p(fix), _p(pf)))
                 feats = (cl, co, layer, fix, pf)
         return self.F, nr.value, feats
+
+    # ---- sliding-window map (the incremental use of the reference's octree) ----
+    def window_open(self, voxel_size=2.0, eigen_thresholds=(1.0 / 16, 1.0 / 16, 1.0 / 9), min_ps=15, layer_limit=2,
+                    min_observers=2):
+        o = VoxelOpts()
+        self.L.balm_voxel_defaults(C.byref(o))
+        o.voxel_size = voxel_size
+        o.eigen_thr = (C.c_float * 3)(*[float(t) for t in eigen_thresholds])
+        o.min_ps, o.layer_limit, o.min_observers = min_ps, layer_limit, min_observers
+        self._check(self.L.balm_window_open(self.h, C.byref(o)))
+
+    def window_add_scan(self, xyz, pose12):
+        """cut_voxel + recut: body-frame points of one scan, its pose [12]"""
+        xyz, pose12 = _c(xyz, np.float32).reshape(-1, 3), _c(pose12).reshape(12)
+        self._check(self.L.balm_window_add_scan(self.h, _p(xyz), xyz.shape[0], _p(pose12)))
+
+    def window_marginalize(self, mg_size, poses=None):
+        """OCTO_TREE_ROOT::marginalize of every root; poses [scans_in_window, 12] (re-transform) or None"""
+        if poses is not None:
+            poses = _c(poses)
+            assert poses.shape[0] == self.window_info()[0]
+        self._check(self.L.balm_window_marginalize(self.h, int(mg_size), _p(poses)))
+
+    def window_features(self, want_features=True):
+        """tras_opt: installs the window's feature table -> (F, (clusters [F,W,10], coeffs [F], layer [F], fix [F,10]))"""
+        F = C.c_int(0)
+        self._check(self.L.balm_window_features(self.h, C.byref(F)))
+        self.F = F.value
+        if not (want_features and self.F > 0):
+            return self.F, None
+        cl, co = np.zeros((self.F, self.W, 10)), np.zeros(self.F)
+        layer, fix = np.zeros(self.F, dtype=np.int32), np.zeros((self.F, 10))
+        self._check(self.L.balm_get_features(self.h, _p(cl), _p(co), _p(layer)))
+        self._check(self.L.balm_get_association(self.h, _p(fix), None))
+        return self.F, (cl, co, layer, fix)
+
+    def window_info(self):
+        a, b, c = C.c_int(0), C.c_long(0), C.c_long(0)
+        self._check(self.L.balm_window_info(self.h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
+    def window_close(self):
+        self._check(self.L.balm_window_close(self.h))
 
     def pose_covariance(self, poses, cluster_cov=None, point_sigma=0.0, want_raw=True):
         """-> (Rcov [n,n], Rcov_raw [n,n] or None): H^-1 Rcov_raw H^-T and the point-noise image sum Ls c_cov Ls^T"""

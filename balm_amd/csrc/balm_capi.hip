@@ -361,6 +361,7 @@ static void one_destroy(balm_ctx *ctx) {
   drop_lm_graphs(ctx);
   hipSetDevice(ctx->device);
   if (ctx->stream) hipStreamSynchronize(ctx->stream);
+  if (ctx->window) { window_close(ctx->window); ctx->window = nullptr; }
   void *ptrs[] = {ctx->d_cl, ctx->d_fix, ctx->d_coe, ctx->d_poses, ctx->d_poses_tmp, ctx->d_C, ctx->d_feat,
                   ctx->d_Gt, ctx->d_part, ctx->d_dpart, ctx->d_rpart, ctx->d_feat_tmp, ctx->d_rpart_tmp, ctx->d_red, ctx->d_jobs, ctx->d_sub, ctx->d_H,
                   ctx->d_g, ctx->d_A, ctx->d_Wp, ctx->d_dvec, ctx->d_z, ctx->d_x, ctx->d_perm, ctx->d_dx, ctx->d_scal, ctx->d_arena, ctx->d_pre, ctx->d_flags, ctx->d_trace, ctx->d_slot, ctx->d_items, ctx->d_csr, ctx->d_chunk_ids, ctx->d_stage};
@@ -574,6 +575,37 @@ void balm_voxel_defaults(balm_voxel_opts *o) {
   o->want_point_features = 0;
 }
 
+// the feature table an association left on the device (hipMalloc'ed [F][W][10] clusters, weights, fix clusters, layers,
+// optionally the feature of every point) becomes the context's feature table; the device arrays are freed
+static int install_associated(balm_ctx *ctx, int F, double *d_out, double *d_coe, double *d_fix, int *d_lay, int *d_pf, long n_pts,
+                              bool has_fix) {
+  const int W = ctx->W;
+  const size_t count = (size_t)F * W * 10;
+  ctx->assoc_clusters.resize(count); ctx->assoc_coeffs.resize(F); ctx->assoc_layer.resize(F); ctx->assoc_fix.resize((size_t)F * 10);
+  if (d_pf) ctx->assoc_point_feat.resize((size_t)n_pts);
+  hipError_t e = hipSuccess;
+  int rc = dalloc(ctx, &ctx->d_cl, count);
+  if (!rc) {
+    launch_transpose_clusters(ctx->stream, d_out, ctx->d_cl, F, W);
+    e = hipMemcpyAsync(ctx->assoc_clusters.data(), d_out, count * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(ctx->assoc_coeffs.data(), d_coe, (size_t)F * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(ctx->assoc_fix.data(), d_fix, (size_t)F * 10 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(ctx->assoc_layer.data(), d_lay, (size_t)F * sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess && d_pf)
+      e = hipMemcpyAsync(ctx->assoc_point_feat.data(), d_pf, (size_t)n_pts * sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  }
+  hipFree(d_out); hipFree(d_coe); hipFree(d_fix); hipFree(d_lay);
+  if (d_pf) hipFree(d_pf);
+  if (rc) return rc;
+  HIP_TRY(e);
+  const double *fix = has_fix ? ctx->assoc_fix.data() : nullptr;
+  if ((rc = feature_bookkeeping(ctx, F, ctx->assoc_clusters.data(), fix, ctx->assoc_coeffs.data()))) return rc;
+  if ((rc = build_sparse_plan(ctx, F, ctx->assoc_clusters.data()))) return rc;
+  if ((rc = install_feature_buffers(ctx, F, fix, ctx->assoc_coeffs.data()))) return rc;
+  return sync_stream(ctx);
+}
+
 static int one_associate(balm_ctx *ctx, const balm_voxel_opts *opts, const float *xyz, const int *frame_id, long n_pts,
                    const double *poses, int *F_out, long *n_root_voxels) {
   if (!ctx) return BALM_ERR_ARG;
@@ -626,31 +658,75 @@ static int one_associate(balm_ctx *ctx, const balm_voxel_opts *opts, const float
   if (arc) { ctx->err = arc == -2 ? "balm_associate: unsupported size" : "balm_associate: device failure"; return BALM_ERR_HIP; }
   if (n_root_voxels) *n_root_voxels = nroots;
   if (F == 0) return BALM_OK;
-  const size_t count = (size_t)F * W * 10;
-  ctx->assoc_clusters.resize(count); ctx->assoc_coeffs.resize(F); ctx->assoc_layer.resize(F); ctx->assoc_fix.resize((size_t)F * 10);
-  if (d_pf) ctx->assoc_point_feat.resize((size_t)n_pts);
-  int rc = dalloc(ctx, &ctx->d_cl, count);
-  if (!rc) {
-    launch_transpose_clusters(ctx->stream, d_out, ctx->d_cl, F, W);
-    e = hipMemcpyAsync(ctx->assoc_clusters.data(), d_out, count * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(ctx->assoc_coeffs.data(), d_coe, (size_t)F * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(ctx->assoc_fix.data(), d_fix, (size_t)F * 10 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(ctx->assoc_layer.data(), d_lay, (size_t)F * sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess && d_pf)
-      e = hipMemcpyAsync(ctx->assoc_point_feat.data(), d_pf, (size_t)n_pts * sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-  }
-  hipFree(d_out); hipFree(d_coe); hipFree(d_fix); hipFree(d_lay);
-  if (d_pf) hipFree(d_pf);
+  int rc = install_associated(ctx, F, d_out, d_coe, d_fix, d_lay, d_pf, n_pts, opts->fix_frames > 0);
   if (rc) return rc;
-  HIP_TRY(e);
-  if ((rc = feature_bookkeeping(ctx, F, ctx->assoc_clusters.data(), opts->fix_frames > 0 ? ctx->assoc_fix.data() : nullptr,
-                                ctx->assoc_coeffs.data())))
-    return rc;
-  if ((rc = build_sparse_plan(ctx, F, ctx->assoc_clusters.data()))) return rc;
-  if ((rc = install_feature_buffers(ctx, F, opts->fix_frames > 0 ? ctx->assoc_fix.data() : nullptr, ctx->assoc_coeffs.data())))
-    return rc;
-  if ((rc = sync_stream(ctx))) return rc;
+  *F_out = F;
+  return BALM_OK;
+}
+
+// ---- sliding-window map (kernels_window.inc) ------------------------------------------------------------------------
+static int window_rc(balm_ctx *ctx, const char *who, int rc) {
+  if (rc == 0) return BALM_OK;
+  ctx->err = std::string(who) + (rc == -2 ? ": window full / bad size" : rc == -3 ? ": non-finite point or beyond 2^20 voxels" : ": device failure");
+  return rc == -1 ? BALM_ERR_HIP : BALM_ERR_ARG;
+}
+
+static int one_window_open(balm_ctx *ctx, const balm_voxel_opts *opts) {
+  if (!ctx) return BALM_ERR_ARG;
+  if (!opts || !(opts->voxel_size > 0) || opts->layer_limit < 0 || opts->layer_limit > 2 || opts->min_observers < 0 || ctx->W > 512 ||
+      opts->max_plane_dist > 0 || opts->max_lambda21 > 0 || opts->max_lambda0 > 0 || opts->fix_frames != 0) {
+    ctx->err = "balm_window_open: bad argument (the strict plane test and fix_frames belong to balm_associate; marginalise with "
+               "balm_window_marginalize)";
+    return BALM_ERR_ARG;
+  }
+  HIP_TRY(hipSetDevice(ctx->device));
+  if (ctx->window) { window_close(ctx->window); ctx->window = nullptr; }
+  AssocOpts ao{ctx->W, opts->voxel_size, {opts->eigen_thr[0], opts->eigen_thr[1], opts->eigen_thr[2]}, opts->min_ps, opts->layer_limit,
+               opts->min_observers, 0, 0, 0, 0};
+  ctx->window = window_open(ctx->stream, ao);
+  if (!ctx->window) { ctx->err = "balm_window_open: allocation failed"; return BALM_ERR_HIP; }
+  return BALM_OK;
+}
+
+static int one_window_add_scan(balm_ctx *ctx, const float *xyz, long n_pts, const double *pose12) {
+  if (!ctx) return BALM_ERR_ARG;
+  if (!ctx->window) { ctx->err = "balm_window_add_scan: no open window"; return BALM_ERR_STATE; }
+  if (!xyz || !pose12 || n_pts < 1) { ctx->err = "balm_window_add_scan: bad argument"; return BALM_ERR_ARG; }
+  HIP_TRY(hipSetDevice(ctx->device));
+  int rc = stage_begin(ctx, (size_t)n_pts * 12);
+  if (rc) return rc;
+  float *d_xyz = stage_take<float>(ctx, (size_t)n_pts * 3);
+  HIP_TRY(hipMemcpyAsync(d_xyz, xyz, (size_t)n_pts * 3 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+  Span sp(ctx, BALM_T_VOXEL);
+  return window_rc(ctx, "balm_window_add_scan", window_add_scan(ctx->window, d_xyz, n_pts, pose12));
+}
+
+static int one_window_marginalize(balm_ctx *ctx, int mg, const double *poses) {
+  if (!ctx) return BALM_ERR_ARG;
+  if (!ctx->window) { ctx->err = "balm_window_marginalize: no open window"; return BALM_ERR_STATE; }
+  HIP_TRY(hipSetDevice(ctx->device));
+  Span sp(ctx, BALM_T_VOXEL);
+  return window_rc(ctx, "balm_window_marginalize", window_marginalize(ctx->window, mg, poses));
+}
+
+static int one_window_features(balm_ctx *ctx, int *F_out) {
+  if (!ctx) return BALM_ERR_ARG;
+  if (!ctx->window) { ctx->err = "balm_window_features: no open window"; return BALM_ERR_STATE; }
+  if (!F_out) { ctx->err = "balm_window_features: bad argument"; return BALM_ERR_ARG; }
+  HIP_TRY(hipSetDevice(ctx->device));
+  *F_out = 0;
+  ctx->F = 0;
+  ctx->assoc_clusters.clear(); ctx->assoc_coeffs.clear(); ctx->assoc_layer.clear(); ctx->assoc_fix.clear(); ctx->assoc_point_feat.clear();
+  int F = 0, *d_lay = nullptr;
+  double *d_out = nullptr, *d_coe = nullptr, *d_fix = nullptr;
+  int rc;
+  {
+    Span sp(ctx, BALM_T_VOXEL);
+    rc = window_features(ctx->window, window_min_observers(ctx->window), &F, &d_out, &d_coe, &d_fix, &d_lay);
+  }
+  if (rc) return window_rc(ctx, "balm_window_features", rc);
+  if (F == 0) return BALM_OK;
+  if ((rc = install_associated(ctx, F, d_out, d_coe, d_fix, d_lay, nullptr, 0, true))) return rc;
   *F_out = F;
   return BALM_OK;
 }
@@ -1076,6 +1152,35 @@ int balm_associate(balm_ctx *ctx, const balm_voxel_opts *opts, const float *xyz,
   if (rc || *F_out == 0) return rc;
   return multi_set_features(ctx, m, *F_out, ctx->assoc_clusters.data(), opts->fix_frames > 0 ? ctx->assoc_fix.data() : nullptr,
                             ctx->assoc_coeffs.data());
+}
+
+int balm_window_open(balm_ctx *ctx, const balm_voxel_opts *opts) { return one_window_open(ctx, opts); }
+int balm_window_add_scan(balm_ctx *ctx, const float *xyz, long n_pts, const double *pose12) {
+  return one_window_add_scan(ctx, xyz, n_pts, pose12);
+}
+int balm_window_marginalize(balm_ctx *ctx, int mg_size, const double *poses) { return one_window_marginalize(ctx, mg_size, poses); }
+int balm_window_features(balm_ctx *ctx, int *F_out) {
+  balm_multi *m = leader_of(ctx);
+  if (!m) return one_window_features(ctx, F_out);
+  ctx->multi = nullptr;
+  int rc = one_window_features(ctx, F_out);
+  ctx->multi = m;
+  m->F = 0;
+  if (rc || *F_out == 0) return rc;
+  return multi_set_features(ctx, m, *F_out, ctx->assoc_clusters.data(), ctx->assoc_fix.data(), ctx->assoc_coeffs.data());
+}
+int balm_window_info(balm_ctx *ctx, int *scans, long *points, long *nodes) {
+  if (!ctx) return BALM_ERR_ARG;
+  if (!ctx->window) { ctx->err = "balm_window_info: no open window"; return BALM_ERR_STATE; }
+  if (scans) *scans = window_count(ctx->window);
+  if (points) *points = window_points(ctx->window);
+  if (nodes) *nodes = window_nodes(ctx->window);
+  return BALM_OK;
+}
+int balm_window_close(balm_ctx *ctx) {
+  if (!ctx) return BALM_ERR_ARG;
+  if (ctx->window) { hipSetDevice(ctx->device); window_close(ctx->window); ctx->window = nullptr; }
+  return BALM_OK;
 }
 
 int balm_evaluate(balm_ctx *ctx, int form, const double *poses, int head, int end, double *Hess, double *JacT, double *residual) {

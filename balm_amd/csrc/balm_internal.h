@@ -43,6 +43,8 @@ struct Timer {
 
 }  // namespace balm
 
+namespace balm { struct WindowSession; }
+
 struct balm_ctx {
   int W = 0, n = 0, npad = 0, T = 0, ntiles = 0, device = 0, flags = 0;
   int nA = 0;                       // solver dimension (n rounded up to NB)
@@ -111,6 +113,7 @@ struct balm_ctx {
   std::vector<double> assoc_clusters, assoc_coeffs;   // host copies of the last balm_associate
   std::vector<int> assoc_layer, assoc_point_feat;
   std::vector<double> assoc_fix;
+  balm::WindowSession *window = nullptr;   // balm_window_*: the sliding-window map (kernels_window.inc)
   void *d_arena = nullptr;          // balm_associate scratch, grown to what the last call needed
   size_t arena_cap = 0;
   char *d_stage = nullptr;          // per-call staging (uploads, layout changes, covariance work matrices): grown, never
@@ -213,6 +216,18 @@ struct AssocOpts {
 int associate_device(hipStream_t s, const float *d_xyz, const int *d_frame, const double *d_poses, long n, const AssocOpts &o,
                      void *arena, size_t arena_cap, size_t *arena_need, int *F_out, double **d_out, double **d_coe,
                      double **d_fix, int **d_layer, int **d_point_feat, long *n_roots);
+
+// sliding-window map: the incremental use of the reference's octree (kernels_window.inc, part of kernels_voxel.hip).
+// Return codes as associate_device.
+WindowSession *window_open(hipStream_t s, const AssocOpts &o);          // o.W = window size
+void window_close(WindowSession *w);
+int window_add_scan(WindowSession *w, const float *d_xyz_new, long n_new, const double *pose12);
+int window_marginalize(WindowSession *w, int mg, const double *poses);
+int window_features(WindowSession *w, int min_observers, int *F_out, double **d_out, double **d_coe, double **d_fix, int **d_layer);
+int window_count(const WindowSession *w);
+int window_min_observers(const WindowSession *w);
+long window_points(const WindowSession *w);
+long window_nodes(const WindowSession *w);
 
 // launchers (kernels_cov.hip)
 int cov_factors_grid(int W, int F);

@@ -782,4 +782,6 @@ int associate_device(hipStream_t s, const float *d_xyz, const int *d_frame, cons
   return 0;
 }
 
+#include "kernels_window.inc"
+
 }  // namespace balm

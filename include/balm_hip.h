@@ -167,6 +167,28 @@ void balm_voxel_defaults(balm_voxel_opts *opts);
 int balm_associate(balm_ctx *ctx, const balm_voxel_opts *opts, const float *xyz, const int *frame_id,
                    long n_pts, const double *poses, int *F_out, long *n_root_voxels);
 
+/* Sliding-window map: the INCREMENTAL use of the reference's adaptive voxel map, kept on the device between calls
+ * (OCTO_TREE_ROOT / OCTO_TREE_NODE, src/benchmark/bavoxel.hpp:625-963; balm_associate above is the batch form).
+ *   balm_window_open         an empty unordered_map<VOXEL_LOC, OCTO_TREE_ROOT*>; window size = the context's `win`;
+ *                            opts as for balm_associate (fix_frames and the strict plane test must be 0)
+ *   balm_window_add_scan     cut_voxel(map, scan, pose, fnum = scans in the window)  (:1170-1223)  followed by
+ *                            recut(win_count) of every root (:737-776): nodes that were cut stay cut and forward the
+ *                            new scan, the others are judged again over fix cluster + all scans.  xyz: n_pts*3 body-frame
+ *                            floats in scan order, pose12: column-major R then p.
+ *   balm_window_features     tras_opt of every root (:908-929) + VOX_HESS::push_voxel (:30-51): installs the feature table
+ *                            (with fix clusters) like balm_associate; read it with balm_get_features / balm_get_association
+ *   balm_window_marginalize  OCTO_TREE_ROOT::marginalize(mg_size, x_poses, win_count) of every root (:948-963, to_margi
+ *                            :778-816): with poses (scans_in_window*12) every cluster and point is re-transformed first;
+ *                            the first mg_size scans of plane voxels join the fix clusters (fix_point.N < 50), the window
+ *                            moves down by mg_size.  poses == NULL is the reference's empty x_poses (no re-transform).
+ * One recut per scan is the reference's own calling convention (a cut node only forwards the newest scan).  */
+int balm_window_open(balm_ctx *ctx, const balm_voxel_opts *opts);
+int balm_window_add_scan(balm_ctx *ctx, const float *xyz, long n_pts, const double *pose12);
+int balm_window_features(balm_ctx *ctx, int *F_out);
+int balm_window_marginalize(balm_ctx *ctx, int mg_size, const double *poses);
+int balm_window_info(balm_ctx *ctx, int *scans_in_window, long *points, long *nodes);
+int balm_window_close(balm_ctx *ctx);
+
 /* Host copies of the feature table installed by the last balm_associate: clusters F*W*10, coeffs F,
  * layer F (octree depth of the feature's voxel).  Any pointer may be NULL. */
 int balm_get_features(balm_ctx *ctx, double *clusters, double *coeffs, int *layer);

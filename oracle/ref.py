@@ -139,3 +139,34 @@ def realworld_features(data_dir, voxel_size=2.0, max_poses=0):
     L.ref_rw_export(h, _p(cl), _p(fx), _p(co), _p(poses))
     L.ref_rw_close(h)
     return cl, fx, co, poses, npts.value
+
+
+class Window:
+    """the reference's octree used incrementally (ref_driver.cpp: cut_voxel + recut per scan, marginalize, tras_opt)"""
+
+    def __init__(self, W, voxel_size=2.0, eigen_thresholds=(1.0 / 16, 1.0 / 16, 1.0 / 9), min_ps=15, layer_limit=2):
+        L = lib()
+        L.ref_win_open.restype = C.c_void_p
+        thr = (C.c_float * 3)(*[float(t) for t in eigen_thresholds])
+        self.W = W
+        self.h = C.c_void_p(L.ref_win_open(int(W), C.c_double(voxel_size), thr, int(min_ps), int(layer_limit)))
+
+    def add_scan(self, xyz, pose12):
+        xyz = np.ascontiguousarray(xyz, dtype=np.float32).reshape(-1, 3)
+        lib().ref_win_add_scan(self.h, _p(xyz), C.c_long(xyz.shape[0]), _p(_c(pose12)))
+
+    def marginalize(self, mg, poses=None):
+        lib().ref_win_marginalize(self.h, int(mg), _p(_c(poses)))
+
+    def features(self):
+        """-> clusters [F,W,10], fix [F,10], coeffs [F]"""
+        F = lib().ref_win_features(self.h)
+        cl, fix, co = np.zeros((F, self.W, 10)), np.zeros((F, 10)), np.zeros(F)
+        if F:
+            lib().ref_win_export(self.h, _p(cl), _p(fix), _p(co))
+        return cl, fix, co
+
+    def close(self):
+        if self.h:
+            lib().ref_win_close(self.h)
+            self.h = None

@@ -300,6 +300,71 @@ void ref_rw_export(void *hh, double *clusters, double *fix, double *coeffs, doub
 
 void ref_rw_close(void *hh) { delete (RwHandle *)hh; }
 
+// ---- the octree used INCREMENTALLY: cut_voxel into a live map, one recut per scan, repeated marginalize ------------
+// (the calling sequence of consistency.cpp:127-136, repeated; every function called is the reference's)
+struct WinHandle {
+  std::unordered_map<VOXEL_LOC, OCTO_TREE_ROOT *> map;
+  int win_count = 0;
+  VOX_HESS *vh = nullptr;
+  ~WinHandle() { delete vh; for (auto &kv : map) delete kv.second; }
+};
+
+void *ref_win_open(int W, double vsize, const float *thr3, int minps, int limit) {
+  win_size = W; voxel_size = vsize; min_ps = minps; layer_limit = limit;
+  for (int k = 0; k < 3; k++) eigen_value_array[k] = thr3[k];
+  return new WinHandle();
+}
+
+void ref_win_add_scan(void *hh, const float *xyz, long n, const double *pose12) {
+  WinHandle *h = (WinHandle *)hh;
+  pcl::PointCloud<PointType> pl;
+  pl.reserve((size_t)n);
+  for (long k = 0; k < n; k++) { PointType ap; ap.x = xyz[3 * k]; ap.y = xyz[3 * k + 1]; ap.z = xyz[3 * k + 2]; pl.push_back(ap); }
+  IMUST x = load_poses(1, pose12)[0];
+  cut_voxel(h->map, pl, x, h->win_count);
+  h->win_count++;
+  for (auto &kv : h->map) kv.second->recut(h->win_count);
+}
+
+void ref_win_marginalize(void *hh, int mg, const double *poses) {
+  WinHandle *h = (WinHandle *)hh;
+  std::vector<IMUST> xs;
+  if (poses) xs = load_poses(h->win_count, poses);
+  for (auto &kv : h->map) kv.second->marginalize(mg, xs, h->win_count);
+  h->win_count -= mg;
+}
+
+int ref_win_features(void *hh) {
+  WinHandle *h = (WinHandle *)hh;
+  delete h->vh;
+  h->vh = new VOX_HESS();
+  for (auto &kv : h->map) kv.second->tras_opt(*h->vh, h->win_count);
+  return (int)h->vh->plvec_voxels.size();
+}
+
+// fix clusters: the lower triangle of P (what SelfAdjointEigenSolver reads; P stops being exactly symmetric once
+// PointCluster::transform has produced it)
+void ref_win_export(void *hh, double *clusters, double *fix, double *coeffs) {
+  WinHandle *h = (WinHandle *)hh;
+  const int W = win_size;
+  const size_t F = h->vh->plvec_voxels.size();
+  auto put = [](const PointCluster &c, double *q) {
+    q[0] = c.P(0, 0); q[1] = c.P(1, 0); q[2] = c.P(2, 0); q[3] = c.P(1, 1); q[4] = c.P(2, 1); q[5] = c.P(2, 2);
+    q[6] = c.v[0]; q[7] = c.v[1]; q[8] = c.v[2]; q[9] = c.N;
+  };
+  for (size_t a = 0; a < F; a++) {
+    for (int i = 0; i < W; i++) put((*h->vh->plvec_voxels[a])[i], clusters + (a * W + i) * 10);
+    put(*h->vh->sig_vecs[a], fix + a * 10);
+    coeffs[a] = h->vh->coeffs[a];
+  }
+}
+
+void ref_win_close(void *hh) {
+  delete (WinHandle *)hh;
+  min_ps = 15; layer_limit = 2;                      // the globals' defaults (bavoxel.hpp:8-12) for whoever runs next
+  for (int k = 0; k < 4; k++) eigen_value_array[k] = 1.0 / 16;
+}
+
 void ref_exp(const double *w, double *R9) {
   Eigen::Matrix3d R = Exp(Eigen::Vector3d(w[0], w[1], w[2]));
   for (int c = 0; c < 3; c++) for (int r = 0; r < 3; r++) R9[3 * c + r] = R(r, c);

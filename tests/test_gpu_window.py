@@ -1,0 +1,172 @@
+"""Sliding-window map (balm_window_*, csrc/kernels_window.inc): the reference's octree used INCREMENTALLY -- cut_voxel into
+a live map, one recut per scan, tras_opt, marginalize with re-transformed poses, repeat -- against the reference's own
+OCTO_TREE_ROOT compiled from bavoxel.hpp (oracle/_ref, ref_driver.cpp ref_win_*), call for call.  The per-scan clusters of
+the features are sums of points in scan order: compared bit for bit as a set.  Fix clusters go through
+PointCluster::transform (a different rounding path than sums of points, and not exactly symmetric): 1e-12 relative."""
+import numpy as np
+import pytest
+
+from balm_amd import capi
+from oracle import ref
+from oracle import numpy_oracle as npo
+from test_gpu_voxel import cluttered_window
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not ref.available(), reason="oracle/_ref not built")]
+
+
+def canon_order(cl):
+    flat = cl.reshape(cl.shape[0], -1)
+    return np.lexsort(flat[:, ::-1].T)
+
+
+def compare(ctx, win, tag):
+    F, feats = ctx.window_features()
+    cl_r, fix_r, co_r = win.features()
+    assert F == cl_r.shape[0], "%s: %d features, reference %d" % (tag, F, cl_r.shape[0])
+    if F == 0:
+        return 0, 0
+    cl, co, layer, fix = feats
+    og, orf = canon_order(cl), canon_order(cl_r)
+    assert np.array_equal(cl[og], cl_r[orf]), tag                       # bit-exact per-scan clusters, same feature set
+    assert np.array_equal(co[og], co_r[orf]), tag
+    scale = np.abs(fix_r[orf]).max(axis=1, keepdims=True) + 1e-300
+    assert np.all(np.abs(fix[og] - fix_r[orf]) <= 1e-12 * scale), tag
+    assert np.array_equal(fix[og][:, 9], fix_r[orf][:, 9]), tag
+    return F, int((fix[:, 9] > 0).sum())
+
+
+def noisy(poses, rng, s_rot, s_tr):
+    """poses [k,12] (column-major R | p) with a small left perturbation: stands in for what an optimiser hands back"""
+    out = poses.copy()
+    for i in range(poses.shape[0]):
+        R = poses[i, :9].reshape(3, 3).T
+        Rn = npo.exp_so3(s_rot * rng.standard_normal(3)) @ R
+        out[i, :9] = Rn.T.reshape(9)
+        out[i, 9:] = poses[i, 9:] + s_tr * rng.standard_normal(3)
+    return out
+
+
+@pytest.mark.parametrize("seed,W,mg,retransform", [(3, 8, 2, True), (5, 6, 1, True), (7, 8, 3, False)])
+def test_sliding_window_matches_reference_octree(seed, W, mg, retransform):
+    slides = 4
+    total = W + slides * mg
+    poses, frames = cluttered_window(seed, total, 40, 120, 1500)
+    rng = np.random.default_rng(seed)
+    start = noisy(poses, rng, 2e-3, 2e-2)                 # odometry-grade initial poses: the map is cut with these
+    ctx = capi.Context(W)
+    ctx.window_open(voxel_size=1.0)
+    win = ref.Window(W, voxel_size=1.0)
+    cur = []                                               # poses of the scans in the window, as the map knows them
+    for i in range(W):
+        ctx.window_add_scan(frames[i], start[i]); win.add_scan(frames[i], start[i]); cur.append(start[i])
+    F0, _ = compare(ctx, win, "full window")
+    assert F0 > 10
+    nxt = W
+    saw_fix = 0
+    for sl in range(slides):
+        # "optimised" poses: closer to the truth than the odometry ones
+        xs = None
+        if retransform:
+            xs = noisy(poses[nxt - W:nxt], rng, 2e-4, 2e-3)
+            cur = list(xs)
+        ctx.window_marginalize(mg, xs); win.marginalize(mg, xs)
+        cur = cur[mg:]
+        assert ctx.window_info()[0] == W - mg
+        for k in range(mg):
+            ctx.window_add_scan(frames[nxt], start[nxt]); win.add_scan(frames[nxt], start[nxt]); cur.append(start[nxt])
+            nxt += 1
+        F, nfix = compare(ctx, win, "slide %d" % sl)
+        assert F > 10
+        saw_fix = max(saw_fix, nfix)
+    assert saw_fix > 0                                     # marginalised scans live on as fix clusters
+    # the installed table (fix clusters included) feeds the optimiser
+    out, lg = ctx.damping_iter(np.stack(cur), form=0, u0=0.01, max_iter=3)
+    assert np.isfinite(out).all()
+    win.close(); ctx.window_close(); ctx.close()
+
+
+def test_window_first_fill_equals_batch_when_nothing_is_cut_early():
+    """adding the scans one by one with a recut each is NOT the batch association in general (a voxel cut on the evidence of
+    three scans stays cut) -- but on exact, well separated planes no voxel changes its mind, and both must agree"""
+    from test_association import exact_plane_scans
+    from balm_amd import realworld as rw
+    poses, frames = exact_plane_scans(4, 8, 40, 60)
+    W = len(frames)
+    ctx = capi.Context(W)
+    ctx.window_open(voxel_size=1.0, layer_limit=0, min_observers=2)
+    for i in range(W):
+        ctx.window_add_scan(frames[i], poses[i])
+    F, (cl, co, layer, fix) = ctx.window_features()
+    Fb, _, (clb, cob, layb) = rw.associate_gpu(ctx, frames, poses, voxel_size=1.0, layer_limit=0)
+    assert F == Fb and F > 5
+    assert np.array_equal(cl[canon_order(cl)], clb[canon_order(clb)])
+    assert not fix.any()
+    ctx.close()
+
+
+def test_window_argument_errors():
+    ctx = capi.Context(4)
+    with pytest.raises(capi.BalmError):
+        ctx.window_add_scan(np.zeros((10, 3), np.float32), np.zeros(12))        # no open window
+    ctx.window_open(voxel_size=1.0)
+    pose = np.array([1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0], dtype=float)
+    pts = np.random.default_rng(0).uniform(-3, 3, (200, 3)).astype(np.float32)
+    for _ in range(4):
+        ctx.window_add_scan(pts, pose)
+    with pytest.raises(capi.BalmError):
+        ctx.window_add_scan(pts, pose)                                         # window full
+    with pytest.raises(capi.BalmError):
+        ctx.window_marginalize(5)
+    bad = pts.copy(); bad[3, 1] = np.nan
+    ctx.window_marginalize(1)
+    with pytest.raises(capi.BalmError):
+        ctx.window_add_scan(bad, pose)
+    assert ctx.window_info()[0] == 3
+    ctx.close()
+
+
+def test_sliding_window_on_shipped_scans():
+    """the shipped benchmark_realworld scans as a stream: a 20-scan window sliding by 5 over the first 45 scans (76 k points
+    per scan, voxel 2 m), poses re-estimated at every slide -- against the reference's octree, call for call"""
+    import os
+    import time
+    from conftest import ROOT
+    scans = os.path.join(ROOT, "oracle", "_ref", "realworld_scans_w177.npz")
+    feats = os.path.join(ROOT, "oracle", "_ref", "realworld_features.npz")
+    if not (os.path.exists(scans) and os.path.exists(feats)):
+        pytest.skip("oracle/_ref/realworld_scans_w177.npz not built (needs /root/reference/datas)")
+    sdat, g = np.load(scans), np.load(feats)
+    counts = sdat["counts"]
+    frames = np.split(sdat["xyz"], np.cumsum(counts)[:-1])
+    poses = g["poses"]
+    W, mg, total = 20, 5, 45
+    rng = np.random.default_rng(1)
+    ctx = capi.Context(W, flags=capi.FLAG_TIMING)
+    ctx.window_open(voxel_size=2.0)
+    win = ref.Window(W, voxel_size=2.0)
+    t_gpu = t_ref = 0.0
+    def add(i):
+        nonlocal t_gpu, t_ref
+        t0 = time.perf_counter(); ctx.window_add_scan(frames[i], poses[i]); t1 = time.perf_counter()
+        win.add_scan(frames[i], poses[i]); t2 = time.perf_counter()
+        t_gpu += t1 - t0; t_ref += t2 - t1
+    for i in range(W):
+        add(i)
+    F, nfix = compare(ctx, win, "first window")
+    layers = []
+    nxt = W
+    while nxt + mg <= total:
+        xs = noisy(poses[nxt - W:nxt], rng, 1e-4, 1e-3)
+        ctx.window_marginalize(mg, xs); win.marginalize(mg, xs)
+        for k in range(mg):
+            add(nxt); nxt += 1
+        F, nfix = compare(ctx, win, "window ending at scan %d" % nxt)
+        layers.append((F, nfix))
+    assert F > 300 and nfix > 100
+    _, (cl, co, layer, fix) = ctx.window_features()
+    assert len(np.unique(layer)) == 3                      # features at all three octree layers
+    scans_in, pts, nodes = ctx.window_info()
+    print("sliding window on shipped scans: %d scans, %d points and %d nodes resident; features/fix per slide %s; layers %s; "
+          "add_scan (cut_voxel + recut) %.1f ms per scan on the device call, reference %.1f ms"
+          % (scans_in, pts, nodes, layers, list(np.bincount(layer)), 1e3 * t_gpu / total, 1e3 * t_ref / total))
+    win.close(); ctx.close()
