@@ -102,6 +102,44 @@ class BALM2_HIP {
     return F;
   }
 
+  // The map used incrementally, on the device (balm_window_*): the three loops a sliding-window caller writes over its
+  // unordered_map<VOXEL_LOC, OCTO_TREE_ROOT*> --
+  //     cut_voxel(surf_map, pl, x, win_count - 1);  for (roots) root->recut(win_count);        -> window_add_scan(pl, x)
+  //     for (roots) root->tras_opt(voxhess, win_count);  opt.damping_iter(x_buf, voxhess);      -> window_features(); damping_iter(x_buf)
+  //     for (roots) root->marginalize(mg, x_buf, win_count);                                    -> window_marginalize(mg, x_buf)
+  // with the globals voxel_size, eigen_value_array, min_ps, layer_limit, win_size read as the reference reads them.
+  // Set reanchor = false for windows that carry fix clusters (they are world-frame; src/simulation/BAs_left.hpp's
+  // damping_iter does not re-anchor either).
+  void window_open() {
+    ensure_ctx();
+    balm_voxel_opts o;
+    balm_voxel_defaults(&o);
+    o.voxel_size = voxel_size;
+    for (int l = 0; l < 3; l++) o.eigen_thr[l] = eigen_value_array[l];
+    o.min_ps = min_ps;
+    o.layer_limit = layer_limit;
+    check(balm_window_open(ctx_, &o));
+  }
+  template <class Cloud>
+  void window_add_scan(const Cloud &pl, const IMUST &x) {
+    std::vector<float> xyz(3 * pl.size());
+    size_t k = 0;
+    for (const auto &pt : pl) { xyz[3 * k] = pt.x; xyz[3 * k + 1] = pt.y; xyz[3 * k + 2] = pt.z; k++; }
+    std::vector<double> pose = flatten_poses(std::vector<IMUST>(1, x));
+    check(balm_window_add_scan(ctx_, xyz.data(), (long)pl.size(), pose.data()));
+  }
+  int window_features() {
+    int F = 0;
+    check(balm_window_features(ctx_, &F));
+    loaded_ = (const void *)this;
+    loaded_F_ = (size_t)F;
+    return F;
+  }
+  void window_marginalize(int mg_size, const std::vector<IMUST> &x_poses) {      // an empty x_poses = no re-transform
+    std::vector<double> poses = flatten_poses(x_poses);
+    check(balm_window_marginalize(ctx_, mg_size, x_poses.empty() ? nullptr : poses.data()));
+  }
+
 #ifdef POINT_NOISE
   // The consistency driver's optimizer (src/simulation/BAs_left.hpp:1025-1098; compiled when the translation unit
   // includes src/simulation/toolss.hpp, whose PointCluster carries the 9x9 noise covariance c_cov): LM loop with
@@ -133,7 +171,9 @@ class BALM2_HIP {
   }
 #endif
 
-  // damping_iter on the features installed by associate()
+  balm_ctx *context() { ensure_ctx(); return ctx_; }     // for the C ABI's read-back calls (balm_get_features, ...)
+
+  // damping_iter on the features installed by associate() / window_features()
   void damping_iter(std::vector<IMUST> &x_stats) { run_lm(x_stats); }
 
   // bavoxel.hpp:1069

@@ -23,6 +23,8 @@ class PointCloud {
   PointCloud &operator+=(const PointCloud &o) { points.insert(points.end(), o.points.begin(), o.points.end()); width = (uint32_t)points.size(); height = 1; return *this; }
   typename std::vector<P>::iterator begin() { return points.begin(); }
   typename std::vector<P>::iterator end() { return points.end(); }
+  typename std::vector<P>::const_iterator begin() const { return points.begin(); }
+  typename std::vector<P>::const_iterator end() const { return points.end(); }
 };
 }  // namespace pcl
 #endif

@@ -104,6 +104,39 @@ int main(int argc, char **argv) {
     dev_tr = std::max(dev_tr, (x_ref[i].p - x_dev[i].p).norm());
   }
 
+  // ---- the map used incrementally: cut_voxel + recut per scan, tras_opt, marginalize(2, poses), two more scans ----
+  // (the reference's own octree against BALM2_HIP::window_*; the "new" scans are scans 0 and 1 seen again)
+  unordered_map<VOXEL_LOC, OCTO_TREE_ROOT *> live_map;
+  BALM2_HIP opt_win;
+  opt_win.verbose = false;
+  opt_win.window_open();
+  int wc = 0;
+  auto push_scan = [&](int i) {
+    cut_voxel(live_map, *pl_fulls[i], x_buf[i], wc);
+    wc++;
+    for (auto &kv : live_map) kv.second->recut(wc);
+    opt_win.window_add_scan(*pl_fulls[i], x_buf[i]);
+  };
+  for (int i = 0; i < W; i++) push_scan(i);
+  std::vector<IMUST> x_opt = x_ref;                      // "optimised" poses: the reference's result
+  for (auto &kv : live_map) kv.second->marginalize(2, x_opt, wc);
+  wc -= 2;
+  opt_win.window_marginalize(2, x_opt);
+  push_scan(0); push_scan(1);
+  VOX_HESS vh_win;
+  for (auto &kv : live_map) kv.second->tras_opt(vh_win, wc);
+  const int nfeat_win = opt_win.window_features();
+  double coe_ref = 0, fix_ref = 0, coe_dev = 0, fix_dev = 0;
+  for (size_t a = 0; a < vh_win.coeffs.size(); a++) { coe_ref += vh_win.coeffs[a]; fix_ref += vh_win.sig_vecs[a]->N; }
+  {
+    std::vector<double> co((size_t)nfeat_win), fx((size_t)nfeat_win * 10);
+    balm_get_features(opt_win.context(), nullptr, co.data(), nullptr);
+    balm_get_association(opt_win.context(), fx.data(), nullptr);
+    for (int a = 0; a < nfeat_win; a++) { coe_dev += co[(size_t)a]; fix_dev += fx[(size_t)a * 10 + 9]; }
+  }
+  const bool win_ok = (size_t)nfeat_win == vh_win.coeffs.size() && coe_ref == coe_dev && fix_ref == fix_dev && fix_ref > 0;
+  for (auto &kv : live_map) delete kv.second;
+
   double max_rot = 0, max_tr = 0;
   for (int i = 0; i < W; i++) {
     Eigen::Vector3d l = Log(x_ref[i].R.transpose() * x_hip[i].R);
@@ -120,9 +153,10 @@ int main(int argc, char **argv) {
     hmax = std::max(hmax, std::fabs(H1(r, c))); hdiff = std::max(hdiff, std::fabs(H1(r, c) - H2(r, c)));
   }
   printf("SHIM_DRIVER features=%zu iters_hip=%zu max_rot=%.3e max_trans=%.3e resid_rel=%.3e hess_rel=%.3e "
-         "dev_features=%d dev_rot=%.3e dev_trans=%.3e\n", nfeat,
-         opt_hip.last_log.size(), max_rot, max_tr, std::fabs(r1 - r2) / r1, hdiff / hmax, nfeat_dev, dev_rot, dev_tr);
+         "dev_features=%d dev_rot=%.3e dev_trans=%.3e win_features=%d/%zu win_points=%.0f/%.0f win_fix_points=%.0f/%.0f\n", nfeat,
+         opt_hip.last_log.size(), max_rot, max_tr, std::fabs(r1 - r2) / r1, hdiff / hmax, nfeat_dev, dev_rot, dev_tr, nfeat_win,
+         vh_win.coeffs.size(), coe_dev, coe_ref, fix_dev, fix_ref);
   for (auto &kv : surf_map) delete kv.second;
   return (max_rot <= 1e-5 && max_tr <= 1e-4 && hdiff / hmax < 1e-10 && (size_t)nfeat_dev == nfeat && dev_rot <= 1e-5 &&
-          dev_tr <= 1e-4) ? 0 : 1;
+          dev_tr <= 1e-4 && win_ok) ? 0 : 1;
 }

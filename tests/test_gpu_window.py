@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 from balm_amd import capi
-from oracle import ref
+from oracle import orc, ref
 from oracle import numpy_oracle as npo
 from test_gpu_voxel import cluttered_window
 
@@ -169,4 +169,56 @@ def test_sliding_window_on_shipped_scans():
     print("sliding window on shipped scans: %d scans, %d points and %d nodes resident; features/fix per slide %s; layers %s; "
           "add_scan (cut_voxel + recut) %.1f ms per scan on the device call, reference %.1f ms"
           % (scans_in, pts, nodes, layers, list(np.bincount(layer)), 1e3 * t_gpu / total, 1e3 * t_ref / total))
+    win.close(); ctx.close()
+
+
+def test_sliding_window_ba_on_shipped_scans_against_the_reference_loop():
+    """BASELINE configs[4]'s sliding window end to end: balm_amd.sliding.SlidingWindowBA (map, features and LM loop on the
+    device) over the first 40 shipped scans, W = 20 sliding by 5 -- against the same loop on the CPU: the reference's own
+    octree (cut_voxel / recut / tras_opt / marginalize, compiled from bavoxel.hpp) and the oracle's LM loop on every window.
+    Why not bavoxel.hpp's BALM2::damping_iter itself: its left_evaluate_acc2 starts C from zero (:325) while its
+    evaluate_only_residual starts from the fix cluster (:443) -- with non-empty fix clusters r1 and r2 of one iteration
+    measure different things (the first slide: gain ratio 15.7 / 2.5).  benchmark_virtual.cpp:241-243 and BAs_left.hpp carry
+    the consistent evaluator (fix cluster in both), which is what the oracle restates and the device computes.  The oracle
+    re-anchors its result to pose 0 (:1159-1164), which a window with world-frame fix clusters must not do; the comparison
+    applies that re-anchoring to the device's poses instead."""
+    import os
+    from conftest import ROOT
+    from balm_amd.sliding import SlidingWindowBA, compose, inverse
+    from util import ROT_TOL_RAD, TRANS_TOL_M, pose_errors
+    scans = os.path.join(ROOT, "oracle", "_ref", "realworld_scans_w177.npz")
+    feats = os.path.join(ROOT, "oracle", "_ref", "realworld_features.npz")
+    if not (os.path.exists(scans) and os.path.exists(feats)):
+        pytest.skip("oracle/_ref/realworld_scans_w177.npz not built (needs /root/reference/datas)")
+    sdat, g = np.load(scans), np.load(feats)
+    counts = sdat["counts"]
+    frames = np.split(sdat["xyz"], np.cumsum(counts)[:-1])
+    odom = g["poses"]
+    W, slide, total = 20, 5, 40
+    ctx = capi.Context(W)
+    ba = SlidingWindowBA(ctx, slide, voxel_size=2.0)
+    win = ref.Window(W, voxel_size=2.0)
+    worst = [0.0, 0.0]
+    nwin = 0
+    for i in range(total):
+        guess_before = None
+        r = ba.push(frames[i], odom[i])
+        # the reference's map sees the same scan with the same pose guess (what push() handed to balm_window_add_scan)
+        guess_before = (r["poses_in"][-1] if r is not None else ba.est[-1])
+        win.add_scan(frames[i], guess_before)
+        if r is None:
+            continue
+        nwin += 1
+        cl_r, fix_r, co_r = win.features()
+        assert cl_r.shape[0] == r["F"]
+        out_r, lg_r = orc.damping_iter(0, cl_r, fix_r, co_r, r["poses_in"], 0.01, 10)
+        assert len(lg_r) == len(r["log"]) and np.array_equal(lg_r[:, 6], r["log"][:, 6])
+        assert np.allclose(lg_r[:, :2], r["log"][:, :2], rtol=1e-8)
+        anchored = np.stack([compose(inverse(r["poses"][0]), p) for p in r["poses"]])
+        rot, tr = pose_errors(anchored, out_r)
+        worst = [max(worst[0], rot.max()), max(worst[1], tr.max())]
+        assert rot.max() <= ROT_TOL_RAD and tr.max() <= TRANS_TOL_M
+        win.marginalize(slide, r["poses"])
+    assert nwin == 5 and ba.trajectory().shape == (total, 12)
+    print("sliding-window BA, %d windows of %d scans: device vs reference loop %.1e rad %.1e m" % (nwin, W, worst[0], worst[1]))
     win.close(); ctx.close()
