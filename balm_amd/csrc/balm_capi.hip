@@ -331,7 +331,7 @@ balm_ctx *balm_create(int win_size, int device, int flags) {
   if (dalloc(ctx, &ctx->d_poses, (size_t)12 * W) || dalloc(ctx, &ctx->d_poses_tmp, (size_t)12 * W) ||
       dalloc(ctx, &ctx->d_red, ctx->red_len) || dalloc(ctx, &ctx->d_jobs, jobs.size()) || dalloc(ctx, &ctx->d_sub, sub.size()) ||
       dalloc(ctx, &ctx->d_H, (size_t)n * n) || dalloc(ctx, &ctx->d_g, (size_t)n) ||
-      dalloc(ctx, &ctx->d_A, (size_t)(2 * nA + NB) * nA) || dalloc(ctx, &ctx->d_Wp, (size_t)NB * (2 * nA + NB)) ||
+      dalloc(ctx, &ctx->d_A, (size_t)(2 * nA + NB) * nA) || dalloc(ctx, &ctx->d_Wp, (size_t)2 * NB * (2 * nA + NB)) ||
       dalloc(ctx, &ctx->d_dvec, (size_t)nA) || dalloc(ctx, &ctx->d_z, (size_t)nA) || dalloc(ctx, &ctx->d_x, (size_t)16 * nA) ||
       dalloc(ctx, &ctx->d_perm, (size_t)nA) || dalloc(ctx, &ctx->d_flags, (size_t)2 * (2 * (nA / NB) + 1) * (nA / NB)) || dalloc(ctx, &ctx->d_dx, (size_t)n) ||
       dalloc(ctx, &ctx->d_scal, (size_t)16) || dalloc(ctx, &ctx->d_pre, (size_t)W + 2))

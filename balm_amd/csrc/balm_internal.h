@@ -90,7 +90,7 @@ struct balm_ctx {
   double *d_g = nullptr;            // [n]
   // solver
   double *d_A = nullptr;            // [nA cols][2 nA + NB rows] permuted damped matrix + RHS row tile + identity -> L, z, L^-T D^+
-  double *d_Wp = nullptr;           // [NB][2 nA + NB]  W21 = L21 * D11 of the current panel
+  double *d_Wp = nullptr;           // [2][NB][2 nA + NB]  W21 = L21 * D11 of the current panel (two alive with lookahead)
   double *d_dvec = nullptr;         // [nA] pivots D
   double *d_z = nullptr;            // [nA] z = D^+ L^-1 P b, then scratch of the backward sweep
   double *d_x = nullptr;            // [16][nA] column-chunk partials of the solution in permuted order

@@ -154,16 +154,15 @@ __device__ __forceinline__ void row4(const Pivot4 &v, double r0, double r1, doub
   e0 = w0 * v.i0; e1 = w1 * v.i1; e2 = w2 * v.i2; e3 = w3 * v.i3;
 }
 
-__global__ __launch_bounds__(256) void k_ldl_panel(double *__restrict__ A, int nA, int c0, int nR,
-                                                   double *__restrict__ dvec, double *__restrict__ Wp,
-                                                   double *__restrict__ zvec) {
+__device__ __forceinline__ void ldl_panel_body(double *__restrict__ A, int nA, int c0, int nR, double *__restrict__ dvec,
+                                               double *__restrict__ Wp, double *__restrict__ zvec, const int bx) {
   __shared__ double cur[4][PANEL_LR];     // the four current columns, all local rows
   __shared__ double Wop[4][PANEL_LR];     // -W (B operand), k-major
   __shared__ double Lop[4][PANEL_LR];     //  L (A operand; only local rows < NB are read)
   const int ldA = 2 * nA + NB;           // nR = live rows: matrix, right-hand side tile, identity tiles <= this panel
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int l15 = lane & 15, l4 = lane >> 4;
-  const int rbase = c0 + NB + blockIdx.x * PANEL_ROWS;        // first own row
+  const int rbase = c0 + NB + bx * PANEL_ROWS;                // first own row
   auto grow = [&](int lr) { return lr < NB ? c0 + lr : rbase + (lr - NB); };   // local -> global row
 
   // ---- load the 7 x 3 tiles into accumulators (wave w owns row tiles w and w + 4) ----
@@ -220,7 +219,7 @@ __global__ __launch_bounds__(256) void k_ldl_panel(double *__restrict__ A, int n
             zvec[c0 + p0] = e0; zvec[c0 + p0 + 1] = e1; zvec[c0 + p0 + 2] = e2; zvec[c0 + p0 + 3] = e3;
           }
         }
-      } else if (blockIdx.x == 0 && lr >= p0 && lr <= p0 + 3) {
+      } else if (bx == 0 && lr >= p0 && lr <= p0 + 3) {
         // the diagonal block's D, once.  L11 is NOT written back: nothing downstream reads it, and the other
         // workgroups of this launch may not have loaded the un-factored diagonal block yet (they start late when
         // other streams share the device: a sharded context's replicated solves) -- an in-place L11 would race
@@ -247,18 +246,25 @@ __global__ __launch_bounds__(256) void k_ldl_panel(double *__restrict__ A, int n
   }
 }
 
+__global__ __launch_bounds__(256) void k_ldl_panel(double *__restrict__ A, int nA, int c0, int nR,
+                                                   double *__restrict__ dvec, double *__restrict__ Wp,
+                                                   double *__restrict__ zvec) {
+  ldl_panel_body(A, nA, c0, nR, dvec, Wp, zvec, (int)blockIdx.x);
+}
+
 // ------------------------------------------------------------------------------------------------
 // ldl_trail: A22 -= W21 L21^T on the lower triangle; one wavefront per 48 (rows i) x 16 (cols j)
 // tile, f64 MFMA, every operand prefetched before the first MFMA (the kernel is latency-bound).
 //   D[m][nn] = sum_k L21[j0+m][k] * W21[i0+nn][k]  -> element (i0+nn, j0+m); lanes of a row group
 //   touch 128 contiguous bytes of a column.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_ldl_trail(double *__restrict__ A, int nA, int c0,
-                                                   const double *__restrict__ Wp, int mt) {
+__device__ __forceinline__ void ldl_trail_body(double *__restrict__ A, int nA, int c0, const double *__restrict__ Wp, int mt,
+                                               int tj_begin, int tj_end, const int bx, const int by) {
   const int ldA = 2 * nA + NB;
   const int lane = threadIdx.x & 63;
-  const int ti = blockIdx.y;                                  // 48-row tile; ti == mt: right-hand side tile
-  const int tj = blockIdx.x * 4 + (threadIdx.x >> 6);         // 16-col tile
+  const int ti = by;                                          // 48-row tile; ti == mt: right-hand side tile
+  const int tj = tj_begin + bx * 4 + (threadIdx.x >> 6);      // 16-col tile, [tj_begin, tj_end) of the trailing square
+  if (tj >= tj_end) return;
   if (ti < mt ? (tj > 3 * ti + 2) : (tj >= 3 * mt)) return;
   const int base = c0 + NB;
   const int i0 = base + ti * NB, j0 = base + tj * 16;
@@ -292,6 +298,27 @@ __global__ __launch_bounds__(256) void k_ldl_trail(double *__restrict__ A, int n
       A[(size_t)(j0 + (lane >> 4) + 4 * e) * ldA + i0 + 16 * y + (lane & 15)] = old[y][e] - acc[y][e];
 }
 
+__global__ __launch_bounds__(256) void k_ldl_trail(double *__restrict__ A, int nA, int c0,
+                                                   const double *__restrict__ Wp, int mt, int tj_begin, int tj_end) {
+  ldl_trail_body(A, nA, c0, Wp, mt, tj_begin, tj_end, (int)blockIdx.x, (int)blockIdx.y);
+}
+
+// Lookahead in one launch: the first `npb` workgroups factor panel p (its 48 columns already carry panel p-1's update: the
+// small launch A(p-1) before this one), the others apply panel p-1 to everything to the RIGHT of those columns (16-col tiles
+// >= 3 of its trailing square).  The twelve latency-bound steps of panel p run beside the bulk of panel p-1's trailing update
+// instead of behind it.  The two parts touch disjoint columns; W21 of both panels is alive: two buffers.
+__global__ __launch_bounds__(256) void k_ldl_panel_trail(double *__restrict__ A, int nA, int c0, int nR, double *__restrict__ dvec,
+                                                         double *__restrict__ Wp, double *__restrict__ zvec, int npb, int c0_prev,
+                                                         const double *__restrict__ Wp_prev, int mt_prev, int gx_prev) {
+  const int b = (int)blockIdx.x;
+  if (b < npb) {
+    ldl_panel_body(A, nA, c0, nR, dvec, Wp, zvec, b);
+  } else {
+    const int t = b - npb;
+    ldl_trail_body(A, nA, c0_prev, Wp_prev, mt_prev, 3, 3 * mt_prev, t % gx_prev, t / gx_prev);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // k_ldl_fused: the whole blocked factorisation (every panel, every trailing update) in ONE persistent launch.
 //
@@ -321,10 +348,10 @@ __global__ __launch_bounds__(256) void k_ldl_trail(double *__restrict__ A, int n
 // staging -- issue-bound at ~3 ns each, plus two LDS round trips of ~100 ns; not flops, not barriers), 3.5 us near
 // update (18 KB of L[p, p-1] from the neighbour + 180 MFMAs on one CU), ~1.5 us flag hop / tile loads / write-out.
 // The launch pair spends ~18.6 us per panel (since its panel kernel lost the in-place L11 store and got the row reads
-// hoisted: 0.47 ms at n = 1200, 0.51 before).  Fused wins for 18 <= P <= 44 panels (0.42 vs 0.47 ms at n = 1200, 0.39 vs
-// 0.42 at the shipped window's n = 1062, 0.56 vs 0.67 at n = 1536); below that its fixed cost (cooperative launch, idle
-// helpers) shows, above it the helpers (one CU per tile update, operands re-read per update) fall behind the
-// trailing-update kernel.
+// hoisted: 0.47 ms at n = 1200, 0.51 before; 0.455 with the lookahead of launch_factor).  Fused wins for 18 <= P <= 40
+// panels (0.43 vs 0.455 ms at n = 1200, 0.39 vs 0.41 at the shipped window's n = 1062, 0.57 vs 0.64 at n = 1536); below that
+// its fixed cost (cooperative launch, idle helpers) shows, above it the helpers (one CU per tile update, operands re-read
+// per update) fall behind the trailing-update kernel (1.07 vs 0.94 ms at n = 2100).
 // ------------------------------------------------------------------------------------------------
 constexpr int FT = 576;                         // 9 wavefronts: one per 16x16 sub-tile of a 48x48 tile
 constexpr int FLR = 2 * NB;                     // local rows of a panel workgroup: 48 diagonal + 48 own
@@ -671,14 +698,16 @@ static int fused_capacity(size_t lds_bytes) {
   return per_cu * cus;
 }
 
-// The factorisation proper: one persistent cooperative launch (k_ldl_fused) where it is the faster one (18..44 panels,
-// i.e. windows of ~140..350 poses: profiles/r02h_solve_paths_by_window.txt), the launch pair per panel otherwise (and on a device that refuses the cooperative
-// launch).  BALM_SOLVE=launches / fused forces one of them (A/B runs, tests).
+// The factorisation proper: one persistent cooperative launch (k_ldl_fused) where it is the faster one (18..40 panels,
+// i.e. windows of ~140..320 poses: profiles/r02k_solve_paths_by_window.txt), launches per panel with lookahead otherwise
+// (and on a device that refuses the cooperative launch).  BALM_SOLVE=launches / fused forces one of them (A/B runs, tests).
+constexpr int FUSED_MAX_P = 40;              // the persistent kernel wins for 18 <= P <= 40 panels (profiles/r02k_solve_paths_by_window.txt)
+
 bool solve_is_persistent(const balm_ctx *c) {
   const int P = c->nA / NB;
   const char *mode = getenv("BALM_SOLVE");              // A/B: "launches" / "fused" force one path
   const bool forced = mode && !strcmp(mode, "fused");
-  return !(mode && !strcmp(mode, "launches")) && P >= 2 && (forced || (P >= 18 && P <= 44)) && c->fused_cap != 0;
+  return !(mode && !strcmp(mode, "launches")) && P >= 2 && (forced || (P >= 18 && P <= FUSED_MAX_P)) && c->fused_cap != 0;
 }
 
 static void launch_factor(balm_ctx *c) {
@@ -702,17 +731,37 @@ static void launch_factor(balm_ctx *c) {
       c->fused_cap = 0;                                  // not again on this context
     }
   }
+  // Launch path (windows outside the persistent kernel's range), with LOOKAHEAD: the trailing update of panel p is split by
+  // column -- A(p) = the next panel's own 48 columns (a small launch right behind the panel), B(p) = everything to the right
+  // of them, which rides in the SAME launch as panel p+1 (k_ldl_panel_trail).  Two launches per panel as before, but the
+  // bulk of the trailing update no longer stands in front of the next panel's twelve latency-bound steps.
+  // (Also measured: A(p) folded into panel p+1's workgroups as an in-register update, one launch per panel: 1.61 instead
+  // of 1.39 ms at n = 2880 -- every panel workgroup then repeats the diagonal block's update, 72 MFMAs on the critical path.)
+  // (Measured and rejected first: the same split on two streams with events -- bit-identical, but every cross-stream
+  // dependency costs ~4 us on this runtime: 1.94 instead of 1.74 ms at n = 2880.)
+  const char *la = getenv("BALM_LOOKAHEAD");              // A/B: 0 / 1 force
+  const bool lookahead = la ? !strcmp(la, "1") : true;
+  const size_t wp_stride = (size_t)NB * (2 * nA + NB);
   for (int p = 0; p < P; p++) {
     const int c0 = p * NB;
     const int m = nA - c0 - NB;                 // square part still to factor
     const int nR = nA + NB + NB * (p + 1);      // live rows: + right-hand side tile + identity tiles 0..p
     const int rows = nR - (c0 + NB);
-    hipLaunchKernelGGL(k_ldl_panel, dim3((rows + PANEL_ROWS - 1) / PANEL_ROWS), dim3(256), 0, s, c->d_A, nA, c0, nR,
-                       c->d_dvec, c->d_Wp, c->d_z);
-    if (m > 0) {
-      const int mt = m / NB;
-      hipLaunchKernelGGL(k_ldl_trail, dim3((3 * mt + 3) / 4, mt + 1 + (p + 1)), dim3(256), 0, s, c->d_A, nA, c0, c->d_Wp, mt);
+    const int npb = (rows + PANEL_ROWS - 1) / PANEL_ROWS;
+    const int mt = m / NB;
+    double *Wp = c->d_Wp + (lookahead ? (size_t)(p & 1) * wp_stride : 0);
+    const int mt_prev = mt + 1;                 // panel p-1's trailing square in 48-blocks
+    if (lookahead && p > 0 && mt_prev > 1) {
+      const int gx = (3 * (mt_prev - 1) + 3) / 4, gy = mt_prev + 1 + p;
+      hipLaunchKernelGGL(k_ldl_panel_trail, dim3(npb + gx * gy), dim3(256), 0, s, c->d_A, nA, c0, nR, c->d_dvec, Wp, c->d_z, npb,
+                         c0 - NB, c->d_Wp + (size_t)((p - 1) & 1) * wp_stride, mt_prev, gx);
+    } else {
+      hipLaunchKernelGGL(k_ldl_panel, dim3(npb), dim3(256), 0, s, c->d_A, nA, c0, nR, c->d_dvec, Wp, c->d_z);
     }
+    if (m <= 0) continue;
+    const int gy = mt + 1 + (p + 1);
+    if (lookahead) hipLaunchKernelGGL(k_ldl_trail, dim3(1, gy), dim3(256), 0, s, c->d_A, nA, c0, Wp, mt, 0, 3);
+    else hipLaunchKernelGGL(k_ldl_trail, dim3((3 * mt + 3) / 4, gy), dim3(256), 0, s, c->d_A, nA, c0, Wp, mt, 0, 3 * mt);
   }
 }
 

@@ -75,3 +75,30 @@ def test_fused_path_many_solves_in_a_row():
         assert rel_err(dx, ref) < 1e-9, k
     os.environ.pop("BALM_SOLVE")
     c.close()
+
+
+@pytest.mark.parametrize("W", [8, 24, 100, 400])
+def test_lookahead_launch_path(W):
+    """the lookahead form of the launch path (default for windows above the persistent kernel's range: one launch per panel,
+    the next panel's own columns updated in its workgroups' registers, the rest of the trailing update beside its steps)
+    agrees with the plain launch pair to rounding, and with itself bit for bit solve after solve (a missing dependency
+    would show up as run-to-run differences)"""
+    rng = np.random.default_rng(W)
+    n = 6 * W
+    B = rng.standard_normal((n, 64))
+    H = B @ B.T / 64 + np.diag(rng.uniform(0.5, 50.0, n))
+    g = rng.standard_normal(n)
+    c = capi.Context(W)
+    os.environ["BALM_SOLVE"] = "launches"
+    try:
+        os.environ["BALM_LOOKAHEAD"] = "0"
+        dx0, q0 = c.solve_damped(H, g, 0.1)
+        os.environ["BALM_LOOKAHEAD"] = "1"
+        dx1, q1 = c.solve_damped(H, g, 0.1)
+        assert rel_err(dx1, dx0) < 1e-11 and abs(q0 - q1) <= 1e-11 * abs(q0)
+        for _ in range(6):
+            dx2, q2 = c.solve_damped(H, g, 0.1)
+            assert np.array_equal(dx1, dx2) and q1 == q2
+    finally:
+        os.environ.pop("BALM_SOLVE"); os.environ.pop("BALM_LOOKAHEAD", None)
+    c.close()

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Times balm_solve_damped's device part (HIP events, BALM_FLAG_TIMING) for both factorisation paths at several window
+"""Times balm_solve_damped's device part (HIP events, BALM_FLAG_TIMING) for the three factorisation paths at several window
 sizes: n = 6 W unknowns.  Usage: python tools/bench_solve.py [W ...]"""
 import os
 import sys
@@ -18,11 +18,9 @@ for W in Ws:
     g = rng.standard_normal(n)
     c = capi.Context(W, 0, capi.FLAG_TIMING)
     row = []
-    for mode in ("launches", "fused"):
-        if mode == "launches":
-            os.environ["BALM_SOLVE"] = "launches"
-        else:
-            os.environ["BALM_SOLVE"] = "fused"
+    for mode in ("launches", "lookahead", "fused"):
+        os.environ["BALM_SOLVE"] = "fused" if mode == "fused" else "launches"
+        os.environ["BALM_LOOKAHEAD"] = "1" if mode == "lookahead" else "0"
         for _ in range(3):
             dx, _ = c.solve_damped(H, g, 0.1)
         c.reset_timing()
@@ -32,7 +30,7 @@ for W in Ws:
         row.append(ms / cnt)
     ref = np.linalg.solve(H + 0.1 * np.diag(np.diag(H)), -g)
     err = np.abs(dx - ref).max() / np.abs(ref).max()
-    print("W=%4d n=%5d  launches %.3f ms   fused %.3f ms   (x%.2f)  err %.1e" % (W, n, row[0], row[1], row[0] / row[1], err), flush=True)
+    print("W=%4d n=%5d  launches %.3f ms   + lookahead %.3f ms   fused %.3f ms   err %.1e" % (W, n, row[0], row[1], row[2], err), flush=True)
     c.close()
 
 if os.environ.get("BALM_SOLVE_TRACE"):
