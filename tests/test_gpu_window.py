@@ -222,3 +222,28 @@ def test_sliding_window_ba_on_shipped_scans_against_the_reference_loop():
     assert nwin == 5 and ba.trajectory().shape == (total, 12)
     print("sliding-window BA, %d windows of %d scans: device vs reference loop %.1e rad %.1e m" % (nwin, W, worst[0], worst[1]))
     win.close(); ctx.close()
+
+
+def test_window_features_feed_a_sharded_context():
+    """balm_window_features on a multi-device context (here: three loopback shards on the one GPU) hands the window's
+    feature table -- fix clusters included -- to the shards; the LM run must land where the single context lands"""
+    from util import pose_errors
+    W, mg = 8, 2
+    poses, frames = cluttered_window(11, W + mg, 40, 120, 1500)
+    outs = []
+    for kw in (dict(), dict(flags=capi.FLAG_LOOPBACK_SHARDS, n_devices=3)):
+        ctx = capi.Context(W, 0, **kw) if kw else capi.Context(W)
+        ctx.window_open(voxel_size=1.0)
+        for i in range(W):
+            ctx.window_add_scan(frames[i], poses[i])
+        ctx.window_marginalize(mg, poses[:W])
+        for i in range(W, W + mg):
+            ctx.window_add_scan(frames[i], poses[i])
+        F, (cl, co, layer, fix) = ctx.window_features()
+        assert F > 10 and (fix[:, 9] > 0).any()
+        out, lg = ctx.damping_iter(poses[mg:], form=0, u0=0.01, max_iter=5, reanchor=False)
+        outs.append((F, out, lg))
+        ctx.close()
+    assert outs[0][0] == outs[1][0] and len(outs[0][2]) == len(outs[1][2])
+    rot, tr = pose_errors(outs[0][1], outs[1][1])
+    assert rot.max() < 1e-10 and tr.max() < 1e-10
