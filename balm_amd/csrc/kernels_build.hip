@@ -4,7 +4,7 @@
 // HBM-bound: 20 bytes per point in (3 f32 + two i32 keys), one 80-byte cluster out per (a,i).
 //
 // k_build_clusters_runs (points grouped by (feature, pose), keys non-decreasing -- the order every driver of the
-// reference produces): a wavefront takes 512 consecutive points, parks their xyz in LDS (coalesced loads, all in flight at once), compacts the
+// reference produces): a wavefront takes 256..512 consecutive points (launch_build_clusters picks the block size), parks their xyz in LDS (coalesced loads, all in flight at once), compacts the
 // heads of the runs of equal keys, and then ONE LANE PER RUN pushes the run's points one by one in order with the
 // reference's own operation sequence (P += v v^T as a rounded product and a rounded add per entry, v += p, N += 1:
 // tools.hpp:311-316 compiled without FMA) -- so a cluster is bit-identical to PointCluster::push, and lanes r, r+1 hold
@@ -13,14 +13,17 @@
 // at its first point: every run has exactly one writer, no atomics.
 // The kernel raises a flag if it meets a decreasing or invalid key; the launcher then redoes the build with
 // k_build_clusters_atomic, which takes points in any order (segmented shuffle scan per wave + ten f64 atomics per run).
+#include <cstdlib>
+
 #include "balm_internal.h"
 
 namespace balm {
 
-constexpr int BUILD_BP = 512;         // points per wavefront block (8 per lane), parked in LDS (256: same speed at 6-point runs, slower at 40)
+// points per wavefront block, parked in LDS: a multiple of 64 (BALM_BUILD_BP = 256 / 384 / 512 selects it for A/B runs)
 
 struct f3 { float x, y, z; };         // 12 bytes, 4-byte aligned: one global_load_dwordx3 per point
 
+template <int BUILD_BP>
 __global__ __launch_bounds__(256) void k_build_clusters_runs(const float *__restrict__ xyz, const int *__restrict__ fid,
                                                              const int *__restrict__ pid, long n_pts, int F, int W,
                                                              double *__restrict__ soa, int *__restrict__ unsorted) {
@@ -142,10 +145,35 @@ __global__ __launch_bounds__(256) void k_build_clusters_atomic(const float *__re
 void launch_build_clusters(hipStream_t s, const float *xyz, const int *feat_id, const int *pose_id, long n_pts, int F,
                            int W, double *soa, int *flag) {
   if (n_pts <= 0) return;
-  long nblk = (n_pts + BUILD_BP - 1) / BUILD_BP;
+  // points per wavefront block: a block's runs are pushed by one lane each, 64 at a time, so the block size that wastes
+  // the fewest lanes is the one that holds a whole number of 64-run rounds.  With l = points per run (the average over the
+  // table: n_pts / (F W)) a block of 64 l points is exactly one round -- 6-point runs: 384 points, 0.169 ms for 24 M
+  // points instead of 0.205 with 512 (85 runs = a full round and a third of one); long runs take the largest block.
+  const char *e = getenv("BALM_BUILD_BP");               // A/B runs: 256 / 320 / 384 / 448 / 512
+  int bp = e ? atoi(e) : 0;
+  if (!bp) {
+    const double len = (double)n_pts / ((double)F * W > 1 ? (double)F * W : 1.0);
+    double best = -1;
+    for (int cand = 256; cand <= 512; cand += 64) {
+      const double runs = cand / (len < 1 ? 1.0 : len);
+      const double rounds = runs <= 64 ? 1.0 : (double)(long)((runs + 63.999) / 64);
+      const double eff = runs / (64.0 * rounds);
+      if (eff >= best - 1e-9) { best = eff; bp = cand; }
+    }
+  }
+  long nblk = (n_pts + bp - 1) / bp;
   long blocks = (nblk + 3) / 4;
   if (blocks > 16384) blocks = 16384;
-  hipLaunchKernelGGL(k_build_clusters_runs, dim3((unsigned)blocks), dim3(256), 0, s, xyz, feat_id, pose_id, n_pts, F, W, soa, flag);
+#define BALM_LAUNCH_RUNS(BP)                                                                                              \
+  hipLaunchKernelGGL(k_build_clusters_runs<BP>, dim3((unsigned)blocks), dim3(256), 0, s, xyz, feat_id, pose_id, n_pts, F, W, soa, flag)
+  switch (bp) {
+    case 256: BALM_LAUNCH_RUNS(256); break;
+    case 320: BALM_LAUNCH_RUNS(320); break;
+    case 384: BALM_LAUNCH_RUNS(384); break;
+    case 448: BALM_LAUNCH_RUNS(448); break;
+    default: BALM_LAUNCH_RUNS(512); break;
+  }
+#undef BALM_LAUNCH_RUNS
 }
 
 void launch_build_clusters_any(hipStream_t s, const float *xyz, const int *feat_id, const int *pose_id, long n_pts, int F,
