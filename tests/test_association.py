@@ -189,3 +189,42 @@ def test_host_association_matches_golden_consistency_rules():
     cl, co, layer, fix, _ = ah.associate(g["frames"], g["poses"], **rw.SIM_RULES)
     assert cl.shape == g["clusters"].shape
     assert np.array_equal(_canon_with_fix(cl, fix), _canon_with_fix(g["clusters"], g["fix"]))
+
+
+@pytest.mark.skipif(not ref.available(), reason="oracle/_ref not built")
+def test_reference_octree_used_incrementally():
+    """oracle/ref_driver.cpp's ref_win_* (the comparator of balm_window_*, tests/test_gpu_window.py): the reference's own
+    cut_voxel / recut / marginalize / tras_opt driven scan by scan.  (i) one recut per scan is NOT the batch association
+    in general (a voxel cut on the evidence of few scans stays cut), but it must be deterministic and, on a window whose
+    every voxel is judged the same way from the first scan on, give the batch result; (ii) a marginalisation moves the
+    first scans of plane voxels into world-frame fix clusters and the scans down."""
+    from test_gpu_voxel import cluttered_window
+    poses, frames = exact_plane_scans(4, 8, 40, 60)
+    W = len(frames)
+    win = ref.Window(W, voxel_size=1.0, layer_limit=0)
+    for i in range(W):
+        win.add_scan(frames[i], poses[i])
+    cl, fix, co = win.features()
+    win.close()
+    cl_h, co_h, lay_h = ah.associate(frames, poses, 1.0, (1.0 / 16, 1.0 / 16, 1.0 / 9), 0, 15)
+    assert cl.shape == cl_h.shape and cl.shape[0] > 5
+    assert np.array_equal(canon(cl), canon(cl_h)) and not fix.any()
+    # sliding: two windows of a cluttered scene
+    poses, frames = cluttered_window(3, 10, 40, 120, 1500)
+    runs = []
+    for _ in range(2):
+        win = ref.Window(8, voxel_size=1.0)
+        for i in range(8):
+            win.add_scan(frames[i], poses[i])
+        n0 = win.features()[0].shape[0]
+        win.marginalize(2, poses[:8])
+        for i in range(8, 10):
+            win.add_scan(frames[i], poses[i])
+        cl, fix, co = win.features()
+        win.close()
+        runs.append((n0, cl, fix, co))
+    assert runs[0][0] == runs[1][0] and np.array_equal(runs[0][1], runs[1][1]) and np.array_equal(runs[0][2], runs[1][2])
+    n0, cl, fix, co = runs[0]
+    assert cl.shape[1] == 8 and (fix[:, 9] > 0).sum() > 50
+    assert np.array_equal(co, cl[..., 9].sum(1))                  # push_voxel's weight: the window's points (bavoxel.hpp:42-44)
+    assert (cl[:, 6:, 9].sum(0) > 0).all()                        # the two new scans sit in the last slots
