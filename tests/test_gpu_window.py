@@ -172,9 +172,10 @@ def test_sliding_window_on_shipped_scans():
     win.close(); ctx.close()
 
 
-def test_sliding_window_ba_on_shipped_scans_against_the_reference_loop():
+@pytest.mark.parametrize("W,slide,total", [(20, 5, 40), (30, 10, 120)])
+def test_sliding_window_ba_on_shipped_scans_against_the_reference_loop(W, slide, total):
     """BASELINE configs[4]'s sliding window end to end: balm_amd.sliding.SlidingWindowBA (map, features and LM loop on the
-    device) over the first 40 shipped scans, W = 20 sliding by 5 -- against the same loop on the CPU: the reference's own
+    device) over the first 40 (W = 20 sliding by 5) and 120 (W = 30 sliding by 10) shipped scans -- against the same loop on the CPU: the reference's own
     octree (cut_voxel / recut / tras_opt / marginalize, compiled from bavoxel.hpp) and the oracle's LM loop on every window.
     Why not bavoxel.hpp's BALM2::damping_iter itself: its left_evaluate_acc2 starts C from zero (:325) while its
     evaluate_only_residual starts from the fix cluster (:443) -- with non-empty fix clusters r1 and r2 of one iteration
@@ -194,7 +195,6 @@ def test_sliding_window_ba_on_shipped_scans_against_the_reference_loop():
     counts = sdat["counts"]
     frames = np.split(sdat["xyz"], np.cumsum(counts)[:-1])
     odom = g["poses"]
-    W, slide, total = 20, 5, 40
     ctx = capi.Context(W)
     ba = SlidingWindowBA(ctx, slide, voxel_size=2.0)
     win = ref.Window(W, voxel_size=2.0)
@@ -219,7 +219,7 @@ def test_sliding_window_ba_on_shipped_scans_against_the_reference_loop():
         worst = [max(worst[0], rot.max()), max(worst[1], tr.max())]
         assert rot.max() <= ROT_TOL_RAD and tr.max() <= TRANS_TOL_M
         win.marginalize(slide, r["poses"])
-    assert nwin == 5 and ba.trajectory().shape == (total, 12)
+    assert nwin == (total - W) // slide + 1 and ba.trajectory().shape == (total, 12)
     print("sliding-window BA, %d windows of %d scans: device vs reference loop %.1e rad %.1e m" % (nwin, W, worst[0], worst[1]))
     win.close(); ctx.close()
 
