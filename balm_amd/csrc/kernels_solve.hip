@@ -312,6 +312,7 @@ __global__ __launch_bounds__(256) void k_ldl_panel_trail(double *__restrict__ A,
                                                          const double *__restrict__ Wp_prev, int mt_prev, int gx_prev) {
   const int b = (int)blockIdx.x;
   if (b < npb) {
+    __builtin_amdgcn_s_setprio(3);          // the panel's waves are the critical path: issue before the trailing tiles' waves
     ldl_panel_body(A, nA, c0, nR, dvec, Wp, zvec, b);
   } else {
     const int t = b - npb;
@@ -737,6 +738,11 @@ static void launch_factor(balm_ctx *c) {
   // bulk of the trailing update no longer stands in front of the next panel's twelve latency-bound steps.
   // (Also measured: A(p) folded into panel p+1's workgroups as an in-register update, one launch per panel: 1.61 instead
   // of 1.39 ms at n = 2880 -- every panel workgroup then repeats the diagonal block's update, 72 MFMAs on the critical path.)
+  // What the shared launch costs: the panel's workgroups run 17 us instead of 11.6 at n = 2880 when trailing-tile waves
+  // sit on their CUs (tools/gpu_solve_trace.sh).  Keeping them apart was tried three ways: the whole CU's LDS requested
+  // per workgroup (one workgroup per CU: 0.89 instead of 0.94 ms at n = 2100, but 1.47 instead of 1.39 at n = 2880 -- the
+  // trailing tiles starve); trailing tiles as workers that leave CUs marked busy by a panel workgroup (__smid) and pull
+  // tiles from a counter (one counter: 12 ns per fetch serialised, 5.9 ms; one per XCD with eight tiles per fetch: 2.6 ms).
   // (Measured and rejected first: the same split on two streams with events -- bit-identical, but every cross-stream
   // dependency costs ~4 us on this runtime: 1.94 instead of 1.74 ms at n = 2880.)
   const char *la = getenv("BALM_LOOKAHEAD");              // A/B: 0 / 1 force
