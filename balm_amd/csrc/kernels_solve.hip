@@ -708,6 +708,11 @@ bool solve_is_persistent(const balm_ctx *c) {
   const int P = c->nA / NB;
   const char *mode = getenv("BALM_SOLVE");              // A/B: "launches" / "fused" force one path
   const bool forced = mode && !strcmp(mode, "fused");
+  // Not from the device threads of an in-process multi-device context: a cooperative launch issued by a thread other than
+  // the process's first leaves this runtime (ROCm 7.2) in a state that segfaults at process exit (tools/exp_crash.py:
+  // exit code 139 after a correct run; launches path: 0).  Those replicas take the launch path with lookahead (+6 % per
+  // solve at n = 1200); one process per GPU (balm_comm_init_rank) is not affected.
+  if (c->multi && c->multi->n > 1) return false;
   return !(mode && !strcmp(mode, "launches")) && P >= 2 && (forced || (P >= 18 && P <= FUSED_MAX_P)) && c->fused_cap != 0;
 }
 

@@ -106,6 +106,23 @@ def test_hip_reproduces_reference_run(case, which):
 
 
 @pytest.mark.gpu
+def test_hip_sharded_reproduces_reference_run_w200_f50000():
+    """the same acceptance test through the multi-device path (BASELINE configs[3]'s mechanism: features sharded, one
+    all-reduce of the assembled payload per evaluation, replicated solve): four shards of the 50 000 features on the one
+    GPU of the test box (BALM_FLAG_LOOPBACK_SHARDS: own streams, host threads and replicas, the library's own reduction) --
+    final poses against the reference's bavoxel.hpp run."""
+    from balm_amd import capi
+    g, sc = load("lm_big_w200_f50000")
+    k = CONSTANTS["bavoxel"]
+    c = capi.Context(sc.W, 0, capi.FLAG_LOOPBACK_SHARDS, n_devices=4)
+    c.set_features(sc.clusters, None, sc.coeffs)
+    out, lg = c.damping_iter(sc.poses_init, form=0, u0=k["u0"], max_iter=k["max_iter"], min_planes=k["min_planes"])
+    c.close()
+    rot, tr = check_run(g, "bavoxel", out, lg)
+    print("lm_big_w200_f50000 bavoxel, 4 shards: %d iterations, max pose difference to the reference %.2e rad %.2e m" % (len(lg), rot, tr))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("args", [(1, 20, 150, 40), (7, 64, 5000, 6)], ids=["launch_defaults", "configs1"])
 def test_cpp_virtual_driver_calls_the_shim_unchanged(args):
     """tests/cpp/shim_virtual_driver.cpp: the reference's benchmark_virtual.cpp translation unit + the shim header;
