@@ -60,6 +60,16 @@ int dalloc(balm_ctx *ctx, T **p, size_t count) {
   return BALM_OK;
 }
 
+// grow-only buffers of the feature table: a caller that installs a table per window (balm_associate, balm_window_features,
+// balm_set_features in a loop) pays for hipMalloc / hipFree only while the tables grow
+template <class T>
+int keep(balm_ctx *ctx, T **p, size_t *cap, size_t count) {
+  if (*p && *cap >= count) return BALM_OK;
+  int rc = dalloc(ctx, p, count + count / 4);
+  *cap = rc ? 0 : count + count / 4;
+  return rc;
+}
+
 template <class T>
 int ensure(balm_ctx *ctx, T **p, size_t *cap, size_t count) {
   if (*p && *cap >= count) return BALM_OK;
@@ -145,7 +155,7 @@ int residual_device(balm_ctx *ctx, const double *d_poses, int f0, int f1, int sl
   } else {
     Span sp(ctx, BALM_T_MOMENTS);
     launch_world_moments(ctx->stream, ctx->d_cl, d_poses, ctx->W, f0, f1, ctx->d_C);
-    ctx->nr_tmp = launch_feature_eigen(ctx->stream, ctx->d_C, ctx->d_fix, ctx->d_coe, f0, f1, ctx->d_feat_tmp,
+    ctx->nr_tmp = launch_feature_eigen(ctx->stream, ctx->d_C, ctx->has_fix ? ctx->d_fix : nullptr, ctx->d_coe, f0, f1, ctx->d_feat_tmp,
                                        ctx->d_rpart_tmp);
     launch_sum_scalar(ctx->stream, ctx->d_rpart_tmp, ctx->nr_tmp, ctx->d_scal + slot);
   }
@@ -188,7 +198,7 @@ int evaluate_device(balm_ctx *ctx, int form, const double *d_poses, int f0, int 
   if (!(ctx->feat_cur_valid && f0 == 0 && f1 == ctx->F)) {
     Span sp(ctx, BALM_T_MOMENTS);
     launch_world_moments(s, ctx->d_cl, d_poses, W, f0, f1, ctx->d_C);
-    ctx->nr_cur = launch_feature_eigen(s, ctx->d_C, ctx->d_fix, ctx->d_coe, f0, f1, ctx->d_feat, ctx->d_rpart);
+    ctx->nr_cur = launch_feature_eigen(s, ctx->d_C, ctx->has_fix ? ctx->d_fix : nullptr, ctx->d_coe, f0, f1, ctx->d_feat, ctx->d_rpart);
     ctx->feat_cur_valid = (f0 == 0 && f1 == ctx->F);
   }
   const int nr = ctx->nr_cur;
@@ -455,8 +465,8 @@ static int build_sparse_plan(balm_ctx *ctx, int F, const double *clusters) {
   for (const Order &o : order) sorted_items.insert(sorted_items.end(), items.begin() + 4L * o.item, items.begin() + 4L * o.item + 4);
   if (chunk_ids.empty()) chunk_ids.push_back(0);
   int rc;
-  if ((rc = dalloc(ctx, &ctx->d_slot, (size_t)F)) || (rc = dalloc(ctx, &ctx->d_items, sorted_items.size())) ||
-      (rc = dalloc(ctx, &ctx->d_chunk_ids, chunk_ids.size())) || (rc = dalloc(ctx, &ctx->d_csr, csr.size())))
+  if ((rc = keep(ctx, &ctx->d_slot, &ctx->cap_slot, (size_t)F)) || (rc = keep(ctx, &ctx->d_items, &ctx->cap_items, sorted_items.size())) ||
+      (rc = keep(ctx, &ctx->d_chunk_ids, &ctx->cap_chunk_ids, chunk_ids.size())) || (rc = keep(ctx, &ctx->d_csr, &ctx->cap_csr, csr.size())))
     return rc;
   HIP_TRY(hipMemcpy(ctx->d_slot, slot.data(), slot.size() * sizeof(int), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(ctx->d_items, sorted_items.data(), sorted_items.size() * sizeof(int), hipMemcpyHostToDevice));
@@ -469,19 +479,18 @@ static int build_sparse_plan(balm_ctx *ctx, int F, const double *clusters) {
 static int install_feature_buffers(balm_ctx *ctx, int F, const double *fix, const double *coeffs) {
   int rc;
   drop_lm_graphs(ctx);
+  ctx->has_fix = fix != nullptr;
   if (fix) {
-    if ((rc = dalloc(ctx, &ctx->d_fix, (size_t)F * 10))) return rc;
+    if ((rc = keep(ctx, &ctx->d_fix, &ctx->cap_fix, (size_t)F * 10))) return rc;
     HIP_TRY(hipMemcpyAsync(ctx->d_fix, fix, (size_t)F * 10 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-  } else if (ctx->d_fix) {
-    hipFree(ctx->d_fix); ctx->d_fix = nullptr;
   }
-  if ((rc = dalloc(ctx, &ctx->d_coe, (size_t)F))) return rc;
+  if ((rc = keep(ctx, &ctx->d_coe, &ctx->cap_coe, (size_t)F))) return rc;
   HIP_TRY(hipMemcpyAsync(ctx->d_coe, coeffs, (size_t)F * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-  if ((rc = dalloc(ctx, &ctx->d_C, (size_t)F * 10))) return rc;
-  if ((rc = dalloc(ctx, &ctx->d_feat, (size_t)F * FEAT_STRIDE))) return rc;
-  if ((rc = dalloc(ctx, &ctx->d_feat_tmp, (size_t)F * FEAT_STRIDE))) return rc;
-  if ((rc = dalloc(ctx, &ctx->d_rpart, (size_t)(F + 255) / 256 + 1))) return rc;
-  if ((rc = dalloc(ctx, &ctx->d_rpart_tmp, (size_t)(F + 255) / 256 + 1))) return rc;
+  if ((rc = keep(ctx, &ctx->d_C, &ctx->cap_C, (size_t)F * 10))) return rc;
+  if ((rc = keep(ctx, &ctx->d_feat, &ctx->cap_feat, (size_t)F * FEAT_STRIDE))) return rc;
+  if ((rc = keep(ctx, &ctx->d_feat_tmp, &ctx->cap_feat_tmp, (size_t)F * FEAT_STRIDE))) return rc;
+  if ((rc = keep(ctx, &ctx->d_rpart, &ctx->cap_rpart, (size_t)(F + 255) / 256 + 1))) return rc;
+  if ((rc = keep(ctx, &ctx->d_rpart_tmp, &ctx->cap_rpart_tmp, (size_t)(F + 255) / 256 + 1))) return rc;
   ctx->feat_cur_valid = false;
   ctx->F = F;
   return BALM_OK;
@@ -496,7 +505,7 @@ static int one_set_features(balm_ctx *ctx, int F, const double *clusters, const 
   const size_t count = (size_t)F * W * 10;
   int rc;
   ctx->F = 0;
-  if ((rc = dalloc(ctx, &ctx->d_cl, count))) return rc;
+  if ((rc = keep(ctx, &ctx->d_cl, &ctx->cap_cl, count))) return rc;
   if ((rc = stage_begin(ctx, count * sizeof(double)))) return rc;
   double *d_aos = stage_take<double>(ctx, count);
   hipError_t e = hipMemcpyAsync(d_aos, clusters, count * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
@@ -522,7 +531,7 @@ static int one_build_clusters(balm_ctx *ctx, int F, const float *xyz, const int 
   const size_t count = (size_t)F * W * 10;
   int rc;
   ctx->F = 0;
-  if ((rc = dalloc(ctx, &ctx->d_cl, count))) return rc;
+  if ((rc = keep(ctx, &ctx->d_cl, &ctx->cap_cl, count))) return rc;
   const size_t np1 = (size_t)(n_pts ? n_pts : 1);
   if ((rc = stage_begin(ctx, np1 * 20 + count * sizeof(double)))) return rc;
   float *d_xyz = stage_take<float>(ctx, np1 * 3);
@@ -575,16 +584,16 @@ void balm_voxel_defaults(balm_voxel_opts *o) {
   o->want_point_features = 0;
 }
 
-// the feature table an association left on the device (hipMalloc'ed [F][W][10] clusters, weights, fix clusters, layers,
-// optionally the feature of every point) becomes the context's feature table; the device arrays are freed
+// the feature table an association left on the device ([F][W][10] clusters, weights, fix clusters, layers, optionally the
+// feature of every point) becomes the context's feature table; the device arrays are freed if they are the caller's to free
 static int install_associated(balm_ctx *ctx, int F, double *d_out, double *d_coe, double *d_fix, int *d_lay, int *d_pf, long n_pts,
-                              bool has_fix) {
+                              bool has_fix, bool owned = true) {
   const int W = ctx->W;
   const size_t count = (size_t)F * W * 10;
   ctx->assoc_clusters.resize(count); ctx->assoc_coeffs.resize(F); ctx->assoc_layer.resize(F); ctx->assoc_fix.resize((size_t)F * 10);
   if (d_pf) ctx->assoc_point_feat.resize((size_t)n_pts);
   hipError_t e = hipSuccess;
-  int rc = dalloc(ctx, &ctx->d_cl, count);
+  int rc = keep(ctx, &ctx->d_cl, &ctx->cap_cl, count);
   if (!rc) {
     launch_transpose_clusters(ctx->stream, d_out, ctx->d_cl, F, W);
     e = hipMemcpyAsync(ctx->assoc_clusters.data(), d_out, count * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
@@ -595,8 +604,10 @@ static int install_associated(balm_ctx *ctx, int F, double *d_out, double *d_coe
       e = hipMemcpyAsync(ctx->assoc_point_feat.data(), d_pf, (size_t)n_pts * sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
   }
-  hipFree(d_out); hipFree(d_coe); hipFree(d_fix); hipFree(d_lay);
-  if (d_pf) hipFree(d_pf);
+  if (owned) {
+    hipFree(d_out); hipFree(d_coe); hipFree(d_fix); hipFree(d_lay);
+    if (d_pf) hipFree(d_pf);
+  }
   if (rc) return rc;
   HIP_TRY(e);
   const double *fix = has_fix ? ctx->assoc_fix.data() : nullptr;
@@ -726,7 +737,7 @@ static int one_window_features(balm_ctx *ctx, int *F_out) {
   }
   if (rc) return window_rc(ctx, "balm_window_features", rc);
   if (F == 0) return BALM_OK;
-  if ((rc = install_associated(ctx, F, d_out, d_coe, d_fix, d_lay, nullptr, 0, true))) return rc;
+  if ((rc = install_associated(ctx, F, d_out, d_coe, d_fix, d_lay, nullptr, 0, true, /*owned=*/false))) return rc;
   *F_out = F;
   return BALM_OK;
 }

@@ -67,6 +67,9 @@ struct balm_ctx {
   int nr_cur = 0, nr_tmp = 0;       // number of valid residual partials in d_rpart / d_rpart_tmp
   bool feat_cur_valid = false;      // d_feat / d_rpart describe d_poses
   double *d_Gt = nullptr;           // [Kcols][npad]  factored Hessian columns (k-major)
+  size_t cap_cl = 0, cap_fix = 0, cap_coe = 0, cap_C = 0, cap_feat = 0, cap_feat_tmp = 0, cap_rpart = 0, cap_rpart_tmp = 0;   // elements
+  size_t cap_slot = 0, cap_items = 0, cap_chunk_ids = 0, cap_csr = 0;
+  bool has_fix = false;             // the installed table carries fix clusters (d_fix may be a larger, older allocation)
   size_t cap_Gt = 0;                // doubles
   double *d_part = nullptr;         // [SG][ntiles][6400] split-K partial tiles
   size_t cap_part = 0;

@@ -32,8 +32,9 @@ for i in range(a.scans):
         inwin = list(out[a.slide:])
 ms, n = ctx.timing()["voxel"]
 scans, pts, nodes = ctx.window_info()
-print("window %d, slide %d, %d scans of ~%d points: add_scan %.2f ms (full window: %.2f), features %.2f ms, LM %.2f ms (%d its last), "
-      "marginalize %.2f ms; device time in balm_window_* %.2f ms per call; %d points, %d nodes resident"
-      % (W, a.slide, a.scans, int(counts[:a.scans].mean()), 1e3 * np.mean(t_add), 1e3 * np.mean(t_add[W:]), 1e3 * np.mean(t_feat),
-         1e3 * np.mean(t_lm), len(lg), 1e3 * np.mean(t_marg), ms / max(n, 1), pts, nodes))
+med = lambda v: 1e3 * float(np.median(v))       # medians: the first calls of each kind size the session's buffers
+print("window %d, slide %d, %d scans of ~%d points, median call times: add_scan %.2f ms (with the window full: %.2f), features %.2f ms, "
+      "LM %.2f ms (%d its last), marginalize %.2f ms; device time in balm_window_* %.2f ms per call; %d points, %d nodes resident"
+      % (W, a.slide, a.scans, int(counts[:a.scans].mean()), med(t_add), med(t_add[W:]), med(t_feat), med(t_lm), len(lg), med(t_marg),
+         ms / max(n, 1), pts, nodes))
 ctx.close()
