@@ -247,3 +247,31 @@ def test_window_features_feed_a_sharded_context():
     assert outs[0][0] == outs[1][0] and len(outs[0][2]) == len(outs[1][2])
     rot, tr = pose_errors(outs[0][1], outs[1][1])
     assert rot.max() < 1e-10 and tr.max() < 1e-10
+
+
+def test_window_edge_cases_against_reference():
+    """small and degenerate sequences, call for call against the reference's octree: a tiny scan, a scan that only revisits
+    known voxels, layer_limit 0 and 1, the whole window marginalised at once and the map used again afterwards"""
+    poses, frames = cluttered_window(21, 9, 30, 80, 600)
+    for limit in (0, 1):
+        ctx = capi.Context(4)
+        ctx.window_open(voxel_size=1.0, layer_limit=limit)
+        win = ref.Window(4, voxel_size=1.0, layer_limit=limit)
+        def both(f, *a):
+            getattr(ctx, "window_" + f)(*a); getattr(win, f)(*a)
+        both("add_scan", frames[0], poses[0])
+        both("add_scan", frames[1][:10], poses[1])                # ten points
+        both("add_scan", frames[0], poses[0])                     # the first scan again: only known voxels
+        both("add_scan", frames[2], poses[2])
+        compare(ctx, win, "limit %d, first window" % limit)
+        both("marginalize", 4, np.stack([poses[0], poses[1], poses[0], poses[2]]))        # everything leaves
+        assert ctx.window_info()[:2] == (0, 0)
+        compare(ctx, win, "limit %d, empty window" % limit)      # no window points: no features on either side
+        for i in range(3, 7):
+            both("add_scan", frames[i], poses[i])
+        F, nfix = compare(ctx, win, "limit %d, refilled" % limit)
+        assert F > 5 and nfix > 0                                  # the fix clusters of the first life are still there
+        both("marginalize", 1, None)
+        both("add_scan", frames[7], poses[7])
+        compare(ctx, win, "limit %d, after a marginalisation without poses" % limit)
+        win.close(); ctx.close()
