@@ -12,7 +12,7 @@ from oracle import orc, ref
 from util import make_scene, pose_errors, rel_err
 
 GOLD = sorted(g for g in glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz"))
-              if not os.path.basename(g).startswith(("cov_", "assoc_", "lm_big_")))      # covariance fixtures: tests/test_cov_oracle.py; LM runs at the BASELINE sizes: tests/test_north_star.py
+              if not os.path.basename(g).startswith(("cov_", "assoc_", "lm_big_", "window_")))      # covariance fixtures: tests/test_cov_oracle.py; LM runs at the BASELINE sizes: tests/test_north_star.py
 
 
 def load(path):

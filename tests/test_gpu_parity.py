@@ -299,7 +299,7 @@ import glob as _glob
 import os as _os
 
 _GOLD = sorted(g for g in _glob.glob(_os.path.join(_os.path.dirname(__file__), "golden", "*.npz"))
-               if not _os.path.basename(g).startswith(("cov_", "assoc_", "lm_big_")))      # covariance fixtures: tests/test_gpu_cov.py
+               if not _os.path.basename(g).startswith(("cov_", "assoc_", "lm_big_", "window_")))      # covariance fixtures: tests/test_gpu_cov.py
 
 
 @pytest.mark.parametrize("path", _GOLD, ids=[_os.path.basename(p)[:-4] for p in _GOLD])
