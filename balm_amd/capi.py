@@ -15,14 +15,14 @@ FORM_LEFT, FORM_RIGHT = 0, 1
 OK, ERR_ARG, ERR_HIP, ERR_STATE, ERR_TOO_FEW_PLANES, ERR_NUMERIC = range(6)
 FLAG_TIMING = 1
 FLAG_LOOPBACK_SHARDS = 2
-T_MOMENTS, T_FACTORS, T_SYRK, T_ASSEMBLE, T_SOLVE, T_UPDATE, T_BUILD, T_VOXEL, T_COV, T_COUNT = range(10)
-TIMING_NAMES = ["moments", "factors", "syrk", "assemble", "solve", "update", "build", "voxel", "cov"]
+T_MOMENTS, T_FACTORS, T_SYRK, T_ASSEMBLE, T_SOLVE, T_UPDATE, T_BUILD, T_VOXEL, T_COV, T_COMM, T_COUNT = range(11)
+TIMING_NAMES = ["moments", "factors", "syrk", "assemble", "solve", "update", "build", "voxel", "cov", "comm"]
 
 # every symbol include/balm_hip.h declares
 EXPORTS = ["balm_create", "balm_create_multi", "balm_destroy", "balm_set_features", "balm_evaluate", "balm_only_residual",
            "balm_solve_damped", "balm_damping_iter", "balm_build_clusters", "balm_voxel_defaults", "balm_associate", "balm_get_features", "balm_get_association", "balm_pose_covariance",
            "balm_window_open", "balm_window_add_scan", "balm_window_features", "balm_window_marginalize", "balm_window_info", "balm_window_close",
-           "balm_set_allreduce", "balm_comm_unique_id", "balm_comm_init_rank",
+           "balm_set_allreduce", "balm_comm_unique_id", "balm_comm_init_rank", "balm_comm_info",
            "balm_get_timing", "balm_get_solve_trace", "balm_reset_timing", "balm_work_model", "balm_last_error", "balm_version"]
 
 
@@ -93,6 +93,7 @@ def lib():
         L.balm_set_allreduce.argtypes = [C.c_void_p, ALLREDUCE_FN, C.c_void_p]
         L.balm_comm_unique_id.argtypes = [C.c_void_p]
         L.balm_comm_init_rank.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.balm_comm_info.argtypes = [C.c_void_p, C.c_void_p]
         L.balm_get_timing.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.balm_get_solve_trace.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_void_p]
         L.balm_reset_timing.argtypes = [C.c_void_p]
@@ -324,6 +325,13 @@ class Context:
         """RCCL inside the library for the one-process-per-GPU launch: no hook, no host synchronisation."""
         buf = C.create_string_buffer(bytes(unique_id), 128)
         self._check(self.L.balm_comm_init_rank(self.h, int(n_ranks), int(rank), buf))
+
+    def comm_info(self):
+        """what the transport itself reports: ranks (ncclCommCount), own rank, payload doubles per evaluation, kind"""
+        out = (C.c_long * 4)()
+        self._check(self.L.balm_comm_info(self.h, out))
+        return {"ranks": int(out[0]), "rank": int(out[1]), "payload_doubles": int(out[2]),
+                "transport": ["none", "rccl-in-library", "loopback-shards", "caller-hook"][int(out[3])]}
 
     def timing(self):
         ms = np.zeros(T_COUNT)

@@ -65,6 +65,8 @@ int dalloc(balm_ctx *ctx, T **p, size_t count) {
 template <class T>
 int keep(balm_ctx *ctx, T **p, size_t *cap, size_t count) {
   if (*p && *cap >= count) return BALM_OK;
+  for (int k = 0; k < 4; k++)           // captured LM graphs hold the old pointer (as in ensure())
+    if (ctx->lm_graph[k]) { hipGraphExecDestroy(ctx->lm_graph[k]); ctx->lm_graph[k] = nullptr; ctx->lm_graph_form[k] = -1; }
   int rc = dalloc(ctx, p, count + count / 4);
   *cap = rc ? 0 : count + count / 4;
   return rc;
@@ -117,8 +119,8 @@ long red_r_off(const balm_ctx *c) { return red_dacc_off(c) + (long)DACC_MAX * c-
 bool has_transport(const balm_ctx *ctx) { return ctx->comm || multi_is_loopback(ctx) || ctx->allreduce; }
 
 int hook_allreduce(balm_ctx *ctx, double *buf, long n) {
-  if (ctx->comm) return comm_allreduce(ctx, buf, n);
-  if (multi_is_loopback(ctx)) return loopback_allreduce(ctx, buf, n);
+  if (ctx->comm) { Span sp(ctx, BALM_T_COMM); return comm_allreduce(ctx, buf, n); }
+  if (multi_is_loopback(ctx)) { Span sp(ctx, BALM_T_COMM); return loopback_allreduce(ctx, buf, n); }
   if (!ctx->allreduce) return BALM_OK;
   int rc = sync_stream(ctx);
   if (rc) return rc;
@@ -159,6 +161,7 @@ int residual_device(balm_ctx *ctx, const double *d_poses, int f0, int f1, int sl
                                        ctx->d_rpart_tmp);
     launch_sum_scalar(ctx->stream, ctx->d_rpart_tmp, ctx->nr_tmp, ctx->d_scal + slot);
   }
+  HIP_TRY(hipGetLastError());          // k_world_moments: dynamic LDS above the 64 KiB default
   return hook_allreduce(ctx, ctx->d_scal + slot, 1);
 }
 
@@ -215,6 +218,9 @@ int evaluate_device(balm_ctx *ctx, int form, const double *d_poses, int f0, int 
     launch_factors(s, form, ctx->d_cl, d_poses, ctx->d_feat, W, ctx->npad, f0, f1, ctx->d_Gt, ctx->d_dpart, nblk,
                    sparse ? ctx->d_slot : nullptr);
   }
+  // the moments / factor kernels ask for up to 150 KB of dynamic LDS (above the 64 KiB default: granted per device by
+  // prepare_device_accum); a refused launch must surface here, not as stale results at the next synchronisation
+  HIP_TRY(hipGetLastError());
   {
     Span sp(ctx, BALM_T_SYRK);
     if (sparse) launch_syrk_sparse(s, ctx->d_Gt, ctx->npad, ctx->d_jobs, ctx->d_items, ctx->d_chunk_ids, ctx->sp_nsteps, ctx->sp_nitems, ctx->d_part);
@@ -679,7 +685,17 @@ static int one_associate(balm_ctx *ctx, const balm_voxel_opts *opts, const float
 static int window_rc(balm_ctx *ctx, const char *who, int rc) {
   if (rc == 0) return BALM_OK;
   ctx->err = std::string(who) + (rc == -2 ? ": window full / bad size" : rc == -3 ? ": non-finite point or beyond 2^20 voxels" : ": device failure");
+  // a device failure (allocation, copy, launch) can strike after the call has already advanced the map's bookkeeping (slot
+  // poses, node counts, the root table) but before its points and clusters are in: a retry would build on a corrupted
+  // map.  The session answers BALM_ERR_STATE from here on; balm_window_open starts a fresh one.
+  if (rc == -1) ctx->window_dead = true;
   return rc == -1 ? BALM_ERR_HIP : BALM_ERR_ARG;
+}
+
+static int window_alive(balm_ctx *ctx, const char *who) {
+  if (!ctx->window) { ctx->err = std::string(who) + ": no open window"; return BALM_ERR_STATE; }
+  if (ctx->window_dead) { ctx->err = std::string(who) + ": an earlier window call failed on the device; re-open the window (balm_window_open)"; return BALM_ERR_STATE; }
+  return BALM_OK;
 }
 
 static int one_window_open(balm_ctx *ctx, const balm_voxel_opts *opts) {
@@ -695,13 +711,14 @@ static int one_window_open(balm_ctx *ctx, const balm_voxel_opts *opts) {
   AssocOpts ao{ctx->W, opts->voxel_size, {opts->eigen_thr[0], opts->eigen_thr[1], opts->eigen_thr[2]}, opts->min_ps, opts->layer_limit,
                opts->min_observers, 0, 0, 0, 0};
   ctx->window = window_open(ctx->stream, ao);
+  ctx->window_dead = false;
   if (!ctx->window) { ctx->err = "balm_window_open: allocation failed"; return BALM_ERR_HIP; }
   return BALM_OK;
 }
 
 static int one_window_add_scan(balm_ctx *ctx, const float *xyz, long n_pts, const double *pose12) {
   if (!ctx) return BALM_ERR_ARG;
-  if (!ctx->window) { ctx->err = "balm_window_add_scan: no open window"; return BALM_ERR_STATE; }
+  if (int rcw = window_alive(ctx, "balm_window_add_scan")) return rcw;
   if (!xyz || !pose12 || n_pts < 1) { ctx->err = "balm_window_add_scan: bad argument"; return BALM_ERR_ARG; }
   HIP_TRY(hipSetDevice(ctx->device));
   int rc = stage_begin(ctx, (size_t)n_pts * 12);
@@ -714,7 +731,7 @@ static int one_window_add_scan(balm_ctx *ctx, const float *xyz, long n_pts, cons
 
 static int one_window_marginalize(balm_ctx *ctx, int mg, const double *poses) {
   if (!ctx) return BALM_ERR_ARG;
-  if (!ctx->window) { ctx->err = "balm_window_marginalize: no open window"; return BALM_ERR_STATE; }
+  if (int rcw = window_alive(ctx, "balm_window_marginalize")) return rcw;
   HIP_TRY(hipSetDevice(ctx->device));
   Span sp(ctx, BALM_T_VOXEL);
   return window_rc(ctx, "balm_window_marginalize", window_marginalize(ctx->window, mg, poses));
@@ -722,7 +739,7 @@ static int one_window_marginalize(balm_ctx *ctx, int mg, const double *poses) {
 
 static int one_window_features(balm_ctx *ctx, int *F_out) {
   if (!ctx) return BALM_ERR_ARG;
-  if (!ctx->window) { ctx->err = "balm_window_features: no open window"; return BALM_ERR_STATE; }
+  if (int rcw = window_alive(ctx, "balm_window_features")) return rcw;
   if (!F_out) { ctx->err = "balm_window_features: bad argument"; return BALM_ERR_ARG; }
   HIP_TRY(hipSetDevice(ctx->device));
   *F_out = 0;
@@ -803,6 +820,7 @@ static int one_pose_covariance(balm_ctx *ctx, const double *poses, const double 
     hipMemsetAsync(Gy + k0 * ctx->npad, 0, (gcols - k0) * ctx->npad * sizeof(double), s);
     launch_cov_factors(s, ctx->d_cl, d_cc, point_sigma * point_sigma, ctx->d_poses, ctx->d_feat, W, ctx->npad, F, Gx, Gy,
                        ctx->d_dpart, nblk);
+    e = hipGetLastError();             // dynamic LDS above the 64 KiB default
     launch_syrk(s, Gx, ctx->npad, ctx->ntiles, ctx->d_jobs, plan, ctx->d_part);
     launch_cov_reduce_tiles(s, ctx->d_part, plan.SG, (long)tiles, redx);
     launch_syrk(s, Gy, ctx->npad, ctx->ntiles, ctx->d_jobs, plan, ctx->d_part);
@@ -825,6 +843,21 @@ static int one_pose_covariance(balm_ctx *ctx, const double *poses, const double 
   if (rc) return rc;
   HIP_TRY(e);
   collect_timing(ctx);
+  return BALM_OK;
+}
+
+int balm_comm_info(balm_ctx *ctx, long *out4) {
+  if (!ctx || !out4) return BALM_ERR_ARG;
+  out4[0] = 1; out4[1] = 0; out4[2] = (long)ctx->red_len; out4[3] = 0;
+  if (ctx->comm) {
+    int cnt = -1, rk = -1;
+    comm_query(ctx, &cnt, &rk);
+    out4[0] = cnt; out4[1] = rk; out4[3] = 1;
+  } else if (multi_is_loopback(ctx)) {
+    out4[0] = ctx->multi->n; out4[1] = ctx->rank; out4[3] = 2;
+  } else if (ctx->allreduce) {
+    out4[0] = -1; out4[3] = 3;                      // the caller's transport: its size is the caller's to know
+  }
   return BALM_OK;
 }
 
@@ -1001,12 +1034,18 @@ static int one_damping_iter(balm_ctx *ctx, const balm_lm_opts *o, double *poses,
   double u = o->u0, v = 2, r1 = 0, r2 = 0;
   bool calc = true;
   int it = 0;
+  // fault injection for tests/test_gpu_multi.py (a device thread that leaves the loop must take its peers out with it, not
+  // leave them waiting): BALM_FAULT_INJECT="<rank>,<iteration>" makes that device of a sharded context fail there
+  int fault_rank = -1, fault_it = -1;
+  if (ctx->multi)
+    if (const char *fi = getenv("BALM_FAULT_INJECT")) sscanf(fi, "%d,%d", &fault_rank, &fault_it);
   while (it < o->max_iter) {
     const bool evaluated = calc || o->force_hess;
+    if (ctx->rank == fault_rank && it == fault_it) { ctx->err = "balm_damping_iter: injected fault"; return BALM_ERR_HIP; }
     if ((rc = set_damping(ctx, u))) return rc;
     if ((rc = lm_iteration(ctx, o->form, evaluated, it))) return rc;
     double sc[3] = {ctx->h_scal[0], ctx->h_scal[1], ctx->h_scal[2]};
-    multi_share_scalars(ctx, it, sc, 3);         // device 0's scalars decide on every device thread
+    if ((rc = multi_share_scalars(ctx, it, sc, 3))) return rc;       // device 0's scalars decide on every device thread
     r1 = sc[0]; r2 = sc[1];
     const double q1 = sc[2];
     double q = r1 - r2;
@@ -1286,6 +1325,16 @@ int balm_work_model(balm_ctx *ctx, double *out4) {
   SyrkPlan p = plan_syrk(ctx->ntiles, 3L * (long)F);
   out4[3] = (double)ctx->ntiles * 25.0 * 2048.0 * ((double)p.Kpad / 4.0);   // 25 MFMAs per k-step of every job
   if (ctx->sparse && !ctx->multi) out4[3] = ctx->sp_steps * 25.0 * 2048.0;
+  if (ctx->multi) {                        // what the shards issue, each with its own plan (dense or block-sparse)
+    double issued = 0;
+    for (size_t k = 0; k < ctx->multi->sub.size(); k++) {
+      const balm_ctx *q = ctx->multi->sub[k];
+      if (q->F < 1) continue;
+      if (q->sparse) issued += q->sp_steps * 25.0 * 2048.0;
+      else { const SyrkPlan pk = plan_syrk(q->ntiles, 3L * q->F); issued += (double)q->ntiles * 25.0 * 2048.0 * ((double)pk.Kpad / 4.0); }
+    }
+    out4[3] = issued;
+  }
   return BALM_OK;
 }
 

@@ -117,6 +117,7 @@ struct balm_ctx {
   std::vector<int> assoc_layer, assoc_point_feat;
   std::vector<double> assoc_fix;
   balm::WindowSession *window = nullptr;   // balm_window_*: the sliding-window map (kernels_window.inc)
+  bool window_dead = false;         // a window call failed on the device half-way: the map is in an undefined state until re-opened
   void *d_arena = nullptr;          // balm_associate scratch, grown to what the last call needed
   size_t arena_cap = 0;
   char *d_stage = nullptr;          // per-call staging (uploads, layout changes, covariance work matrices): grown, never
@@ -177,6 +178,11 @@ struct balm_multi {
   const std::function<int(int)> *job = nullptr;
   std::vector<int> rc;
   balm::Barrier *bar = nullptr;
+  // first non-zero status any device thread returned from the current job: the other threads leave their host-side waits
+  // (the scalar hand-over of the LM loop, the loopback barrier) with it instead of waiting for a peer that is gone.  An
+  // RCCL communicator whose peer never enqueued its collective is aborted (ncclCommAbort) and the context is dead.
+  std::atomic<int> abort_rc{0};
+  bool dead = false;
   // LM decision scalars of device 0, per iteration parity
   std::atomic<uint64_t> lm_seq{0};
   uint64_t lm_epoch = 0;
@@ -196,9 +202,11 @@ int comm_init_rank(balm_ctx *ctx, int nranks, int rank, const void *id128);
 void comm_destroy(balm_ctx *ctx);
 const char *rccl_load_error();
 int comm_allreduce(balm_ctx *ctx, double *buf, long n);      // stream-ordered sum over the ranks of ctx->comm
+void comm_query(const balm_ctx *ctx, int *count, int *rank);  // what RCCL reports for ctx->comm
 int loopback_allreduce(balm_ctx *ctx, double *buf, long n);   // shards of one physical device (test transport)
 bool multi_is_loopback(const balm_ctx *ctx);
-void multi_share_scalars(balm_ctx *ctx, int it, double *vals, int count);   // rank 0's LM scalars -> all device threads
+int multi_share_scalars(balm_ctx *ctx, int it, double *vals, int count);    // rank 0's LM scalars -> all device threads; != 0: a peer failed
+void multi_abort(balm_multi *m, int rc);                      // a device thread failed: wake every host-side wait of the job
 int multi_host_barrier_rc(balm_ctx *ctx, int rc);             // all device threads meet; returns the first non-zero rc
 
 // launchers (kernels_solve.hip)

@@ -36,6 +36,9 @@ struct Rccl {
   ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
   ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
+  ncclResult_t (*CommUserRank)(const ncclComm_t, int *) = nullptr;
   const char *(*GetErrorString)(ncclResult_t) = nullptr;
   std::string err;
 };
@@ -55,6 +58,9 @@ const Rccl *rccl() {
     g_rccl.AllReduce = (decltype(g_rccl.AllReduce))sym("ncclAllReduce");
     g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))sym("ncclCommDestroy");
     g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))sym("ncclGetErrorString");
+    g_rccl.CommAbort = (decltype(g_rccl.CommAbort))dlsym(g_rccl.h, "ncclCommAbort");     // optional
+    g_rccl.CommCount = (decltype(g_rccl.CommCount))dlsym(g_rccl.h, "ncclCommCount");
+    g_rccl.CommUserRank = (decltype(g_rccl.CommUserRank))dlsym(g_rccl.h, "ncclCommUserRank");
   });
   return g_rccl.err.empty() ? &g_rccl : nullptr;
 }
@@ -90,6 +96,15 @@ void comm_destroy(balm_ctx *ctx) {
   ctx->comm = nullptr;
 }
 
+// ranks / own rank as the communicator itself reports them (-1: not available)
+void comm_query(const balm_ctx *ctx, int *count, int *rank) {
+  *count = -1; *rank = -1;
+  const Rccl *r = rccl();
+  if (!r || !ctx->comm) return;
+  if (r->CommCount) r->CommCount((ncclComm_t)ctx->comm, count);
+  if (r->CommUserRank) r->CommUserRank((ncclComm_t)ctx->comm, rank);
+}
+
 int comm_allreduce(balm_ctx *ctx, double *buf, long n) {
   const Rccl *r = rccl();
   const ncclResult_t e = r->AllReduce(buf, buf, (size_t)n, ncclDouble, ncclSum, (ncclComm_t)ctx->comm, ctx->stream);
@@ -100,15 +115,40 @@ int comm_allreduce(balm_ctx *ctx, double *buf, long n) {
 // ---- device threads ----------------------------------------------------------------------------------------------
 struct Barrier {
   std::mutex mu; std::condition_variable cv; int n = 1, waiting = 0; uint64_t gen = 0; int rc_acc = 0, rc_out = 0;
-  int arrive(int rc) {          // returns the first non-zero rc any thread brought to this round
+  const std::atomic<int> *abort_rc = nullptr;      // the job's abort status (balm_multi::abort_rc)
+  int arrive(int rc) {          // returns the first non-zero rc any thread brought to this round, or the job's abort status
     std::unique_lock<std::mutex> lk(mu);
     if (rc && !rc_acc) rc_acc = rc;
     const uint64_t g = gen;
     if (++waiting == n) { waiting = 0; rc_out = rc_acc; rc_acc = 0; gen++; cv.notify_all(); return rc_out; }
-    cv.wait(lk, [&] { return gen != g; });
+    cv.wait(lk, [&] { return gen != g || (abort_rc && abort_rc->load(std::memory_order_acquire)); });
+    if (gen == g) {             // a peer left the job with an error and will never arrive: this round is void
+      waiting--;
+      return abort_rc->load(std::memory_order_acquire);
+    }
     return rc_out;
   }
+  void reset() { std::lock_guard<std::mutex> lk(mu); waiting = 0; rc_acc = 0; }
+  void wake() { std::lock_guard<std::mutex> lk(mu); cv.notify_all(); }
 };
+
+// A device thread returned `rc` != 0 from the current job.  Its peers may be waiting for it on the host (the LM loop's
+// scalar hand-over, the loopback barrier) or on the device (an all-reduce it never enqueued): the former are woken with the
+// status, the latter are taken down with their communicators (ncclCommAbort releases the peers' collective kernels); a
+// context that lost its communicators answers BALM_ERR_STATE from then on.
+void multi_abort(balm_multi *m, int rc) {
+  int expected = 0;
+  if (!m->abort_rc.compare_exchange_strong(expected, rc, std::memory_order_acq_rel)) return;
+  m->bar->wake();
+  if (!m->loopback && m->n > 1) {
+    const Rccl *r = rccl();
+    if (r && r->CommAbort) {
+      for (auto *c : m->sub)
+        if (c->comm) { r->CommAbort((ncclComm_t)c->comm); c->comm = nullptr; }
+      m->dead = true;
+    }
+  }
+}
 
 static void worker_main(balm_multi *m, int k) {
   hipSetDevice(m->sub[(size_t)k]->device);
@@ -120,6 +160,7 @@ static void worker_main(balm_multi *m, int k) {
     seen = m->gen;
     lk.unlock();
     const int rc = (*m->job)(k);
+    if (rc) multi_abort(m, rc);
     lk.lock();
     m->rc[(size_t)k] = rc;
     if (--m->pending == 0) m->cv_done.notify_all();
@@ -129,13 +170,17 @@ static void worker_main(balm_multi *m, int k) {
 // f(k) on the thread of device k (k = 0: the calling thread); returns the first non-zero result
 int multi_run(balm_multi *m, const std::function<int(int)> &f) {
   if (m->n == 1) return f(0);
+  if (m->dead) { m->sub[0]->err = "the context lost its communicators when a device failed (ncclCommAbort): destroy it"; return BALM_ERR_STATE; }
   {
     std::lock_guard<std::mutex> lk(m->mu);
+    m->abort_rc.store(0, std::memory_order_release);
+    m->bar->reset();
     m->job = &f; m->pending = m->n - 1; m->gen++; m->lm_epoch++;
   }
   m->cv_go.notify_all();
   hipSetDevice(m->sub[0]->device);
   m->rc[0] = f(0);
+  if (m->rc[0]) multi_abort(m, m->rc[0]);
   {
     std::unique_lock<std::mutex> lk(m->mu);
     m->cv_done.wait(lk, [&] { return m->pending == 0; });
@@ -149,7 +194,7 @@ balm_multi *multi_new(const std::vector<balm_ctx *> &subs, bool loopback, std::s
   balm_multi *m = new balm_multi();
   m->n = (int)subs.size(); m->sub = subs; m->loopback = loopback;
   m->fbeg.assign((size_t)m->n + 1, 0); m->rc.assign((size_t)m->n, 0);
-  m->bar = new Barrier(); m->bar->n = m->n;
+  m->bar = new Barrier(); m->bar->n = m->n; m->bar->abort_rc = &m->abort_rc;
   if (!loopback) {
     const Rccl *r = rccl();
     if (!r) { *err = rccl_load_error(); delete m->bar; delete m; return nullptr; }
@@ -198,17 +243,22 @@ int multi_host_barrier_rc(balm_ctx *ctx, int rc) {
 }
 
 // the LM decision scalars of device 0 reach every device thread (identical by construction; this makes it a guarantee)
-void multi_share_scalars(balm_ctx *ctx, int it, double *vals, int count) {
+int multi_share_scalars(balm_ctx *ctx, int it, double *vals, int count) {
   balm_multi *m = ctx->multi;
-  if (!m || m->n == 1) return;
+  if (!m || m->n == 1) return BALM_OK;
   const uint64_t want = (m->lm_epoch << 24) + (uint64_t)it + 1;
   if (ctx->rank == 0) {
     for (int k = 0; k < count; k++) m->lm_vals[it & 1][k] = vals[k];
     m->lm_seq.store(want, std::memory_order_release);
   } else {
-    while (m->lm_seq.load(std::memory_order_acquire) < want) std::this_thread::yield();
+    while (m->lm_seq.load(std::memory_order_acquire) < want) {
+      // device 0 left the loop with an error (it will never publish this iteration), or another peer failed
+      if (const int a = m->abort_rc.load(std::memory_order_acquire)) { ctx->err = "a peer device of the sharded context failed"; return a; }
+      std::this_thread::yield();
+    }
     for (int k = 0; k < count; k++) vals[k] = m->lm_vals[it & 1][k];
   }
+  return m->abort_rc.load(std::memory_order_acquire);
 }
 
 // ---- loopback transport: sum over the shards' buffers on one physical device ------------------------------------
@@ -241,7 +291,7 @@ int loopback_allreduce(balm_ctx *ctx, double *buf, long n) {
   long grid = (n + 255) / 256; if (grid > 2048) grid = 2048;
   hipLaunchKernelGGL(k_sum_buffers, dim3((unsigned)grid), dim3(256), 0, ctx->stream, bl, m->n, n, m->lb_tmp[(size_t)k]);
   hipEventRecord(m->ev2[(size_t)k], ctx->stream);
-  m->bar->arrive(0);                                                                          // every sum is enqueued
+  if ((rc = m->bar->arrive(0))) { ctx->err = "loopback all-reduce: a peer shard failed"; return rc; }   // every sum is enqueued
   for (int j = 0; j < m->n; j++) hipStreamWaitEvent(ctx->stream, m->ev2[(size_t)j], 0);      // ... and done reading buf
   hipMemcpyAsync(buf, m->lb_tmp[(size_t)k], (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream);
   return BALM_OK;

@@ -61,17 +61,29 @@ class SlidingWindowBA:
         F, feats = ctx.window_features(want_features=self.optimise is not None)
         poses = np.stack(self.est)
         t0 = time.perf_counter()
-        if self.optimise is not None:
+        skipped = None
+        if F == 0:
+            # no plane survived the association: nothing to optimise, but the window must keep sliding
+            out, log, skipped = poses.copy(), np.zeros((0, 8)), "no features"
+        elif self.optimise is not None:
             out, log = self.optimise(feats, poses)
         else:
-            out, log = ctx.damping_iter(poses, form=0, reanchor=False, **self.lm)
+            from . import capi
+            try:
+                out, log = ctx.damping_iter(poses, form=0, reanchor=False, **self.lm)
+            except capi.BalmError as e:
+                # the reference prints its message and stops optimising this window (bavoxel.hpp:1079-1085, there followed by
+                # exit(0)); a stream of scans goes on: keep the odometry-chained poses and slide
+                if e.code != capi.ERR_TOO_FEW_PLANES:
+                    raise
+                out, log, skipped = poses.copy(), np.zeros((0, 8)), "a pose sees fewer than %d planes" % self.lm["min_planes"]
         dt = time.perf_counter() - t0
         ctx.window_marginalize(self.slide, out)
         self.done.extend(out[:self.slide])
         self.est = list(out[self.slide:])
         self.odom = self.odom[self.slide:]
         self.windows += 1
-        return dict(F=F, poses=out, poses_in=poses, log=log, seconds_lm=dt)
+        return dict(F=F, poses=out, poses_in=poses, log=log, seconds_lm=dt, skipped=skipped)
 
     def trajectory(self):
         """every scan pushed so far: left the window (final) or still in it (current estimate)"""
@@ -100,9 +112,9 @@ def main(argv=None):
         r = ba.push(f, p)
         if r is not None:
             lg = r["log"]
-            print("window %3d (scans %d..%d): %5d features, %2d LM iterations, residual %.6g -> %.6g, %.1f ms"
+            print("window %3d (scans %d..%d): %5d features, %2d LM iterations, residual %.6g -> %.6g, %.1f ms%s"
                   % (ba.windows, i - a.window + 1, i, r["F"], len(lg), lg[0, 0] if len(lg) else 0, lg[-1, 1] if len(lg) else 0,
-                     1e3 * r["seconds_lm"]))
+                     1e3 * r["seconds_lm"], "  [not optimised: %s]" % r["skipped"] if r["skipped"] else ""))
     print("%d scans, %d windows in %.2f s" % (len(frames), ba.windows, time.perf_counter() - t0))
     if a.out:
         np.save(a.out, ba.trajectory())

@@ -90,6 +90,12 @@ balm_ctx *balm_create_multi(int win_size, int first_device, int n_devices, int f
  * balm_only_residual / balm_damping_iter / balm_pose_covariance sum over the ranks inside the library. */
 int balm_comm_unique_id(void *id128);
 int balm_comm_init_rank(balm_ctx *ctx, int n_ranks, int rank, const void *id128);
+/* What the transport itself reports, for a run that has to prove it really was N ranks: out[0] = ranks in the
+ * communicator as RCCL counts them (ncclCommCount; the shard count of a loopback context; 1 without a transport),
+ * out[1] = this context's rank (ncclCommUserRank), out[2] = doubles in the all-reduce payload of one Hessian
+ * evaluation ([SYRK tiles | per-pose gradient + block diagonal | residual]), out[3] = transport kind: 0 none,
+ * 1 RCCL in the library, 2 loopback shards, 3 caller's hook. */
+int balm_comm_info(balm_ctx *ctx, long *out4);
 
 /* Replaces F calls of VOX_HESS::push_voxel (bavoxel.hpp:30-51): the shim flattens the borrowed
  * `const vector<PointCluster>*` / `const PointCluster* fix` pointers into these arrays.  Copies to
@@ -230,7 +236,8 @@ enum {
   BALM_T_BUILD = 6,     /* cluster build from points (balm_build_clusters kernel only)        */
   BALM_T_VOXEL = 7,     /* adaptive-voxel association (balm_associate, device part only)      */
   BALM_T_COV = 8,       /* balm_pose_covariance: covariance factors, its two SYRKs, H^-1 R H^-T */
-  BALM_T_COUNT = 9
+  BALM_T_COMM = 9,      /* the all-reduces of the sharded path (stream time: includes waiting for the slowest rank) */
+  BALM_T_COUNT = 10
 };
 int balm_get_timing(balm_ctx *ctx, double *ms, long *count);
 

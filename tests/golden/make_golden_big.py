@@ -34,6 +34,10 @@ from oracle import ref, ref_virtual  # noqa: E402
 CASES = {
     "lm_big_w64_f5000": dict(seed=2025, W=64, F=5000, pts=6),
     "lm_big_w200_f50000": dict(seed=2024, W=200, F=50000, pts=6),      # bench.py's scene
+    # BASELINE configs[3]: the 8-GPU problem (bench.py --gpus N, strong_scaling_reference).  bavoxel flavour only by
+    # default (4 threads, ~6 min here; needs BALM_REF_RECLAIM_LEAKS=1, set below: bavoxel.hpp:312-320 leaks 20 GB per
+    # evaluation at this size); `virtual` (single thread, ~25 min, 240 M points) when asked for: "lm_big_w200_f200000:virtual"
+    "lm_big_w200_f200000": dict(seed=2024, W=200, F=200000, pts=6, flavours=("bavoxel",)),
 }
 
 
@@ -46,23 +50,30 @@ def checksums(sc):
 
 
 def main():
+    os.environ.setdefault("BALM_REF_RECLAIM_LEAKS", "1")        # read once by oracle/compat/Eigen/Core when _ref loads
     ref.build()
-    names = sys.argv[1:] or list(CASES)
+    names = sys.argv[1:] or [n for n in CASES if "flavours" not in CASES[n]]
     for name in names:
+        name, _, extra = name.partition(":")
         c = CASES[name]
-        sc = scene.generate(c["seed"], c["W"], c["F"], c["pts"], mode=1, keep_points=True)
-        out = dict(seed=c["seed"], W=c["W"], F=c["F"], pts=c["pts"], checksums=checksums(sc), poses_gt=sc.poses_gt)
-        t0 = time.time()
-        poses, lg, sec = ref_virtual.damping_iter(sc.points, sc.poses_init)
-        out["lm_poses_virtual"], out["lm_log_virtual"], out["seconds_virtual"] = poses, lg, sec
-        print(name, "virtual: %d iterations, %.1f s (%.1f s wall)" % (len(lg), sec, time.time() - t0), flush=True)
-        print(lg[:, :3], flush=True)
-        t0 = time.time()
-        poses, lg = ref.damping_iter(sc.clusters, None, sc.coeffs, sc.poses_init)
-        out["lm_poses_bavoxel"], out["lm_log_bavoxel"], out["seconds_bavoxel"] = poses, lg, time.time() - t0
-        print(name, "bavoxel: %d iterations, %.1f s" % (len(lg), time.time() - t0), flush=True)
-        print(lg[:, :3], flush=True)
-        np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+        flavours = tuple(c.get("flavours", ("virtual", "bavoxel"))) + ((extra,) if extra else ())
+        path = os.path.join(HERE, name + ".npz")
+        sc = scene.generate(c["seed"], c["W"], c["F"], c["pts"], mode=1, keep_points="virtual" in flavours)
+        out = dict(np.load(path)) if os.path.exists(path) and extra else {}
+        out.update(seed=c["seed"], W=c["W"], F=c["F"], pts=c["pts"], checksums=checksums(sc), poses_gt=sc.poses_gt)
+        if "virtual" in flavours:
+            t0 = time.time()
+            poses, lg, sec = ref_virtual.damping_iter(sc.points, sc.poses_init)
+            out["lm_poses_virtual"], out["lm_log_virtual"], out["seconds_virtual"] = poses, lg, sec
+            print(name, "virtual: %d iterations, %.1f s (%.1f s wall)" % (len(lg), sec, time.time() - t0), flush=True)
+            print(lg[:, :3], flush=True)
+        if "bavoxel" in flavours and not (extra and "lm_poses_bavoxel" in out):
+            t0 = time.time()
+            poses, lg = ref.damping_iter(sc.clusters, None, sc.coeffs, sc.poses_init)
+            out["lm_poses_bavoxel"], out["lm_log_bavoxel"], out["seconds_bavoxel"] = poses, lg, time.time() - t0
+            print(name, "bavoxel: %d iterations, %.1f s" % (len(lg), time.time() - t0), flush=True)
+            print(lg[:, :3], flush=True)
+        np.savez_compressed(path, **out)
 
 
 if __name__ == "__main__":

@@ -122,3 +122,25 @@ def test_cpp_virtual_driver_with_n_devices_goes_through_rccl():
                        cwd=root, capture_output=True, text=True, timeout=600, env=env)
     line = [l for l in p.stdout.splitlines() if l.startswith("SHIM_VIRTUAL")]
     assert p.returncode == 0 and line and "multi=1" in line[0], (p.returncode, p.stdout[-800:], p.stderr[-800:])
+
+
+@pytest.mark.parametrize("fault", ["0,1", "2,0", "1,2"])
+def test_a_failing_device_thread_takes_its_peers_out_instead_of_hanging(fault):
+    """an error on one device thread of a sharded context used to leave the others spinning in the LM loop's
+    scalar hand-over or in the loopback barrier forever.  A fault is injected on one shard at one iteration: the call
+    must come back with that error, and the (loopback) context must stay usable."""
+    import os
+    sc, _ = make_scene(5, 24, 120, 6)
+    c = capi.Context(sc.W, 0, capi.FLAG_LOOPBACK_SHARDS, n_devices=3)
+    c.set_features(sc.clusters, None, sc.coeffs)
+    ref, lref = c.damping_iter(sc.poses_init, u0=0.1, max_iter=6)
+    os.environ["BALM_FAULT_INJECT"] = fault
+    try:
+        with pytest.raises(capi.BalmError) as e:
+            c.damping_iter(sc.poses_init, u0=0.1, max_iter=6)
+        assert e.value.code == capi.ERR_HIP
+    finally:
+        os.environ.pop("BALM_FAULT_INJECT")
+    out, lg = c.damping_iter(sc.poses_init, u0=0.1, max_iter=6)            # the next job starts clean
+    assert np.array_equal(out, ref) and np.array_equal(lg, lref)
+    c.close()

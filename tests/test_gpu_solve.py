@@ -102,3 +102,63 @@ def test_lookahead_launch_path(W):
     finally:
         os.environ.pop("BALM_SOLVE"); os.environ.pop("BALM_LOOKAHEAD", None)
     c.close()
+
+
+def _test_matrix(W, kind, seed):
+    rng = np.random.default_rng(seed)
+    n = 6 * W
+    B = rng.standard_normal((n, 96))
+    H = B @ B.T / 96 + np.diag(rng.uniform(0.5, 50.0, n))
+    if kind == "indefinite":
+        s = np.where(rng.uniform(size=n) < 0.2, -1.0, 1.0)
+        H = (H * s[:, None]) * s[None, :]
+        H[np.diag_indices(n)] *= s
+    return H, rng.standard_normal(n)
+
+
+@pytest.mark.parametrize("W", [350, 400, 500, 700, 1024])
+@pytest.mark.parametrize("kind", ["spd", "indefinite"])
+def test_large_window_paths_match_lapack(W, kind):
+    """An INDEPENDENT comparator for the factorisation paths windows above 320 poses take (BASELINE configs[4] names
+    W = 500): the launch path with lookahead (k_ldl_panel_trail, their default), the plain launch pair and the persistent
+    kernel are each compared with LAPACK (numpy.linalg.solve of the damped system, bavoxel.hpp:1113-1114), not with one
+    another; then with one another to rounding."""
+    H, g = _test_matrix(W, kind, 1000 + W + (kind == "spd"))
+    u = 0.1
+    ref = np.linalg.solve(H + u * np.diag(np.diag(H)), -g)
+    q1_ref = 0.5 * ref @ (u * np.diag(H) * ref - g)              # bavoxel.hpp:1127
+    c = capi.Context(W)
+    got = {}
+    try:
+        dx, q1 = c.solve_damped(H, g, u)                         # the default for this window size
+        got["default"] = dx
+        assert rel_err(dx, ref) < 1e-9 and abs(q1 - q1_ref) <= 1e-9 * abs(q1_ref), ("default", rel_err(dx, ref))
+        for mode, la in (("launches", "1"), ("launches", "0"), ("fused", None)):
+            os.environ["BALM_SOLVE"] = mode
+            if la is not None:
+                os.environ["BALM_LOOKAHEAD"] = la
+            dx, q1 = c.solve_damped(H, g, u)
+            os.environ.pop("BALM_LOOKAHEAD", None)
+            got[mode + (la or "")] = dx
+            assert rel_err(dx, ref) < 1e-9 and abs(q1 - q1_ref) <= 1e-9 * abs(q1_ref), (mode, la, rel_err(dx, ref))
+    finally:
+        os.environ.pop("BALM_SOLVE", None); os.environ.pop("BALM_LOOKAHEAD", None)
+    for k, v in got.items():
+        assert rel_err(v, got["default"]) < 1e-10, k
+    c.close()
+
+
+def test_large_window_solve_of_an_lm_hessian_matches_lapack():
+    """the same at W = 500 on a Hessian of the path itself (sparse co-visibility, indefinite at the noisy start): residual
+    of the damped system and LAPACK's solution"""
+    sc, _ = make_scene(77, 500, 600, 6, drop=0.5)
+    c = capi.Context(sc.W)
+    c.set_features(sc.clusters, None, sc.coeffs)
+    H, g, _ = c.evaluate(0, sc.poses_init)
+    for u in (0.01, 0.1):
+        A = H + u * np.diag(np.diag(H))
+        ref = np.linalg.solve(A, -g)
+        dx, _ = c.solve_damped(H, g, u)
+        assert np.linalg.norm(A @ dx + g) / np.linalg.norm(g) < 1e-8
+        assert rel_err(dx, ref) < 1e-7
+    c.close()

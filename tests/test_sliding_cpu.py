@@ -83,3 +83,41 @@ def test_sliding_window_bookkeeping():
     # y of every scan = 0.5 per optimisation it sat in, on top of what its pose guess inherited from its predecessor:
     # scans 0, 1: one window; 2, 3: two; 4, 5: guess at 0.5 + two windows; 6, 7: guess at 1.0 + one window so far; 8: guess at 1.5
     assert np.allclose(traj[:, 10], [0.5, 0.5, 1.0, 1.0, 1.5, 1.5, 1.5, 1.5, 1.5])
+
+
+def test_a_window_that_cannot_be_optimised_still_slides():
+    """damping_iter raising for 'no features' / the 20-planes precheck used to leave the device window full, so
+    that every later push failed with 'window full'.  The window is reported as skipped and marginalised with the
+    odometry-chained poses, as a stream of scans needs (the reference prints its message and stops, bavoxel.hpp:1079-1085)."""
+    from balm_amd import capi
+
+    class Starved(FakeContext):
+        def __init__(self, W):
+            super().__init__(W)
+            self.windows = 0
+
+        def window_features(self, want_features=True):
+            self.windows += 1
+            return (0 if self.windows == 2 else 42), None
+
+        def damping_iter(self, poses, **kw):
+            if self.windows == 1:
+                raise capi.BalmError(capi.ERR_TOO_FEW_PLANES, "Initial error too large.")
+            return super().damping_iter(poses, **kw)
+
+    W, slide = 4, 2
+    ctx = Starved(W)
+    ba = SlidingWindowBA(ctx, slide)
+    ident = np.array([1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0], dtype=float)
+    out = []
+    for i in range(8):
+        p = ident.copy(); p[9] = i
+        r = ba.push(np.full((5, 3), i, np.float32), p)
+        if r is not None:
+            out.append(r)
+    assert [r["skipped"] is not None for r in out] == [True, True, False]
+    assert "planes" in out[0]["skipped"] and out[1]["skipped"] == "no features"
+    assert np.array_equal(out[0]["poses"], out[0]["poses_in"]) and len(out[0]["log"]) == 0
+    margs = [c for c in ctx.calls if c[0] == "marg"]
+    assert len(margs) == 3                      # every window slid, optimised or not
+    assert np.allclose(out[2]["poses"][:, 10], 0.5)

@@ -29,7 +29,8 @@ for k in ("k_hessian_syrk", "k_feature_factors", "k_world_moments", "k_ldl_fused
     if r.get("SQ_BUSY_CU_CYCLES") and float(r["SQ_BUSY_CU_CYCLES"]) > 0:
         e["mfma_busy_frac"] = float(r.get("SQ_VALU_MFMA_BUSY_CYCLES") or 0) / float(r["SQ_BUSY_CU_CYCLES"]) / 4.0
     if r.get("GRBM_GUI_ACTIVE"):
-        e["clock_ghz_under_pmc"] = float(r["GRBM_GUI_ACTIVE"]) / float(r["dur_ns"])
+        # GRBM_GUI_ACTIVE comes out summed over the 8 XCDs of the device: per-XCD cycles / duration = the clock
+        e["clock_ghz_under_pmc"] = float(r["GRBM_GUI_ACTIVE"]) / 8.0 / float(r["dur_ns"])
     if k in alg:
         e["algorithmic_bytes"] = alg[k]
     out[k] = e
