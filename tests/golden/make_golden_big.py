@@ -34,10 +34,16 @@ from oracle import ref, ref_virtual  # noqa: E402
 CASES = {
     "lm_big_w64_f5000": dict(seed=2025, W=64, F=5000, pts=6),
     "lm_big_w200_f50000": dict(seed=2024, W=200, F=50000, pts=6),      # bench.py's scene
-    # BASELINE configs[3]: the 8-GPU problem (bench.py --gpus N, strong_scaling_reference).  bavoxel flavour only by
+    # BASELINE configs[3]: the 8-GPU problem -- the SAME global scene bench.py --gpus N shards (seed 2024, mode 1: feature a
+    # has its own engine, so rank r's shard is features [r F/N, (r+1) F/N) of this table) and its strong_scaling_reference.  bavoxel flavour only by
     # default (4 threads, ~6 min here; needs BALM_REF_RECLAIM_LEAKS=1, set below: bavoxel.hpp:312-320 leaks 20 GB per
     # evaluation at this size); `virtual` (single thread, ~25 min, 240 M points) when asked for: "lm_big_w200_f200000:virtual"
     "lm_big_w200_f200000": dict(seed=2024, W=200, F=200000, pts=6, flavours=("bavoxel",)),
+    # BASELINE configs[4] names a 500-pose window: the factorisation path of windows above 320 poses (launches with
+    # lookahead) under an LM run with sparse co-visibility.  `bavoxel` = the reference's optimizer (u0 = 0.01, 10 it.);
+    # `oracle_u01` = the oracle's LM loop with benchmark_virtual.cpp's constants (u0 = 0.1, 20 it.; the reference's own
+    # dampingIter(x_stats, plSurfs) builds dense clusters from clouds and cannot take a sparse table)
+    "lm_big_sparse_w500_f2000": dict(seed=31, W=500, F=2000, pts=6, drop=0.5, flavours=("bavoxel", "oracle_u01")),
 }
 
 
@@ -59,8 +65,10 @@ def main():
         flavours = tuple(c.get("flavours", ("virtual", "bavoxel"))) + ((extra,) if extra else ())
         path = os.path.join(HERE, name + ".npz")
         sc = scene.generate(c["seed"], c["W"], c["F"], c["pts"], mode=1, keep_points="virtual" in flavours)
+        if c.get("drop"):
+            scene.sparsify(sc, c["seed"] + 100, c["drop"])          # as tests/util.make_scene
         out = dict(np.load(path)) if os.path.exists(path) and extra else {}
-        out.update(seed=c["seed"], W=c["W"], F=c["F"], pts=c["pts"], checksums=checksums(sc), poses_gt=sc.poses_gt)
+        out.update(seed=c["seed"], W=c["W"], F=c["F"], pts=c["pts"], drop=c.get("drop", 0.0), checksums=checksums(sc), poses_gt=sc.poses_gt)
         if "virtual" in flavours:
             t0 = time.time()
             poses, lg, sec = ref_virtual.damping_iter(sc.points, sc.poses_init)
@@ -72,6 +80,13 @@ def main():
             poses, lg = ref.damping_iter(sc.clusters, None, sc.coeffs, sc.poses_init)
             out["lm_poses_bavoxel"], out["lm_log_bavoxel"], out["seconds_bavoxel"] = poses, lg, time.time() - t0
             print(name, "bavoxel: %d iterations, %.1f s" % (len(lg), time.time() - t0), flush=True)
+            print(lg[:, :3], flush=True)
+        if "oracle_u01" in flavours:
+            from oracle import orc
+            t0 = time.time()
+            poses, lg = orc.damping_iter(0, sc.clusters, None, sc.coeffs, sc.poses_init, 0.1, 20, threads=8)
+            out["lm_poses_oracle_u01"], out["lm_log_oracle_u01"], out["seconds_oracle_u01"] = poses, lg, time.time() - t0
+            print(name, "oracle (u0 = 0.1, <= 20 it.): %d iterations, %.1f s" % (len(lg), time.time() - t0), flush=True)
             print(lg[:, :3], flush=True)
         np.savez_compressed(path, **out)
 

@@ -142,6 +142,8 @@ LM_CASES = [
     (1, 20, 20, 40, 0.0, 1, 0.1, 20),     # right form
     (6, 30, 150, 10, 0.4, 0, 0.01, 10),   # sparse co-visibility
     (7, 64, 400, 6, 0.0, 0, 0.1, 20),     # configs[1] shape
+    (8, 64, 400, 6, 0.0, 1, 0.1, 20),     # right form at configs[1]'s window (acc_evaluate2 + the right update, bavoxel.hpp:1119-1120)
+    (9, 96, 300, 6, 0.3, 1, 0.01, 10),    # right form, sparse co-visibility, bavoxel constants
 ]
 
 
