@@ -225,6 +225,50 @@ def test_build_clusters_matches_push():
     c.close()
 
 
+@pytest.mark.parametrize("terms", ["0", "1"])
+@pytest.mark.parametrize("W,F,pts", [(6, 9, 40), (200, 30, 40), (5, 7, 150), (3, 4, 700), (2, 3, 2500), (7, 11, 6), (9, 5, 24)])
+def test_build_clusters_long_runs_both_lane_mappings(W, F, pts, terms):
+    """N1 with runs of 6 .. 2500 points per (feature, pose) -- the launch default is 40 (benchmark_virtual.launch:4-9) -- through
+    both lane mappings of k_build_clusters_runs (one lane per run / one lane per (run, term column)) and through the
+    continuation paths of a run that leaves its block (staged 64 points / chunked): bit-identical to PointCluster::push"""
+    import os
+    sc = scene.generate(60 + pts, W, F, pts, keep_points=True)
+    xyz = sc.points.reshape(-1, 3)
+    fid = np.repeat(np.arange(F, dtype=np.int32), W * pts)
+    pid = np.tile(np.repeat(np.arange(W, dtype=np.int32), pts), F)
+    c = capi.Context(W)
+    os.environ["BALM_BUILD_TERMS"] = terms
+    try:
+        for bp in ("256", "512", ""):
+            if bp:
+                os.environ["BALM_BUILD_BP"] = bp
+            else:
+                os.environ.pop("BALM_BUILD_BP", None)
+            got = c.build_clusters(F, xyz, fid, pid, None, sc.coeffs)
+            assert np.array_equal(got, sc.clusters), (bp, np.abs(got - sc.clusters).max())
+        # ragged runs: drop a prefix of every run's points (lengths 1 .. pts), keys stay grouped
+        rng = np.random.default_rng(pts)
+        keep = np.ones(xyz.shape[0], bool)
+        for k in range(F * W):
+            keep[k * pts: k * pts + int(rng.integers(0, pts))] = False
+        got = c.build_clusters(F, xyz[keep], fid[keep], pid[keep], None, sc.coeffs)
+        ref = np.zeros_like(sc.clusters)
+        P = sc.points.reshape(F, W, pts, 3).astype(np.float64)
+        K = keep.reshape(F, W, pts)
+        for a in range(F):
+            for i in range(W):
+                acc = np.zeros(10)
+                for q in P[a, i][K[a, i]]:       # the reference's push: one rounding per operation, in order
+                    acc[:6] += np.array([q[0] * q[0], q[0] * q[1], q[0] * q[2], q[1] * q[1], q[1] * q[2], q[2] * q[2]])
+                    acc[6:9] += q
+                    acc[9] += 1
+                ref[a, i] = acc
+        assert np.array_equal(got, ref)
+    finally:
+        os.environ.pop("BALM_BUILD_TERMS", None); os.environ.pop("BALM_BUILD_BP", None)
+    c.close()
+
+
 def test_timing_slots_fill_when_enabled():
     sc, _ = make_scene(60, 20, 40, 6)
     c = ctx_for(sc, flags=capi.FLAG_TIMING)
