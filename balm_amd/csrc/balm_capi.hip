@@ -349,7 +349,7 @@ balm_ctx *balm_create(int win_size, int device, int flags) {
       dalloc(ctx, &ctx->d_H, (size_t)n * n) || dalloc(ctx, &ctx->d_g, (size_t)n) ||
       dalloc(ctx, &ctx->d_A, (size_t)(2 * nA + NB) * nA) || dalloc(ctx, &ctx->d_Wp, (size_t)2 * NB * (2 * nA + NB)) ||
       dalloc(ctx, &ctx->d_dvec, (size_t)nA) || dalloc(ctx, &ctx->d_z, (size_t)nA) || dalloc(ctx, &ctx->d_x, (size_t)16 * nA) ||
-      dalloc(ctx, &ctx->d_perm, (size_t)nA) || dalloc(ctx, &ctx->d_flags, (size_t)2 * (2 * (nA / NB) + 1) * (nA / NB)) || dalloc(ctx, &ctx->d_dx, (size_t)n) ||
+      dalloc(ctx, &ctx->d_perm, (size_t)nA) || dalloc(ctx, &ctx->d_flags, (size_t)2 * (2 * (nA / NB) + 1) * (nA / NB) + (nA / NB) + 8) || dalloc(ctx, &ctx->d_minv, (size_t)(nA / NB) * NB * NB) || dalloc(ctx, &ctx->d_dx, (size_t)n) ||
       dalloc(ctx, &ctx->d_scal, (size_t)16) || dalloc(ctx, &ctx->d_pre, (size_t)W + 2))
     return fail();
   if (hipHostMalloc((void **)&ctx->h_scal, (16 + 64) * sizeof(double)) != hipSuccess) return fail();
@@ -380,7 +380,7 @@ static void one_destroy(balm_ctx *ctx) {
   if (ctx->window) { window_close(ctx->window); ctx->window = nullptr; }
   void *ptrs[] = {ctx->d_cl, ctx->d_fix, ctx->d_coe, ctx->d_poses, ctx->d_poses_tmp, ctx->d_C, ctx->d_feat,
                   ctx->d_Gt, ctx->d_part, ctx->d_dpart, ctx->d_rpart, ctx->d_feat_tmp, ctx->d_rpart_tmp, ctx->d_red, ctx->d_jobs, ctx->d_sub, ctx->d_H,
-                  ctx->d_g, ctx->d_A, ctx->d_Wp, ctx->d_dvec, ctx->d_z, ctx->d_x, ctx->d_perm, ctx->d_dx, ctx->d_scal, ctx->d_arena, ctx->d_pre, ctx->d_flags, ctx->d_trace, ctx->d_slot, ctx->d_items, ctx->d_csr, ctx->d_chunk_ids, ctx->d_stage};
+                  ctx->d_g, ctx->d_A, ctx->d_Wp, ctx->d_dvec, ctx->d_z, ctx->d_x, ctx->d_perm, ctx->d_dx, ctx->d_scal, ctx->d_arena, ctx->d_pre, ctx->d_flags, ctx->d_minv, ctx->d_trace, ctx->d_slot, ctx->d_items, ctx->d_csr, ctx->d_chunk_ids, ctx->d_stage};
   for (void *p : ptrs) if (p) hipFree(p);
   if (ctx->h_scal) hipHostFree(ctx->h_scal);
   for (auto &sp : ctx->timer.pending) { hipEventDestroy(sp.a); hipEventDestroy(sp.b); }

@@ -98,9 +98,11 @@ struct balm_ctx {
   double *d_z = nullptr;            // [nA] z = D^+ L^-1 P b, then scratch of the backward sweep
   double *d_x = nullptr;            // [16][nA] column-chunk partials of the solution in permuted order
   int *d_perm = nullptr;            // [nA] position -> original index
-  int *d_flags = nullptr;           // [2][2P+1][P] done / far flags of k_ldl_fused (zeroed by k_build_A)
+  int *d_flags = nullptr;           // [2][2P+1][P] done / far flags of k_ldl_fused / k_ldl_chain, + [P] minv flags + abort (zeroed by k_build_A)
   long long *d_trace = nullptr;     // BALM_SOLVE_TRACE=1: [2P+1][P][6] phase timestamps of the last k_ldl_fused (diagnostics)
   int fused_cap = -1;               // co-resident workgroups of k_ldl_fused on this device (-1 = not asked yet, 0 = unavailable)
+  int chain_cap = -1;               // ... of k_ldl_chain
+  double *d_minv = nullptr;         // [P][48][48] Minv_p = L11^-T D11^-1 of every panel (k_ldl_chain)
   double *d_dx = nullptr;           // [n]
   double *d_scal = nullptr;         // [16] device scalars: 0 r1, 1 r2, 2 q1, 3 flags
   double *h_scal = nullptr;         // pinned mirror (16) + a ring of damping values on their way to d_scal[SCAL_U] (64)

@@ -664,8 +664,10 @@ __global__ __launch_bounds__(256) void k_ldl_apply(const double *__restrict__ A,
 __global__ __launch_bounds__(1024) void k_ldl_finish(const double *__restrict__ x, int nA, int n,
                                                      const int *__restrict__ perm, const double *__restrict__ H,
                                                      const double *__restrict__ g, const double *__restrict__ pu,
-                                                     double *__restrict__ dx, double *__restrict__ scal) {
+                                                     double *__restrict__ dx, double *__restrict__ scal, const int *__restrict__ abort_flag) {
   const double u = *pu;
+  // a persistent factorisation that gave up on a flag (k_ldl_chain's bounded waits) must not pass for a solution
+  const double poison = *abort_flag ? __longlong_as_double(0x7ff8000000000000ll) : 0.0;
   __shared__ double red[1024];
   const int tid = threadIdx.x;
   double q = 0.0;
@@ -675,6 +677,7 @@ __global__ __launch_bounds__(1024) void k_ldl_finish(const double *__restrict__ 
       double xv = 0.0;
 #pragma unroll
       for (int k = 0; k < APPLY_CHUNKS; k++) xv += x[(size_t)k * nA + r];       // partial products of k_ldl_apply
+      xv += poison;
       dx[p] = xv;
       q += xv * (u * H[(size_t)p * n + p] * xv - g[p]);
     }
@@ -687,6 +690,8 @@ __global__ __launch_bounds__(1024) void k_ldl_finish(const double *__restrict__ 
   }
   if (tid == 0) scal[2] = 0.5 * red[0];
 }
+
+#include "kernels_chain.inc"
 
 // Co-resident workgroups of k_ldl_fused on the current device (0 = the cooperative launch is not available).
 static int fused_capacity(size_t lds_bytes) {
@@ -704,22 +709,38 @@ static int fused_capacity(size_t lds_bytes) {
 // (and on a device that refuses the cooperative launch).  BALM_SOLVE=launches / fused forces one of them (A/B runs, tests).
 constexpr int FUSED_MAX_P = 40;              // the persistent kernel wins for 18 <= P <= 40 panels (profiles/r02k_solve_paths_by_window.txt)
 
+// Which persistent kernel: BALM_SOLVE=chain forces k_ldl_chain (round 3), =fused k_ldl_fused (round 2).  Default: k_ldl_chain
+// wherever a persistent kernel is the choice at all -- it beats k_ldl_fused at every size (profiles/r03d_solve_paths_by_window.txt:
+// n = 1200: 0.283 vs 0.428 ms) and the launch path from 5 to 40 panels (n = 240: 0.086 vs 0.089, n = 1920: 0.73 vs 0.84).
+constexpr int CHAIN_MIN_P = 5, CHAIN_MAX_P = 40;
+static bool solve_wants_chain(const balm_ctx *c, const char *mode) {
+  if (mode && !strcmp(mode, "chain")) return true;
+  if (mode && !strcmp(mode, "fused")) return false;
+  return c->chain_cap != 0;
+}
+
 bool solve_is_persistent(const balm_ctx *c) {
   const int P = c->nA / NB;
-  const char *mode = getenv("BALM_SOLVE");              // A/B: "launches" / "fused" force one path
-  const bool forced = mode && !strcmp(mode, "fused");
+  const char *mode = getenv("BALM_SOLVE");              // A/B: "launches" / "fused" / "chain" force one path
+  const bool forced = mode && (!strcmp(mode, "fused") || !strcmp(mode, "chain"));
   // Not from the device threads of an in-process multi-device context: a cooperative launch issued by a thread other than
   // the process's first leaves this runtime (ROCm 7.2) in a state that segfaults at process exit (tools/exp_crash.py:
   // exit code 139 after a correct run; launches path: 0).  Those replicas take the launch path with lookahead (+6 % per
   // solve at n = 1200); one process per GPU (balm_comm_init_rank) is not affected.
   if (c->multi && c->multi->n > 1) return false;
-  return !(mode && !strcmp(mode, "launches")) && P >= 2 && (forced || (P >= 18 && P <= FUSED_MAX_P)) && c->fused_cap != 0;
+  if (mode && !strcmp(mode, "launches")) return false;
+  if (forced) return P >= 2 && (c->fused_cap != 0 || c->chain_cap != 0);
+  return (P >= CHAIN_MIN_P && P <= CHAIN_MAX_P && c->chain_cap != 0) || (P >= 18 && P <= FUSED_MAX_P && c->fused_cap != 0);
 }
 
 static void launch_factor(balm_ctx *c) {
   hipStream_t s = c->stream;
   const int nA = c->nA, P = nA / NB;
   const bool want_fused = solve_is_persistent(c);
+  {
+    const char *mode = getenv("BALM_SOLVE");
+    if (want_fused && solve_wants_chain(c, mode) && launch_factor_chain(c)) return;
+  }
   if (want_fused) {
     const size_t lds = (size_t)(12 * FLR + 2 * NB * NB + NB) * sizeof(double);
     if (c->fused_cap < 0) c->fused_cap = fused_capacity(lds);
@@ -788,12 +809,15 @@ void launch_solve(balm_ctx *c, bool new_hessian) {      // damping u = c->d_scal
     if (grid > 4096) grid = 4096;
     const int P = nA / NB;
     hipLaunchKernelGGL(k_build_A, dim3(grid), dim3(256), 0, s, c->d_H, c->d_g, n, nA, c->d_perm, c->d_scal + SCAL_U, c->d_A, c->d_flags,
-                       2 * (2 * P + 1) * P);
+                       2 * (2 * P + 1) * P + P + 8);
   }
   launch_factor(c);
   hipLaunchKernelGGL(k_ldl_apply, dim3((nA + 63) / 64, APPLY_CHUNKS), dim3(256), 0, s, c->d_A, nA, c->d_dvec, c->d_z, c->d_x);
-  hipLaunchKernelGGL(k_ldl_finish, dim3(1), dim3(1024), 0, s, c->d_x, nA, n, c->d_perm, c->d_H, c->d_g, c->d_scal + SCAL_U, c->d_dx,
-                     c->d_scal);
+  {
+    const int P = nA / NB;
+    hipLaunchKernelGGL(k_ldl_finish, dim3(1), dim3(1024), 0, s, c->d_x, nA, n, c->d_perm, c->d_H, c->d_g, c->d_scal + SCAL_U, c->d_dx,
+                       c->d_scal, c->d_flags + (size_t)2 * (2 * P + 1) * P + P);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -162,3 +162,41 @@ def test_large_window_solve_of_an_lm_hessian_matches_lapack():
         assert np.linalg.norm(A @ dx + g) / np.linalg.norm(g) < 1e-8
         assert rel_err(dx, ref) < 1e-7
     c.close()
+
+
+@pytest.mark.parametrize("W", [8, 9, 16, 17, 24, 33, 48, 64, 100, 144, 177, 200, 256, 320, 400, 500])
+@pytest.mark.parametrize("kind", ["spd", "indefinite"])
+def test_chain_kernel_matches_lapack(W, kind):
+    """k_ldl_chain (round 3: one workgroup owns the diagonal, everybody else's rows are one product with Minv = L11^-T D11^-1)
+    against LAPACK and against the launch path, solve after solve (flags are re-zeroed per solve)"""
+    H, g = _test_matrix(W, kind, 77 * W + (kind == "spd"))
+    u = 0.1
+    ref = np.linalg.solve(H + u * np.diag(np.diag(H)), -g)
+    c = capi.Context(W)
+    os.environ["BALM_SOLVE"] = "chain"
+    try:
+        for _ in range(3):
+            dx, q1 = c.solve_damped(H, g, u)
+            assert np.all(np.isfinite(dx)), "k_ldl_chain gave up on a flag (bounded waits) or was not launched"
+            assert rel_err(dx, ref) < 1e-9
+        os.environ["BALM_SOLVE"] = "launches"
+        dx0, q0 = c.solve_damped(H, g, u)
+        assert rel_err(dx, dx0) < 1e-10 and abs(q1 - q0) <= 1e-10 * abs(q0)
+    finally:
+        os.environ.pop("BALM_SOLVE", None)
+    c.close()
+
+
+def test_chain_kernel_lm_run_and_real_hessian():
+    sc, _ = make_scene(23, 64, 600, 8, drop=0.3)
+    c = capi.Context(sc.W)
+    c.set_features(sc.clusters, None, sc.coeffs)
+    os.environ["BALM_SOLVE"] = "launches"
+    try:
+        pa, la = c.damping_iter(sc.poses_init, u0=0.01, max_iter=10)
+        os.environ["BALM_SOLVE"] = "chain"
+        pb, lb = c.damping_iter(sc.poses_init, u0=0.01, max_iter=10)
+    finally:
+        os.environ.pop("BALM_SOLVE", None)
+    assert len(la) == len(lb) and np.allclose(la[:, :3], lb[:, :3], rtol=1e-9, atol=0) and np.abs(pa - pb).max() < 1e-10
+    c.close()

@@ -9,7 +9,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from balm_amd import capi  # noqa: E402
 
-Ws = [int(a) for a in sys.argv[1:]] or [20, 64, 100, 177, 200, 300, 480, 700, 1024]
+Ws = [int(a) for a in sys.argv[1:]] or [20, 32, 40, 64, 100, 128, 144, 177, 200, 256, 300, 320, 350, 400, 480, 500, 700, 1024]
 for W in Ws:
     n = 6 * W
     rng = np.random.default_rng(W)
@@ -18,8 +18,8 @@ for W in Ws:
     g = rng.standard_normal(n)
     c = capi.Context(W, 0, capi.FLAG_TIMING)
     row = []
-    for mode in ("launches", "lookahead", "fused"):
-        os.environ["BALM_SOLVE"] = "fused" if mode == "fused" else "launches"
+    for mode in ("launches", "lookahead", "fused", "chain"):
+        os.environ["BALM_SOLVE"] = mode if mode in ("fused", "chain") else "launches"
         os.environ["BALM_LOOKAHEAD"] = "1" if mode == "lookahead" else "0"
         for _ in range(3):
             dx, _ = c.solve_damped(H, g, 0.1)
@@ -30,7 +30,15 @@ for W in Ws:
         row.append(ms / cnt)
     ref = np.linalg.solve(H + 0.1 * np.diag(np.diag(H)), -g)
     err = np.abs(dx - ref).max() / np.abs(ref).max()
-    print("W=%4d n=%5d  launches %.3f ms   + lookahead %.3f ms   fused %.3f ms   err %.1e" % (W, n, row[0], row[1], row[2], err), flush=True)
+    os.environ.pop("BALM_SOLVE", None); os.environ.pop("BALM_LOOKAHEAD", None)
+    for _ in range(3):
+        dx, _ = c.solve_damped(H, g, 0.1)
+    c.reset_timing()
+    for _ in range(10):
+        dx, _ = c.solve_damped(H, g, 0.1)
+    ms, cnt = c.timing()["solve"]
+    print("W=%4d n=%5d  launches %.3f ms   + lookahead %.3f ms   fused (r2) %.3f ms   chain (r3) %.3f ms   default %.3f ms   err %.1e"
+          % (W, n, row[0], row[1], row[2], row[3], ms / cnt, err), flush=True)
     c.close()
 
 if os.environ.get("BALM_SOLVE_TRACE"):
