@@ -21,7 +21,7 @@ TIMING_NAMES = ["moments", "factors", "syrk", "assemble", "solve", "update", "bu
 # every symbol include/balm_hip.h declares
 EXPORTS = ["balm_create", "balm_create_multi", "balm_destroy", "balm_set_features", "balm_evaluate", "balm_only_residual",
            "balm_solve_damped", "balm_damping_iter", "balm_build_clusters", "balm_voxel_defaults", "balm_associate", "balm_get_features", "balm_get_association", "balm_pose_covariance",
-           "balm_window_open", "balm_window_add_scan", "balm_window_features", "balm_window_marginalize", "balm_window_info", "balm_window_close",
+           "balm_window_open", "balm_window_add_scan", "balm_window_recut", "balm_window_get_points", "balm_window_features", "balm_window_marginalize", "balm_window_info", "balm_window_close",
            "balm_set_allreduce", "balm_comm_unique_id", "balm_comm_init_rank", "balm_comm_info",
            "balm_get_timing", "balm_get_solve_trace", "balm_reset_timing", "balm_work_model", "balm_last_error", "balm_version"]
 
@@ -40,7 +40,8 @@ class LMOpts(C.Structure):
 class VoxelOpts(C.Structure):
     _fields_ = [("voxel_size", C.c_double), ("eigen_thr", C.c_float * 3), ("min_ps", C.c_int), ("layer_limit", C.c_int),
                 ("min_observers", C.c_int), ("fix_frames", C.c_int), ("max_plane_dist", C.c_double),
-                ("max_lambda21", C.c_double), ("max_lambda0", C.c_double), ("want_point_features", C.c_int)]
+                ("max_lambda21", C.c_double), ("max_lambda0", C.c_double), ("want_point_features", C.c_int),
+                ("fix_point_limit", C.c_int), ("defer_recut", C.c_int)]
 
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_long, C.c_void_p)
@@ -79,6 +80,8 @@ def lib():
                                           C.c_void_p, C.c_void_p, C.c_void_p]
         L.balm_window_open.argtypes = [C.c_void_p, C.POINTER(VoxelOpts)]
         L.balm_window_add_scan.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_void_p]
+        L.balm_window_recut.argtypes = [C.c_void_p]
+        L.balm_window_get_points.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_void_p]
         L.balm_window_features.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
         L.balm_window_marginalize.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.balm_window_info.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_long), C.POINTER(C.c_long)]
@@ -202,13 +205,29 @@ class Context:
 
     # ---- sliding-window map (the incremental use of the reference's octree) ----
     def window_open(self, voxel_size=2.0, eigen_thresholds=(1.0 / 16, 1.0 / 16, 1.0 / 9), min_ps=15, layer_limit=2,
-                    min_observers=2):
+                    min_observers=2, fix_frames=0, strict=None, fix_point_limit=50, defer_recut=False):
+        """strict = (max_plane_dist, max_lambda21, max_lambda0): the consistency driver's plane test (BAs_left.hpp:674)"""
         o = VoxelOpts()
         self.L.balm_voxel_defaults(C.byref(o))
         o.voxel_size = voxel_size
         o.eigen_thr = (C.c_float * 3)(*[float(t) for t in eigen_thresholds])
         o.min_ps, o.layer_limit, o.min_observers = min_ps, layer_limit, min_observers
+        o.fix_frames, o.fix_point_limit, o.defer_recut = int(fix_frames), int(fix_point_limit), int(bool(defer_recut))
+        if strict is not None:
+            o.max_plane_dist, o.max_lambda21, o.max_lambda0 = [float(v) for v in strict]
         self._check(self.L.balm_window_open(self.h, C.byref(o)))
+
+    def window_points(self):
+        """-> (xyz [n,3] float32 body frame, window slot [n], feature of the last window_features [n] or -1), scan order"""
+        n = self.window_info()[1]
+        xyz, slot, feat = np.zeros((n, 3), np.float32), np.zeros(n, np.int32), np.zeros(n, np.int32)
+        got = C.c_long(0)
+        self._check(self.L.balm_window_get_points(self.h, _p(xyz), _p(slot), _p(feat), n, C.byref(got)))
+        return xyz[:got.value], slot[:got.value], feat[:got.value]
+
+    def window_recut(self):
+        """OCTO_TREE_ROOT::recut over the scans no recut has seen (window_open(defer_recut=True): consistency.cpp:127-136)"""
+        self._check(self.L.balm_window_recut(self.h))
 
     def window_add_scan(self, xyz, pose12):
         """cut_voxel + recut: body-frame points of one scan, its pose [12]"""

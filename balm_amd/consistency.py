@@ -43,6 +43,26 @@ def load_window(data_dir, n_poses=101):
     return poses, frames
 
 
+def associate_incremental(ctx, frames, poses):
+    """the driver's own sequence (consistency.cpp:108-136) on the device map: cut_voxel for win_size + fix_size scans, ONE
+    recut, ONE marginalize(fix_size, {}, win_count), tras_opt -- and the points of the features for the noise runs.
+    -> (clusters, coeffs, layer, fix, (xyz, feature, scan)) like the batch association's tuple"""
+    from . import realworld as rw
+    R = rw.SIM_RULES
+    ctx.window_open(voxel_size=R["voxel_size"], eigen_thresholds=R["eigen_thresholds"], min_ps=R["min_ps"], layer_limit=R["layer_limit"],
+                    min_observers=R["min_observers"], fix_frames=R["fix_frames"], strict=R["strict"], fix_point_limit=30,
+                    defer_recut=True)
+    for f, p in zip(frames, poses):
+        ctx.window_add_scan(f, p)
+    ctx.window_recut()
+    ctx.window_marginalize(R["fix_frames"])
+    F, (cl, co, layer, fix) = ctx.window_features()
+    xyz, slot, feat = ctx.window_points()
+    ctx.window_close()
+    keep = feat >= 0
+    return cl, co, layer, fix, (xyz[keep], feat[keep], slot[keep])
+
+
 def monte_carlo(ctx, frames, poses, pnoise=0.02, runs=1, seed=0, verbose=False, association=None):
     """consistency.cpp:96-170 around the GPU path: associate the noise-free scans (first scan marginalised into
     fix clusters), then per run corrupt every feature point with N(0, pnoise^2) (OCTO_TREE_NODE::corrupt,
@@ -83,6 +103,8 @@ def main(argv=None):
     ap.add_argument("--runs", type=int, default=1)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--device", type=int, default=0)
+    ap.add_argument("--batch", action="store_true", help="associate with balm_associate (all scans at once) instead of the driver's own "
+                                                         "incremental sequence on the device map")
     a = ap.parse_args(argv)
     from . import capi
     poses, frames = load_window(a.data_dir)
@@ -90,7 +112,8 @@ def main(argv=None):
     print("The size of poses: %d" % W)                                                  # consistency.cpp:138
     ctx = capi.Context(W, a.device)
     t = time.time()
-    vals, F = monte_carlo(ctx, frames, poses, a.pnoise, a.runs, a.seed, verbose=a.runs == 1)
+    assoc = None if a.batch else associate_incremental(ctx, frames, poses)
+    vals, F = monte_carlo(ctx, frames, poses, a.pnoise, a.runs, a.seed, verbose=a.runs == 1, association=assoc)
     print("%d plane features, %d run(s) in %.2f s" % (F, a.runs, time.time() - t))
     print("The expected NEES is 6*%d = %d." % (W, 6 * W))                              # :169
     for v in vals:

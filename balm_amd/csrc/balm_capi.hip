@@ -588,6 +588,7 @@ void balm_voxel_defaults(balm_voxel_opts *o) {
   o->min_ps = 15; o->layer_limit = 2; o->min_observers = 2; o->fix_frames = 0;
   o->max_plane_dist = 0; o->max_lambda21 = 0; o->max_lambda0 = 0;
   o->want_point_features = 0;
+  o->fix_point_limit = 50; o->defer_recut = 0;              // bavoxel.hpp:793
 }
 
 // the feature table an association left on the device ([F][W][10] clusters, weights, fix clusters, layers, optionally the
@@ -660,7 +661,7 @@ static int one_associate(balm_ctx *ctx, const balm_voxel_opts *opts, const float
     Span sp(ctx, BALM_T_VOXEL);
     AssocOpts ao{WT, opts->voxel_size, {opts->eigen_thr[0], opts->eigen_thr[1], opts->eigen_thr[2]}, opts->min_ps,
                  opts->layer_limit, opts->min_observers, opts->fix_frames, opts->max_plane_dist, opts->max_lambda21,
-                 opts->max_lambda0};
+                 opts->max_lambda0, opts->fix_point_limit > 0 ? opts->fix_point_limit : 50, 0};
     arc = associate_device(ctx->stream, d_xyz, d_f, d_pos, n_pts, ao, ctx->d_arena, ctx->arena_cap, &need, &F, &d_out, &d_coe,
                            &d_fix, &d_lay, opts->want_point_features ? &d_pf : nullptr, &nroots);
   }
@@ -684,7 +685,7 @@ static int one_associate(balm_ctx *ctx, const balm_voxel_opts *opts, const float
 // ---- sliding-window map (kernels_window.inc) ------------------------------------------------------------------------
 static int window_rc(balm_ctx *ctx, const char *who, int rc) {
   if (rc == 0) return BALM_OK;
-  ctx->err = std::string(who) + (rc == -2 ? ": window full / bad size" : rc == -3 ? ": non-finite point or beyond 2^20 voxels" : ": device failure");
+  ctx->err = std::string(who) + (rc == -2 ? ": window full / bad size / scans that no recut has seen" : rc == -3 ? ": non-finite point or beyond 2^20 voxels" : ": device failure");
   // a device failure (allocation, copy, launch) can strike after the call has already advanced the map's bookkeeping (slot
   // poses, node counts, the root table) but before its points and clusters are in: a retry would build on a corrupted
   // map.  The session answers BALM_ERR_STATE from here on; balm_window_open starts a fresh one.
@@ -700,16 +701,16 @@ static int window_alive(balm_ctx *ctx, const char *who) {
 
 static int one_window_open(balm_ctx *ctx, const balm_voxel_opts *opts) {
   if (!ctx) return BALM_ERR_ARG;
-  if (!opts || !(opts->voxel_size > 0) || opts->layer_limit < 0 || opts->layer_limit > 2 || opts->min_observers < 0 || ctx->W > 512 ||
-      opts->max_plane_dist > 0 || opts->max_lambda21 > 0 || opts->max_lambda0 > 0 || opts->fix_frames != 0) {
-    ctx->err = "balm_window_open: bad argument (the strict plane test and fix_frames belong to balm_associate; marginalise with "
-               "balm_window_marginalize)";
+  if (!opts || !(opts->voxel_size > 0) || opts->layer_limit < 0 || opts->layer_limit > 2 || opts->min_observers < 0 || opts->fix_frames < 0 ||
+      ctx->W + opts->fix_frames > 512 || opts->max_plane_dist < 0 || opts->max_lambda21 < 0 || opts->max_lambda0 < 0 || opts->fix_point_limit < 0) {
+    ctx->err = "balm_window_open: bad argument";
     return BALM_ERR_ARG;
   }
   HIP_TRY(hipSetDevice(ctx->device));
   if (ctx->window) { window_close(ctx->window); ctx->window = nullptr; }
   AssocOpts ao{ctx->W, opts->voxel_size, {opts->eigen_thr[0], opts->eigen_thr[1], opts->eigen_thr[2]}, opts->min_ps, opts->layer_limit,
-               opts->min_observers, 0, 0, 0, 0};
+               opts->min_observers, opts->fix_frames, opts->max_plane_dist, opts->max_lambda21, opts->max_lambda0,
+               opts->fix_point_limit > 0 ? opts->fix_point_limit : 50, opts->defer_recut != 0};
   ctx->window = window_open(ctx->stream, ao);
   ctx->window_dead = false;
   if (!ctx->window) { ctx->err = "balm_window_open: allocation failed"; return BALM_ERR_HIP; }
@@ -727,6 +728,14 @@ static int one_window_add_scan(balm_ctx *ctx, const float *xyz, long n_pts, cons
   HIP_TRY(hipMemcpyAsync(d_xyz, xyz, (size_t)n_pts * 3 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
   Span sp(ctx, BALM_T_VOXEL);
   return window_rc(ctx, "balm_window_add_scan", window_add_scan(ctx->window, d_xyz, n_pts, pose12));
+}
+
+static int one_window_recut(balm_ctx *ctx) {
+  if (!ctx) return BALM_ERR_ARG;
+  if (int rcw = window_alive(ctx, "balm_window_recut")) return rcw;
+  HIP_TRY(hipSetDevice(ctx->device));
+  Span sp(ctx, BALM_T_VOXEL);
+  return window_rc(ctx, "balm_window_recut", window_recut(ctx->window));
 }
 
 static int one_window_marginalize(balm_ctx *ctx, int mg, const double *poses) {
@@ -1208,6 +1217,7 @@ int balm_window_open(balm_ctx *ctx, const balm_voxel_opts *opts) { return one_wi
 int balm_window_add_scan(balm_ctx *ctx, const float *xyz, long n_pts, const double *pose12) {
   return one_window_add_scan(ctx, xyz, n_pts, pose12);
 }
+int balm_window_recut(balm_ctx *ctx) { return one_window_recut(ctx); }
 int balm_window_marginalize(balm_ctx *ctx, int mg_size, const double *poses) { return one_window_marginalize(ctx, mg_size, poses); }
 int balm_window_features(balm_ctx *ctx, int *F_out) {
   balm_multi *m = leader_of(ctx);
@@ -1225,6 +1235,17 @@ int balm_window_info(balm_ctx *ctx, int *scans, long *points, long *nodes) {
   if (scans) *scans = window_count(ctx->window);
   if (points) *points = window_points(ctx->window);
   if (nodes) *nodes = window_nodes(ctx->window);
+  return BALM_OK;
+}
+int balm_window_get_points(balm_ctx *ctx, float *xyz, int *slot, int *feature, long capacity, long *n_out) {
+  if (!ctx) return BALM_ERR_ARG;
+  if (int rcw = window_alive(ctx, "balm_window_get_points")) return rcw;
+  if (!n_out || capacity < 0) { ctx->err = "balm_window_get_points: bad argument"; return BALM_ERR_ARG; }
+  HIP_TRY(hipSetDevice(ctx->device));
+  const long n = window_get_points(ctx->window, xyz, slot, feature, capacity);
+  if (n == -2) { ctx->err = "balm_window_get_points: capacity too small"; return BALM_ERR_ARG; }
+  if (n < 0) return window_rc(ctx, "balm_window_get_points", -1);
+  *n_out = n;
   return BALM_OK;
 }
 int balm_window_close(balm_ctx *ctx) {

@@ -225,6 +225,8 @@ struct AssocOpts {
   float thr[3];
   int min_ps, layer_limit, min_observers, fix_frames;
   double max_dis, ratio21_max, lam0_max;
+  int fix_limit = 50;       // to_margi: fix_point.N < fix_limit (bavoxel.hpp:793: 50; BAs_left.hpp:756: 30)
+  int defer_recut = 0;      // window map: add_scan is cut_voxel only
 };
 int associate_device(hipStream_t s, const float *d_xyz, const int *d_frame, const double *d_poses, long n, const AssocOpts &o,
                      void *arena, size_t arena_cap, size_t *arena_need, int *F_out, double **d_out, double **d_coe,
@@ -235,8 +237,10 @@ int associate_device(hipStream_t s, const float *d_xyz, const int *d_frame, cons
 WindowSession *window_open(hipStream_t s, const AssocOpts &o);          // o.W = window size
 void window_close(WindowSession *w);
 int window_add_scan(WindowSession *w, const float *d_xyz_new, long n_new, const double *pose12);
+int window_recut(WindowSession *w);
 int window_marginalize(WindowSession *w, int mg, const double *poses);
 int window_features(WindowSession *w, int min_observers, int *F_out, double **d_out, double **d_coe, double **d_fix, int **d_layer);
+long window_get_points(WindowSession *w, float *xyz, int *slot, int *feature, long cap);
 int window_count(const WindowSession *w);
 int window_min_observers(const WindowSession *w);
 long window_points(const WindowSession *w);

@@ -168,6 +168,11 @@ typedef struct balm_voxel_opts {
   double max_lambda21;      /* 0 = off                                                           */
   double max_lambda0;       /* 0 = off                                                           */
   int want_point_features;  /* keep the point -> feature map for balm_get_association            */
+  int fix_point_limit;      /* to_margi folds marginalised scans into a fix cluster while it holds fewer points than
+                               this: 50 (bavoxel.hpp:793), 30 in the consistency driver (BAs_left.hpp:756); 0 = 50  */
+  int defer_recut;          /* balm_window_*: balm_window_add_scan is cut_voxel only; the caller runs
+                               balm_window_recut when it wants OCTO_TREE_ROOT::recut (consistency.cpp:127-136 adds the
+                               whole window first, then recuts and marginalises ONCE)                              */
 } balm_voxel_opts;
 void balm_voxel_defaults(balm_voxel_opts *opts);
 int balm_associate(balm_ctx *ctx, const balm_voxel_opts *opts, const float *xyz, const int *frame_id,
@@ -175,8 +180,11 @@ int balm_associate(balm_ctx *ctx, const balm_voxel_opts *opts, const float *xyz,
 
 /* Sliding-window map: the INCREMENTAL use of the reference's adaptive voxel map, kept on the device between calls
  * (OCTO_TREE_ROOT / OCTO_TREE_NODE, src/benchmark/bavoxel.hpp:625-963; balm_associate above is the batch form).
- *   balm_window_open         an empty unordered_map<VOXEL_LOC, OCTO_TREE_ROOT*>; window size = the context's `win`;
- *                            opts as for balm_associate (fix_frames and the strict plane test must be 0)
+ *   balm_window_open         an empty unordered_map<VOXEL_LOC, OCTO_TREE_ROOT*>; window size = the context's `win`, plus
+ *                            opts->fix_frames extra scans the map can hold until they are marginalised (the
+ *                            `win_size + fix_size` slots of src/simulation/BAs_left.hpp:640-641).  opts as for balm_associate:
+ *                            the consistency driver's plane test (max_plane_dist / max_lambda21 / max_lambda0,
+ *                            BAs_left.hpp:647-674) and its fix_point_limit (:756) apply to recut / marginalize here too
  *   balm_window_add_scan     cut_voxel(map, scan, pose, fnum = scans in the window)  (:1170-1223)  followed by
  *                            recut(win_count) of every root (:737-776): nodes that were cut stay cut and forward the
  *                            new scan, the others are judged again over fix cluster + all scans.  xyz: n_pts*3 body-frame
@@ -187,12 +195,22 @@ int balm_associate(balm_ctx *ctx, const balm_voxel_opts *opts, const float *xyz,
  *                            :778-816): with poses (scans_in_window*12) every cluster and point is re-transformed first;
  *                            the first mg_size scans of plane voxels join the fix clusters (fix_point.N < 50), the window
  *                            moves down by mg_size.  poses == NULL is the reference's empty x_poses (no re-transform).
- * One recut per scan is the reference's own calling convention (a cut node only forwards the newest scan).  */
+ *   balm_window_recut        recut(win_count) of every root over the scans no recut has seen yet -- with opts->defer_recut the
+ *                            calling sequence of consistency.cpp:108-136: cut_voxel for the whole window, ONE recut, ONE
+ *                            marginalize(fix_size, {}, win_count).
+ * One recut per scan is bavoxel.hpp's own calling convention (a cut node only forwards the newest scan).
+ * balm_window_features / _marginalize want every scan recut, and at most `win` scans in the window for _features.  */
 int balm_window_open(balm_ctx *ctx, const balm_voxel_opts *opts);
+int balm_window_recut(balm_ctx *ctx);
 int balm_window_add_scan(balm_ctx *ctx, const float *xyz, long n_pts, const double *pose12);
 int balm_window_features(balm_ctx *ctx, int *F_out);
 int balm_window_marginalize(balm_ctx *ctx, int mg_size, const double *poses);
 int balm_window_info(balm_ctx *ctx, int *scans_in_window, long *points, long *nodes);
+/* The points the map holds, in scan order: body-frame xyz (n*3), window slot, and the feature of the last balm_window_features
+ * each belongs to (-1: none) -- what OCTO_TREE_NODE::corrupt (src/simulation/BAs_left.hpp:886-906) walks, and what
+ * balm_build_clusters needs to rebuild the clusters from perturbed points.  Arrays may be NULL; capacity in points
+ * (balm_window_info gives the count); *n_out = points written. */
+int balm_window_get_points(balm_ctx *ctx, float *xyz, int *slot, int *feature, long capacity, long *n_out);
 int balm_window_close(balm_ctx *ctx);
 
 /* Host copies of the feature table installed by the last balm_associate: clusters F*W*10, coeffs F,

@@ -80,3 +80,34 @@ def associate(frames_xyz, poses, fix=1, voxel_size=1.0):
     if F:
         L.refsim_associate(n, fix, _p(xyz), _p(counts), _p(poses), C.c_double(voxel_size), _p(cl), _p(fx))
     return cl, fx
+
+
+class Window:
+    """BAs_left.hpp's OCTO_TREE_ROOT map driven call for call (refsim_win_*): cut_voxel / recut / marginalize / tras_opt"""
+
+    def __init__(self, W, fix, voxel_size=1.0):
+        L = lib()
+        L.refsim_win_open.restype = C.c_void_p
+        self.W, self.h = W, C.c_void_p(L.refsim_win_open(W, fix, C.c_double(voxel_size)))
+
+    def cut_voxel(self, xyz, pose12):
+        xyz = np.ascontiguousarray(xyz, dtype=np.float32).reshape(-1, 3)
+        lib().refsim_win_cut_voxel(self.h, _p(xyz), C.c_long(xyz.shape[0]), _p(_c(pose12).reshape(12)))
+
+    def recut(self):
+        lib().refsim_win_recut(self.h)
+
+    def marginalize(self, mg, poses=None):
+        lib().refsim_win_marginalize(self.h, int(mg), _p(_c(poses)) if poses is not None else None)
+
+    def features(self):
+        F = lib().refsim_win_features(self.h)
+        cl, fx = np.zeros((F, self.W, 10)), np.zeros((F, 10))
+        if F:
+            lib().refsim_win_export(self.h, _p(cl), _p(fx))
+        return cl, fx
+
+    def close(self):
+        if self.h:
+            lib().refsim_win_close(self.h)
+            self.h = None

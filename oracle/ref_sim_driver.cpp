@@ -183,4 +183,68 @@ int refsim_evaluate(int W, int F, const double *clusters, const double *fix, con
   return 0;
 }
 
+// ---- the consistency driver's map used call for call (consistency.cpp:108-136 and beyond): comparator of balm_window_* with
+// the strict plane test, fix_frames and defer_recut (tests/test_gpu_window.py) ----
+struct SimWin {
+  std::unordered_map<VOXEL_LOC, OCTO_TREE_ROOT *> map;
+  int win_count = 0;
+  VOX_HESS *vh = nullptr;
+  ~SimWin() { for (auto &kv : map) delete kv.second; delete vh; }
+};
+
+void *refsim_win_open(int W, int fix, double vsize) {
+  win_size = W; fix_size = fix; voxel_size = vsize;
+  return new SimWin();
+}
+
+void refsim_win_cut_voxel(void *hh, const float *xyz, long n, const double *pose12) {
+  SimWin *h = (SimWin *)hh;
+  pcl::PointCloud<PointType> pl;
+  pl.reserve((size_t)n);
+  for (long k = 0; k < n; k++) { PointType ap; ap.x = xyz[3 * k]; ap.y = xyz[3 * k + 1]; ap.z = xyz[3 * k + 2]; pl.push_back(ap); }
+  IMUST x = load_poses(1, pose12)[0];
+  cut_voxel(h->map, pl, x, h->win_count);
+  h->win_count++;
+}
+
+void refsim_win_recut(void *hh) {
+  SimWin *h = (SimWin *)hh;
+  for (auto &kv : h->map) kv.second->recut(h->win_count);
+}
+
+void refsim_win_marginalize(void *hh, int mg, const double *poses) {
+  SimWin *h = (SimWin *)hh;
+  std::vector<IMUST> xs;
+  if (poses) xs = load_poses(h->win_count, poses);
+  for (auto &kv : h->map) kv.second->marginalize(mg, xs, h->win_count);
+  h->win_count -= mg;
+}
+
+int refsim_win_features(void *hh) {
+  SimWin *h = (SimWin *)hh;
+  delete h->vh;
+  h->vh = new VOX_HESS();
+  for (auto &kv : h->map) kv.second->tras_opt(*h->vh, h->win_count);
+  return (int)h->vh->plvec_voxels.size();
+}
+
+void refsim_win_export(void *hh, double *clusters, double *fix) {
+  SimWin *h = (SimWin *)hh;
+  const int W = win_size;
+  const size_t F = h->vh->plvec_voxels.size();
+  auto put = [](const PointCluster &c, double *q) {
+    q[0] = c.P(0, 0); q[1] = c.P(1, 0); q[2] = c.P(2, 0); q[3] = c.P(1, 1); q[4] = c.P(2, 1); q[5] = c.P(2, 2);
+    q[6] = c.v[0]; q[7] = c.v[1]; q[8] = c.v[2]; q[9] = c.N;
+  };
+  for (size_t a = 0; a < F; a++) {
+    for (int i = 0; i < W; i++) put((*h->vh->plvec_voxels[a])[i], clusters + (a * W + i) * 10);
+    put(*h->vh->sig_vecs[a], fix + a * 10);
+  }
+}
+
+void refsim_win_close(void *hh) {
+  delete (SimWin *)hh;
+  win_size = 100; fix_size = 1; voxel_size = 1;         // the globals' defaults (BAs_left.hpp:13-23)
+}
+
 }  // extern "C"

@@ -241,3 +241,31 @@ def test_pose_covariance_two_ranks_sharded_on_one_gpu():
         p.join(timeout=120)
         assert p.exitcode == 0
     assert rel(Rraw2, Rraw1) < 1e-12 and rel(Rcov2, Rcov1) < 1e-9
+
+
+def test_consistency_experiment_incremental_association():
+    """the same experiment with the driver's OWN association sequence (consistency.cpp:108-136: cut_voxel for 101 scans, one
+    recut, one marginalize) on the device map (balm_window_* with the strict plane test, fix_frames, defer_recut) and the
+    feature points read back from the map: the feature set of the batch association bit for bit, the points rebuild the
+    clusters, NEES about 600"""
+    path = os.path.join(ROOT, "oracle", "_ref", "consistency_scans.npz")
+    if not os.path.exists(path):
+        pytest.skip("oracle/_ref/consistency_scans.npz not built (needs /root/reference/datas)")
+    from balm_amd import realworld as rw
+    d = np.load(path)
+    frames = np.split(d["xyz"], np.cumsum(d["counts"])[:-1])
+    c = capi.Context(100)
+    cl, co, layer, fix, (xyz, fid, sid) = consistency.associate_incremental(c, frames, d["poses"])
+    assert cl.shape[0] == 1096
+    Fb, _, (clb, cob, layb, fixb, _) = rw.associate_gpu(c, frames, d["poses"], want_points=True, **rw.SIM_RULES)
+    key = lambda a, f: np.concatenate([a.reshape(a.shape[0], -1), f], axis=1)
+    ka, kb = key(cl, fix), key(clb, fixb)
+    assert np.array_equal(ka[np.lexsort(ka[:, ::-1].T)], kb[np.lexsort(kb[:, ::-1].T)])
+    # the points the map hands out are the points of the clusters: counts per (feature, scan)
+    N = np.zeros(cl.shape[:2])
+    np.add.at(N, (fid, sid), 1)
+    assert np.array_equal(N, cl[:, :, 9])
+    vals, F = consistency.monte_carlo(c, frames, d["poses"], pnoise=0.02, runs=2, seed=11, association=(cl, co, layer, fix, (xyz, fid, sid)))
+    c.close()
+    print("consistency experiment, incremental association: %d features, NEES %s" % (F, np.round(vals, 1)))
+    assert np.all(np.abs(np.array(vals) - 600) < 6 * np.sqrt(1200))

@@ -275,3 +275,58 @@ def test_window_edge_cases_against_reference():
         both("add_scan", frames[7], poses[7])
         compare(ctx, win, "limit %d, after a marginalisation without poses" % limit)
         win.close(); ctx.close()
+
+
+def _canon_fix(cl, fix):
+    both = np.concatenate([cl.reshape(cl.shape[0], -1), fix], axis=1)
+    return both[np.lexsort(both[:, ::-1].T)]
+
+
+@pytest.mark.parametrize("seed,W,fix", [(4, 8, 1), (9, 6, 2)])
+def test_window_map_with_the_consistency_drivers_rules(seed, W, fix):
+    """The one driver of the reference that really uses its octree incrementally (src/simulation/consistency.cpp:108-136):
+    cut_voxel for win_size + fix_size scans, ONE recut, ONE marginalize(fix_size, {}, win_count) -- with that file's copy
+    of the map (BAs_left.hpp: the strict plane test :647-674 over the points' distances, fix_point.N < 30 :756, a cut_voxel
+    that keeps every point :1120) -- on the device map (fix_frames, strict, fix_point_limit, defer_recut) against the
+    compiled BAs_left.hpp octree call for call, against the batch balm_associate with the same rules, and onward: more
+    scans, one recut each, another marginalisation."""
+    from oracle import ref_sim
+    from balm_amd import realworld as rw
+    from test_association import exact_plane_scans
+    if not ref_sim.available():
+        pytest.skip("oracle/_ref/libbalm_ref_sim.so not built")
+    extra = 2 * fix
+    poses, frames = exact_plane_scans(seed, W + fix + extra, 40, 60)
+    R = rw.SIM_RULES
+    ctx = capi.Context(W)
+    ctx.window_open(voxel_size=R["voxel_size"], eigen_thresholds=R["eigen_thresholds"], min_ps=R["min_ps"], layer_limit=R["layer_limit"],
+                    min_observers=R["min_observers"], fix_frames=fix, strict=R["strict"], fix_point_limit=30, defer_recut=True)
+    win = ref_sim.Window(W, fix, R["voxel_size"])
+    for i in range(W + fix):
+        ctx.window_add_scan(frames[i], poses[i])
+        win.cut_voxel(frames[i], poses[i])
+    with pytest.raises(capi.BalmError):                    # scans no recut has seen, and more than `win` of them
+        ctx.window_features()
+    ctx.window_recut(); win.recut()
+    ctx.window_marginalize(fix); win.marginalize(fix)
+    F, (cl, co, layer, fx) = ctx.window_features()
+    cl_r, fx_r = win.features()
+    assert F == cl_r.shape[0] >= 10 and (fx[:, 9] > 0).any()
+    assert np.array_equal(_canon_fix(cl, fx), _canon_fix(cl_r, fx_r))          # no re-transform: fix clusters are sums too -> bit for bit
+    # the batch form with the same rules (pinned to the reference's compiled association in tests/test_association.py)
+    c2 = capi.Context(W)
+    rules = dict(R, fix_frames=fix)
+    Fb, _, (clb, cob, layb, fxb, _) = rw.associate_gpu(c2, frames[:W + fix], poses[:W + fix], want_points=True, **rules)
+    assert Fb == F and np.array_equal(_canon_fix(clb, fxb), _canon_fix(cl, fx))
+    c2.close()
+    # onward: the map stays alive -- scan, recut, scan, recut, marginalise (the calling convention of bavoxel.hpp on this map)
+    for rnd in range(2):
+        for k in range(fix):
+            i = W + fix + rnd * fix + k
+            ctx.window_add_scan(frames[i], poses[i]); ctx.window_recut()
+            win.cut_voxel(frames[i], poses[i]); win.recut()
+        ctx.window_marginalize(fix); win.marginalize(fix)
+        F, (cl, co, layer, fx) = ctx.window_features()
+        cl_r, fx_r = win.features()
+        assert F == cl_r.shape[0] and np.array_equal(_canon_fix(cl, fx), _canon_fix(cl_r, fx_r)), rnd
+    win.close(); ctx.close()
