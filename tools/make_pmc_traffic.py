@@ -13,13 +13,13 @@ src, tag = sys.argv[1], sys.argv[2]
 W = int(sys.argv[3]) if len(sys.argv) > 3 else 200
 Fg = int(sys.argv[4]) if len(sys.argv) > 4 else 50000
 rows = {r["kernel"].split("::")[-1].split("<")[0]: r for r in csv.DictReader(open(src))}
-out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE / --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE "
+out = {"run": tag, "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE / --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE "
                  "(separate passes) -- python bench.py --steps 3 --warmup 1 --no-cpu; profiles/%s_pmc_summary.csv" % tag,
        "correction": "FETCH_SIZE (KiB) x 1024 x 2 (gfx950 tallies 128-B requests at 64 B), WRITE_SIZE (KiB) x 1024",
        "W": W, "features_per_gpu": Fg}
 alg = {"k_hessian_syrk": 8.0 * (3.0 * Fg) * (6.0 * W) + 8.0 * 6400 * 35 * 114,      # G-tilde once + the split-K partial tiles
        "k_feature_factors": 224.0 * Fg * W, "k_world_moments": 80.0 * Fg * W}
-for k in ("k_hessian_syrk", "k_feature_factors", "k_world_moments", "k_ldl_fused", "k_build_clusters_runs"):
+for k in ("k_hessian_syrk", "k_feature_factors", "k_world_moments", "k_ldl_chain", "k_ldl_fused", "k_build_clusters_runs"):
     r = rows.get(k)
     if not r or not r.get("FETCH_SIZE"):
         continue
