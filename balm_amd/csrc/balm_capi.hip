@@ -65,7 +65,7 @@ int dalloc(balm_ctx *ctx, T **p, size_t count) {
 template <class T>
 int keep(balm_ctx *ctx, T **p, size_t *cap, size_t count) {
   if (*p && *cap >= count) return BALM_OK;
-  for (int k = 0; k < 4; k++)           // captured LM graphs hold the old pointer (as in ensure())
+  for (int k = 0; k < balm_ctx::LM_GRAPHS; k++)           // captured LM graphs hold the old pointer (as in ensure())
     if (ctx->lm_graph[k]) { hipGraphExecDestroy(ctx->lm_graph[k]); ctx->lm_graph[k] = nullptr; ctx->lm_graph_form[k] = -1; }
   int rc = dalloc(ctx, p, count + count / 4);
   *cap = rc ? 0 : count + count / 4;
@@ -75,7 +75,7 @@ int keep(balm_ctx *ctx, T **p, size_t *cap, size_t count) {
 template <class T>
 int ensure(balm_ctx *ctx, T **p, size_t *cap, size_t count) {
   if (*p && *cap >= count) return BALM_OK;
-  for (int k = 0; k < 4; k++)           // captured LM graphs hold the old pointer
+  for (int k = 0; k < balm_ctx::LM_GRAPHS; k++)           // captured LM graphs hold the old pointer
     if (ctx->lm_graph[k]) { hipGraphExecDestroy(ctx->lm_graph[k]); ctx->lm_graph[k] = nullptr; ctx->lm_graph_form[k] = -1; }
   int rc = dalloc(ctx, p, count);
   if (rc) return rc;
@@ -140,7 +140,7 @@ int set_damping(balm_ctx *ctx, double u) {
 }
 
 void drop_lm_graphs(balm_ctx *ctx) {
-  for (int k = 0; k < 4; k++) {
+  for (int k = 0; k < balm_ctx::LM_GRAPHS; k++) {
     if (ctx->lm_graph[k]) hipGraphExecDestroy(ctx->lm_graph[k]);
     ctx->lm_graph[k] = nullptr; ctx->lm_graph_form[k] = -1;
   }
@@ -165,6 +165,17 @@ int residual_device(balm_ctx *ctx, const double *d_poses, int f0, int f1, int sl
   return hook_allreduce(ctx, ctx->d_scal + slot, 1);
 }
 
+// The LM loop's trial evaluation as ONE pass over the clusters (k_moments_factors): residual AND the factors of the trial
+// poses, which an accepted step's Hessian evaluation then starts from.  OPT-IN (BALM_FUSE_TRIAL=1): measured at config 2
+// (profiles/r03g_one_pass_trial.txt) the one-pass kernel takes 1.55 ms where K1 + K1b + K2 take 0.74 -- a workgroup's features
+// are serialised behind a single lane's 3x3 Jacobi (~10 us; K1b runs 64 of them per wavefront), and the 62 KB of per-pose
+// accumulators allow only two workgroups per CU to hide it.  Kept because it is parity-tested and halves the HBM reads of the
+// clusters; see DESIGN.md 4.2 for what a version that wins would need.  One pose per lane: W <= 256.
+bool fuse_trial(const balm_ctx *ctx) {
+  const char *e = getenv("BALM_FUSE_TRIAL");
+  return ctx->W <= 256 && ctx->F > 0 && e && e[0] == '1';
+}
+
 // scratch of one Hessian evaluation over nf features (grown, never shrunk): every allocation an evaluation can need
 // happens here, so that a rank of a sharded run can fail BEFORE the collectives start (see one_damping_iter)
 int prepare_evaluate(balm_ctx *ctx, int form, int nf) {
@@ -178,7 +189,13 @@ int prepare_evaluate(balm_ctx *ctx, int form, int nf) {
   }
   if ((rc = ensure(ctx, &ctx->d_Gt, &ctx->cap_Gt, gcols * ctx->npad))) return rc;
   if ((rc = ensure(ctx, &ctx->d_part, &ctx->cap_part, parts * TILE_ELEMS))) return rc;
-  return ensure(ctx, &ctx->d_dpart, &ctx->cap_dpart, (size_t)factors_grid(ctx->W, nf, form) * DACC_MAX * ctx->W);
+  if ((rc = ensure(ctx, &ctx->d_dpart, &ctx->cap_dpart, (size_t)factors_grid(ctx->W, nf, form) * DACC_MAX * ctx->W))) return rc;
+  if (nf == ctx->F && fuse_trial(ctx)) {       // the trial poses' factors (same sizes; reallocation invalidates what they held)
+    if (ctx->cap_Gt2 < gcols * ctx->npad || ctx->cap_dpart2 < (size_t)factors_grid(ctx->W, nf, form) * DACC_MAX * ctx->W) ctx->gt_trial_valid = false;
+    if ((rc = ensure(ctx, &ctx->d_Gt2, &ctx->cap_Gt2, gcols * ctx->npad))) return rc;
+    if ((rc = ensure(ctx, &ctx->d_dpart2, &ctx->cap_dpart2, (size_t)factors_grid(ctx->W, nf, form) * DACC_MAX * ctx->W))) return rc;
+  }
+  return BALM_OK;
 }
 
 // Hessian + gradient + residual of features [f0,f1) at device poses -> d_H, d_g, d_scal[slot]
@@ -207,7 +224,7 @@ int evaluate_device(balm_ctx *ctx, int form, const double *d_poses, int f0, int 
   const int nr = ctx->nr_cur;
   const bool sparse = ctx->sparse && f0 == 0 && f1 == ctx->F;       // sub-ranges keep the dense plan and column order
   const size_t kpad = sparse ? (size_t)ctx->sp_nchunks * ctx->sp_nsteps * 4 : (size_t)plan.Kpad;
-  {
+  if (!(ctx->gt_cur_valid && ctx->feat_cur_valid && f0 == 0 && f1 == ctx->F)) {
     Span sp(ctx, BALM_T_FACTORS);
     // zero the Gt columns the factor kernel does not write: [3 nf, Kpad + 8) and the row padding
     const size_t k0 = (size_t)3 * nf, k1 = kpad + 64;   // + prefetch overrun of the k-ring
@@ -217,6 +234,7 @@ int evaluate_device(balm_ctx *ctx, int form, const double *d_poses, int f0, int 
                                (size_t)(ctx->npad - ctx->n) * sizeof(double), k0 ? k0 : 1, s));
     launch_factors(s, form, ctx->d_cl, d_poses, ctx->d_feat, W, ctx->npad, f0, f1, ctx->d_Gt, ctx->d_dpart, nblk,
                    sparse ? ctx->d_slot : nullptr);
+    ctx->gt_cur_valid = false;                // (set by the LM loop only, when an accepted trial's factors become current)
   }
   // the moments / factor kernels ask for up to 150 KB of dynamic LDS (above the 64 KiB default: granted per device by
   // prepare_device_accum); a refused launch must surface here, not as stale results at the next synchronisation
@@ -240,6 +258,34 @@ int evaluate_device(balm_ctx *ctx, int form, const double *d_poses, int f0, int 
                            hipMemcpyDeviceToDevice, s));
   }
   return BALM_OK;
+}
+
+// The trial evaluation of the LM loop, fused: residual at the trial poses -> d_scal[slot] (summed over ranks), eigen records ->
+// d_feat_tmp, AND the factors of the trial poses -> d_Gt2 / d_dpart2.  All features of this context (shard).
+int trial_device(balm_ctx *ctx, int form, const double *d_poses, int slot) {
+  const int W = ctx->W, F = ctx->F;
+  hipStream_t s = ctx->stream;
+  const SyrkPlan plan = plan_syrk(ctx->ntiles, 3L * F);
+  const bool sparse = ctx->sparse;
+  const size_t kpad = sparse ? (size_t)ctx->sp_nchunks * ctx->sp_nsteps * 4 : (size_t)plan.Kpad;
+  const int nblk = factors_grid(W, F, form);
+  {
+    Span sp(ctx, BALM_T_FACTORS);
+    const size_t k0 = (size_t)3 * F, k1 = kpad + 64;
+    HIP_TRY(hipMemsetAsync(ctx->d_Gt2 + k0 * ctx->npad, 0, (k1 - k0) * ctx->npad * sizeof(double), s));
+    if (ctx->npad > ctx->n)
+      HIP_TRY(hipMemset2DAsync(ctx->d_Gt2 + ctx->n, (size_t)ctx->npad * sizeof(double), 0,
+                               (size_t)(ctx->npad - ctx->n) * sizeof(double), k0, s));
+    ctx->nr_tmp = launch_moments_factors(s, form, ctx->d_cl, d_poses, ctx->has_fix ? ctx->d_fix : nullptr, ctx->d_coe, W, ctx->npad, F,
+                                         ctx->d_Gt2, ctx->d_dpart2, nblk, sparse ? ctx->d_slot : nullptr, ctx->d_feat_tmp, ctx->d_rpart_tmp);
+  }
+  HIP_TRY(hipGetLastError());
+  {
+    Span sp(ctx, BALM_T_MOMENTS);
+    launch_sum_scalar(s, ctx->d_rpart_tmp, ctx->nr_tmp, ctx->d_scal + slot);
+  }
+  ctx->gt_trial_valid = true;
+  return hook_allreduce(ctx, ctx->d_scal + slot, 1);
 }
 
 int read_scalars(balm_ctx *ctx) {
@@ -379,7 +425,7 @@ static void one_destroy(balm_ctx *ctx) {
   if (ctx->stream) hipStreamSynchronize(ctx->stream);
   if (ctx->window) { window_close(ctx->window); ctx->window = nullptr; }
   void *ptrs[] = {ctx->d_cl, ctx->d_fix, ctx->d_coe, ctx->d_poses, ctx->d_poses_tmp, ctx->d_C, ctx->d_feat,
-                  ctx->d_Gt, ctx->d_part, ctx->d_dpart, ctx->d_rpart, ctx->d_feat_tmp, ctx->d_rpart_tmp, ctx->d_red, ctx->d_jobs, ctx->d_sub, ctx->d_H,
+                  ctx->d_Gt, ctx->d_Gt2, ctx->d_dpart2, ctx->d_part, ctx->d_dpart, ctx->d_rpart, ctx->d_feat_tmp, ctx->d_rpart_tmp, ctx->d_red, ctx->d_jobs, ctx->d_sub, ctx->d_H,
                   ctx->d_g, ctx->d_A, ctx->d_Wp, ctx->d_dvec, ctx->d_z, ctx->d_x, ctx->d_perm, ctx->d_dx, ctx->d_scal, ctx->d_arena, ctx->d_pre, ctx->d_flags, ctx->d_minv, ctx->d_trace, ctx->d_slot, ctx->d_items, ctx->d_csr, ctx->d_chunk_ids, ctx->d_stage};
   for (void *p : ptrs) if (p) hipFree(p);
   if (ctx->h_scal) hipHostFree(ctx->h_scal);
@@ -495,16 +541,16 @@ static int install_feature_buffers(balm_ctx *ctx, int F, const double *fix, cons
   if ((rc = keep(ctx, &ctx->d_C, &ctx->cap_C, (size_t)F * 10))) return rc;
   if ((rc = keep(ctx, &ctx->d_feat, &ctx->cap_feat, (size_t)F * FEAT_STRIDE))) return rc;
   if ((rc = keep(ctx, &ctx->d_feat_tmp, &ctx->cap_feat_tmp, (size_t)F * FEAT_STRIDE))) return rc;
-  if ((rc = keep(ctx, &ctx->d_rpart, &ctx->cap_rpart, (size_t)(F + 255) / 256 + 1))) return rc;
-  if ((rc = keep(ctx, &ctx->d_rpart_tmp, &ctx->cap_rpart_tmp, (size_t)(F + 255) / 256 + 1))) return rc;
-  ctx->feat_cur_valid = false;
+  if ((rc = keep(ctx, &ctx->d_rpart, &ctx->cap_rpart, (size_t)(F + 255) / 256 + 1024 + 1))) return rc;       // + one per workgroup of the fused trial evaluation
+  if ((rc = keep(ctx, &ctx->d_rpart_tmp, &ctx->cap_rpart_tmp, (size_t)(F + 255) / 256 + 1024 + 1))) return rc;
+  ctx->feat_cur_valid = false; ctx->gt_cur_valid = false;
   ctx->F = F;
   return BALM_OK;
 }
 
 static int one_set_features(balm_ctx *ctx, int F, const double *clusters, const double *fix, const double *coeffs) {
   if (!ctx) return BALM_ERR_ARG;
-  if (ctx->multi && F == 0) { ctx->F = 0; ctx->feat_cur_valid = false; return BALM_OK; }      // a shard without features
+  if (ctx->multi && F == 0) { ctx->F = 0; ctx->feat_cur_valid = false; ctx->gt_cur_valid = false; return BALM_OK; }      // a shard without features
   if (F < 1 || !clusters || !coeffs) { ctx->err = "balm_set_features: bad argument"; return BALM_ERR_ARG; }
   HIP_TRY(hipSetDevice(ctx->device));
   const int W = ctx->W;
@@ -798,9 +844,9 @@ static int one_pose_covariance(balm_ctx *ctx, const double *poses, const double 
   const int W = ctx->W, n = ctx->n, nA = ctx->nA, F = ctx->F;
   hipStream_t s = ctx->stream;
   HIP_TRY(hipMemcpyAsync(ctx->d_poses, poses, (size_t)12 * W * sizeof(double), hipMemcpyHostToDevice, s));
-  ctx->feat_cur_valid = false;
+  ctx->feat_cur_valid = false; ctx->gt_cur_valid = false;
   int rc = evaluate_device(ctx, BALM_FORM_LEFT, ctx->d_poses, 0, F, 0);     // d_H, and the eigen records in d_feat
-  ctx->feat_cur_valid = false;
+  ctx->feat_cur_valid = false; ctx->gt_cur_valid = false;
   if (rc) return rc;
   const SyrkPlan plan = plan_syrk(ctx->ntiles, 3L * (F > 0 ? F : 1));
   const size_t gcols = (size_t)plan.Kpad + 64, tiles = (size_t)ctx->ntiles * TILE_ELEMS;
@@ -890,9 +936,9 @@ static int one_evaluate(balm_ctx *ctx, int form, const double *poses, int head, 
   HIP_TRY(hipSetDevice(ctx->device));
   const int n = ctx->n;
   HIP_TRY(hipMemcpyAsync(ctx->d_poses, poses, (size_t)12 * ctx->W * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-  ctx->feat_cur_valid = false;
+  ctx->feat_cur_valid = false; ctx->gt_cur_valid = false;
   int rc = evaluate_device(ctx, form, ctx->d_poses, head, end, 0);
-  ctx->feat_cur_valid = false;
+  ctx->feat_cur_valid = false; ctx->gt_cur_valid = false;
   if (rc) return rc;
   if (Hess) HIP_TRY(hipMemcpyAsync(Hess, ctx->d_H, (size_t)n * n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   if (JacT) HIP_TRY(hipMemcpyAsync(JacT, ctx->d_g, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
@@ -953,7 +999,10 @@ static int lm_enqueue(balm_ctx *ctx, int form, bool evaluated) {
     Span sp(ctx, BALM_T_UPDATE);
     launch_update_poses(ctx->stream, form, ctx->W, ctx->d_poses, ctx->d_dx, ctx->d_poses_tmp);
   }
-  if ((rc = residual_device(ctx, ctx->d_poses_tmp, 0, ctx->F, 1))) return rc;
+  ctx->gt_trial_valid = false;
+  if (fuse_trial(ctx) && ctx->d_Gt2 && ctx->d_dpart2) {
+    if ((rc = trial_device(ctx, form, ctx->d_poses_tmp, 1))) return rc;
+  } else if ((rc = residual_device(ctx, ctx->d_poses_tmp, 0, ctx->F, 1))) return rc;
   HIP_TRY(hipMemcpyAsync(ctx->h_scal, ctx->d_scal, 16 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   return BALM_OK;
 }
@@ -970,7 +1019,8 @@ static int lm_iteration(balm_ctx *ctx, int form, bool evaluated, int it) {
   const bool graphable = !disabled && ctx->graphs_ok && it >= 1 && !ctx->timer.on && !has_transport(ctx) && !ctx->multi &&
                          ctx->feat_cur_valid && ctx->F > 0 && !solve_is_persistent(ctx);
   if (graphable) {
-    const int slot = (evaluated ? 2 : 0) | ctx->parity;
+    const bool fused = fuse_trial(ctx) && ctx->d_Gt2 && ctx->d_dpart2;       // what lm_enqueue would issue depends on all four
+    const int slot = (ctx->gt_parity ? 16 : 0) | (fused ? 8 : 0) | (ctx->gt_cur_valid ? 4 : 0) | (evaluated ? 2 : 0) | ctx->parity;
     if (ctx->lm_graph[slot] && ctx->lm_graph_form[slot] != form) {
       hipGraphExecDestroy(ctx->lm_graph[slot]); ctx->lm_graph[slot] = nullptr;
     }
@@ -1039,7 +1089,7 @@ static int one_damping_iter(balm_ctx *ctx, const balm_lm_opts *o, double *poses,
     }
   }
   HIP_TRY(hipMemcpyAsync(ctx->d_poses, poses, (size_t)12 * W * sizeof(double), hipMemcpyHostToDevice, s));
-  ctx->feat_cur_valid = false;
+  ctx->feat_cur_valid = false; ctx->gt_cur_valid = false;
   double u = o->u0, v = 2, r1 = 0, r2 = 0;
   bool calc = true;
   int it = 0;
@@ -1076,6 +1126,12 @@ static int one_damping_iter(balm_ctx *ctx, const balm_lm_opts *o, double *poses,
       t = ctx->d_rpart; ctx->d_rpart = ctx->d_rpart_tmp; ctx->d_rpart_tmp = t;
       ctx->nr_cur = ctx->nr_tmp;
       ctx->feat_cur_valid = true;
+      ctx->gt_cur_valid = ctx->gt_trial_valid;        // the trial's factors (fused evaluation) become the current poses'
+      if (ctx->gt_trial_valid) {
+        std::swap(ctx->d_Gt, ctx->d_Gt2); std::swap(ctx->cap_Gt, ctx->cap_Gt2);
+        std::swap(ctx->d_dpart, ctx->d_dpart2); std::swap(ctx->cap_dpart, ctx->cap_dpart2);
+        ctx->gt_parity ^= 1;
+      }
       ctx->parity ^= 1;
       q = q / q1; v = 2; q = 1 - std::pow(2 * q - 1, 3);
       u *= (q < 1.0 / 3.0 ? 1.0 / 3.0 : q);
@@ -1087,7 +1143,7 @@ static int one_damping_iter(balm_ctx *ctx, const balm_lm_opts *o, double *poses,
     if (!o->no_stop && std::fabs(r1 - r2) / r1 < o->rel_tol) break;   // :1155
     if (!o->no_stop && o->abs_tol > 0 && std::fabs(r1 - r2) < o->abs_tol) break;   // BAs_left.hpp:1083
   }
-  ctx->feat_cur_valid = false;
+  ctx->feat_cur_valid = false; ctx->gt_cur_valid = false;
   if (o->reanchor) launch_reanchor(s, W, ctx->d_poses);
   HIP_TRY(hipMemcpyAsync(poses, ctx->d_poses, (size_t)12 * W * sizeof(double), hipMemcpyDeviceToHost, s));
   if ((rc = sync_stream(ctx))) return rc;

@@ -67,6 +67,12 @@ struct balm_ctx {
   int nr_cur = 0, nr_tmp = 0;       // number of valid residual partials in d_rpart / d_rpart_tmp
   bool feat_cur_valid = false;      // d_feat / d_rpart describe d_poses
   double *d_Gt = nullptr;           // [Kcols][npad]  factored Hessian columns (k-major)
+  // the fused trial evaluation (k_moments_factors) leaves the TRIAL poses' factors here; swapped in when the step is accepted
+  double *d_Gt2 = nullptr, *d_dpart2 = nullptr;
+  size_t cap_Gt2 = 0, cap_dpart2 = 0;
+  bool gt_cur_valid = false;        // d_Gt / d_dpart (and d_feat / d_rpart) describe d_poses: the next evaluation starts at the SYRK
+  int gt_parity = 0;                // flips with every (d_Gt, d_Gt2) swap: captured LM graphs hold the pointers
+  bool gt_trial_valid = false;      // d_Gt2 / d_dpart2 describe d_poses_tmp (this iteration's trial)
   size_t cap_cl = 0, cap_fix = 0, cap_coe = 0, cap_C = 0, cap_feat = 0, cap_feat_tmp = 0, cap_rpart = 0, cap_rpart_tmp = 0;   // elements
   size_t cap_slot = 0, cap_items = 0, cap_chunk_ids = 0, cap_csr = 0;
   bool has_fix = false;             // the installed table carries fix clusters (d_fix may be a larger, older allocation)
@@ -108,8 +114,9 @@ struct balm_ctx {
   double *h_scal = nullptr;         // pinned mirror (16) + a ring of damping values on their way to d_scal[SCAL_U] (64)
   int u_ring = 0;
   // one LM iteration as a replayable hipGraph, per (Hessian evaluated?, which pose buffer is current): [4]
-  hipGraphExec_t lm_graph[4] = {nullptr, nullptr, nullptr, nullptr};
-  int lm_graph_form[4] = {-1, -1, -1, -1};
+  static constexpr int LM_GRAPHS = 32;       // (which factor buffer is current, fused trial evaluation, factors current, evaluated, pose-buffer parity)
+  hipGraphExec_t lm_graph[LM_GRAPHS] = {};
+  int lm_graph_form[LM_GRAPHS] = {};
   bool graphs_ok = true;            // false after a failed capture: never tried again on this context
   int parity = 0;                   // toggles with every accepted step (pointer swap of current / trial buffers)
   // host bookkeeping
@@ -147,6 +154,8 @@ int launch_feature_eigen(hipStream_t s, const double *C, const double *fix, cons
 int factors_grid(int W, int nfeat, int form);
 void launch_factors(hipStream_t s, int form, const double *cl, const double *poses, const double *feat, int W,
                     int npad, int f0, int f1, double *Gt, double *dpart, int nblk, const int *slot = nullptr);
+int launch_moments_factors(hipStream_t s, int form, const double *cl, const double *poses, const double *fix, const double *coe, int W,
+                           int npad, int F, double *Gt, double *dpart, int nblk, const int *slot, double *feat, double *rpart);
 struct SyrkPlan { int SG; int nsteps; int Kpad; long nblocks; };   // k-slices, MFMA k-steps per wave, padded K, workgroups
 SyrkPlan plan_syrk(int ntiles, long K);
 void launch_syrk(hipStream_t s, const double *Gt, int npad, int ntiles, const int *tileIJ, const SyrkPlan &p,

@@ -280,6 +280,197 @@ __device__ __forceinline__ void store6(double *dst, const double x[6]) {
   q[0] = t0; q[1] = t1; q[2] = t2;
 }
 
+// One observation (feature a, pose i) of K2: the three Gt columns of the pose, and its gradient / block-diagonal terms added to
+// the lane's accumulators in LDS (sacc[k * Wc + il]).  Shared by k_feature_factors and the fused k_moments_factors.
+struct FeatRec { double NN, iNN, vbar[3], u0[3], u1[3], u2[3], c0, c1, c2, coe; };
+
+template <int FORM>
+__device__ __forceinline__ void obs_factors(const FeatRec &fr, const double P[6], const double v[3], const double N,
+                                            const double *__restrict__ sp, double *__restrict__ sacc, const int Wc, const int il,
+                                            double col0[6], double col1[6], double col2[6]) {
+  const double NN = fr.NN, iNN = fr.iNN, c0 = fr.c0, c1 = fr.c1, c2 = fr.c2, coe = fr.coe;
+  const double *vbar = fr.vbar, *u0 = fr.u0, *u1 = fr.u1, *u2 = fr.u2;
+  if ((int)N > 0) {
+    double R[9], p[3];
+#pragma unroll
+    for (int c = 0; c < 9; c++) R[c] = sp[c * Wc + il];
+#pragma unroll
+    for (int c = 0; c < 3; c++) p[c] = sp[(9 + c) * Wc + il];
+
+    if (FORM == 0) {
+      // ---- LEFT form, bavoxel.hpp:365-402 -------------------------------------------------
+      Obs o;
+      to_world(P, v, N, R, p, o);
+      // M = TC_i [R_i, p_i - vbar]^T (:368-370):  M_top = P' - b vbar^T ,  M_bot = (b - N vbar)^T
+      const double Pw[3][3] = {{o.Pw[0], o.Pw[1], o.Pw[2]}, {o.Pw[1], o.Pw[3], o.Pw[4]}, {o.Pw[2], o.Pw[4], o.Pw[5]}};
+      double cvec[3];
+#pragma unroll
+      for (int r = 0; r < 3; r++) cvec[r] = o.b[r] - N * vbar[r];
+      double m0[3], m1[3], m2[3];
+      const double vu0 = vbar[0] * u0[0] + vbar[1] * u0[1] + vbar[2] * u0[2];
+      const double vu1 = vbar[0] * u1[0] + vbar[1] * u1[1] + vbar[2] * u1[2];
+      const double vu2 = vbar[0] * u2[0] + vbar[1] * u2[1] + vbar[2] * u2[2];
+#pragma unroll
+      for (int r = 0; r < 3; r++) {
+        m0[r] = Pw[r][0] * u0[0] + Pw[r][1] * u0[1] + Pw[r][2] * u0[2] - o.b[r] * vu0;
+        m1[r] = Pw[r][0] * u1[0] + Pw[r][1] * u1[1] + Pw[r][2] * u1[2] - o.b[r] * vu1;
+        m2[r] = Pw[r][0] * u2[0] + Pw[r][1] * u2[1] + Pw[r][2] * u2[2] - o.b[r] * vu2;
+      }
+      const double s0 = cvec[0] * u0[0] + cvec[1] * u0[1] + cvec[2] * u0[2];
+      const double s1 = cvec[0] * u1[0] + cvec[1] * u1[1] + cvec[2] * u1[2];
+      const double s2 = cvec[0] * u2[0] + cvec[1] * u2[1] + cvec[2] * u2[2];
+      // g_k = (U_k M u_0 + U_0 M u_k)/NN (:371-378) with U_k [x;s] = [x cross u_k ; s u_k]
+      double x00[3], x01[3], x10[3], x02[3], x20[3], bxu[3];
+      cross3(m0, u0, x00);
+      cross3(m0, u1, x01); cross3(m1, u0, x10);
+      cross3(m0, u2, x02); cross3(m2, u0, x20);
+      cross3(o.b, u0, bxu);                       // w = (U_0 TC_i)[:,3] = [b x u0 ; N u0] (:380)
+      double grad[6];
+#pragma unroll
+      for (int r = 0; r < 3; r++) {
+        grad[r] = 2.0 * coe * iNN * x00[r];       // coe * g_0 (:381)
+        grad[3 + r] = 2.0 * coe * iNN * s0 * u0[r];
+        col0[r] = c0 * bxu[r];
+        col0[3 + r] = c0 * N * u0[r];
+        col1[r] = c1 * (x01[r] + x10[r]);
+        col1[3 + r] = c1 * (s0 * u1[r] + s1 * u0[r]);
+        col2[r] = c2 * (x02[r] + x20[r]);
+        col2[3 + r] = c2 * (s0 * u2[r] + s2 * u0[r]);
+      }
+      // B_i = coe (Ell + Ell^T in the top-left 3x3) + (2 coe/NN) U_0 TCT_i U_0^T   (:387-388,:397-402)
+      //   Ell + Ell^T = (u0 m0^T + m0 u0^T - 2 (m0.u0) I)/NN
+      //   U_0 TCT U_0^T = [[K P' K^T, (b x u0) u0^T],[u0 (b x u0)^T, N u0 u0^T]],  K = hat(u0)
+      const double K[3][3] = {{0, -u0[2], u0[1]}, {u0[2], 0, -u0[0]}, {-u0[1], u0[0], 0}};
+      double KP[3][3];
+#pragma unroll
+      for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) KP[r][c] = K[r][0] * Pw[0][c] + K[r][1] * Pw[1][c] + K[r][2] * Pw[2][c];
+      const double m0u0 = m0[0] * u0[0] + m0[1] * u0[1] + m0[2] * u0[2];
+      const double k1 = coe * iNN, k2 = 2.0 * coe * iNN;
+      double bd[21];
+      int q = 0;
+#pragma unroll
+      for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int c = r; c < 3; c++) {          // TL, symmetric
+          double kpk = KP[r][0] * K[c][0] + KP[r][1] * K[c][1] + KP[r][2] * K[c][2];
+          double ell = u0[r] * m0[c] + m0[r] * u0[c] - (r == c ? 2.0 * m0u0 : 0.0);
+          bd[q++] = k1 * ell + k2 * kpk;
+        }
+#pragma unroll
+      for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) bd[q++] = k2 * bxu[r] * u0[c];   // TR (rows 0..2, cols 3..5)
+#pragma unroll
+      for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int c = r; c < 3; c++) bd[q++] = k2 * N * u0[r] * u0[c];   // BR, symmetric
+#pragma unroll
+      for (int k = 0; k < 6; k++) sacc[k * Wc + il] += grad[k];
+#pragma unroll
+      for (int k = 0; k < 21; k++) sacc[(6 + k) * Wc + il] += bd[k];
+    } else {
+      // ---- RIGHT form, bavoxel.hpp:93-130 ("Right update.pdf") ----------------------------
+      const double Pf[3][3] = {{P[0], P[1], P[2]}, {P[1], P[3], P[4]}, {P[2], P[4], P[5]}};
+      const double NNi = (double)(int)NN;            // int NN in the reference (:82)
+      const double jNN = 1.0 / NNi;
+      double r3[3];                                   // R^T u0
+#pragma unroll
+      for (int c = 0; c < 3; c++) r3[c] = R[3 * c] * u0[0] + R[3 * c + 1] * u0[1] + R[3 * c + 2] * u0[2];
+      double ai[3];
+      cross3(v, r3, ai);                              // hat(v) r
+      double ti[3];
+#pragma unroll
+      for (int r = 0; r < 3; r++) ti[r] = p[r] - vbar[r];
+      const double s = u0[0] * ti[0] + u0[1] * ti[1] + u0[2] * ti[2];
+      double Pr[3];
+#pragma unroll
+      for (int r = 0; r < 3; r++) Pr[r] = Pf[r][0] * r3[0] + Pf[r][1] * r3[1] + Pf[r][2] * r3[2];
+      // combo1 = hat(P r) + hat(v) s ; combo2 = R v + n t
+      const double h1[3] = {Pr[0] + v[0] * s, Pr[1] + v[1] * s, Pr[2] + v[2] * s};   // combo1 = hat(h1)
+      const double C1[3][3] = {{0, -h1[2], h1[1]}, {h1[2], 0, -h1[0]}, {-h1[1], h1[0], 0}};
+      const double rh[3][3] = {{0, -r3[2], r3[1]}, {r3[2], 0, -r3[0]}, {-r3[1], r3[0], 0}};
+      double Rv[3], combo2[3];
+#pragma unroll
+      for (int r = 0; r < 3; r++) {
+        Rv[r] = R[r] * v[0] + R[3 + r] * v[1] + R[6 + r] * v[2];
+        combo2[r] = Rv[r] + N * ti[r];
+      }
+      // Auk = [ ((R P + t v^T) rh - R combo1) , (combo2 u0^T + (combo2.u0) I) ] / NN     (3x6)
+      double E[3][3];      // R P + t v^T
+#pragma unroll
+      for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int c = 0; c < 3; c++)
+          E[r][c] = R[r] * Pf[0][c] + R[3 + r] * Pf[1][c] + R[6 + r] * Pf[2][c] + ti[r] * v[c];
+      double Auk[3][6];
+      const double c2u = combo2[0] * u0[0] + combo2[1] * u0[1] + combo2[2] * u0[2];
+#pragma unroll
+      for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+          double erh = E[r][0] * rh[0][c] + E[r][1] * rh[1][c] + E[r][2] * rh[2][c];
+          double rc1 = R[r] * C1[0][c] + R[3 + r] * C1[1][c] + R[6 + r] * C1[2][c];
+          Auk[r][c] = (erh - rc1) * jNN;
+          Auk[r][3 + c] = (combo2[r] * u0[c] + (r == c ? c2u : 0.0)) * jNN;
+        }
+      double jjt[6], a1[6], a2[6];
+#pragma unroll
+      for (int c = 0; c < 6; c++) {
+        jjt[c] = Auk[0][c] * u0[0] + Auk[1][c] * u0[1] + Auk[2][c] * u0[2];
+        a1[c] = Auk[0][c] * u1[0] + Auk[1][c] * u1[1] + Auk[2][c] * u1[2];
+        a2[c] = Auk[0][c] * u2[0] + Auk[1][c] * u2[1] + Auk[2][c] * u2[2];
+      }
+      // Gt columns: c0' [a_i ; n u0], c1' Auk^T u1, c2' Auk^T u2 with the 1/NN already in Auk.
+      // FT_C* carry 1/NN (double NN); the right form divides by the int NN -> rescale.
+      const double r0 = c0 * NN * jNN, r1 = c1 * NN, r2 = c2 * NN;
+#pragma unroll
+      for (int r = 0; r < 3; r++) {
+        col0[r] = r0 * ai[r];
+        col0[3 + r] = r0 * N * u0[r];
+      }
+#pragma unroll
+      for (int c = 0; c < 6; c++) { col1[c] = r1 * a1[c]; col2[c] = r2 * a2[c]; }
+      // B_i (right) = Hess_ii + (Gt Gt^T)_ii:
+      //   TL = coe (2/NN (combo1 - rh P) rh - 0.5 hat(jjt[0:3]))   (general 3x3)
+      //   TR = coe 2/NN a_i u0^T ; BR = coe 2 n/NN u0 u0^T
+      double D1[3][3];
+#pragma unroll
+      for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int c = 0; c < 3; c++)
+          D1[r][c] = C1[r][c] - (rh[r][0] * Pf[0][c] + rh[r][1] * Pf[1][c] + rh[r][2] * Pf[2][c]);
+      const double hj[3][3] = {{0, -jjt[2], jjt[1]}, {jjt[2], 0, -jjt[0]}, {-jjt[1], jjt[0], 0}};
+      const double k2 = 2.0 * coe * jNN;
+      double bd[24];
+      int q = 0;
+#pragma unroll
+      for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+          double d1rh = D1[r][0] * rh[0][c] + D1[r][1] * rh[1][c] + D1[r][2] * rh[2][c];
+          bd[q++] = k2 * d1rh - 0.5 * coe * hj[r][c];
+        }
+#pragma unroll
+      for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) bd[q++] = k2 * ai[r] * u0[c];
+#pragma unroll
+      for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int c = r; c < 3; c++) bd[q++] = k2 * N * u0[r] * u0[c];
+#pragma unroll
+      for (int k = 0; k < 6; k++) sacc[k * Wc + il] += coe * jjt[k];
+#pragma unroll
+      for (int k = 0; k < 24; k++) sacc[(6 + k) * Wc + il] += bd[k];
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 6; k++) col0[k] = col1[k] = col2[k] = 0.0;
+  }
+}
+
 template <int FORM>
 __global__ __launch_bounds__(256) void k_feature_factors(const double *__restrict__ cl,
                                                          const double *__restrict__ poses,
@@ -299,7 +490,9 @@ __global__ __launch_bounds__(256) void k_feature_factors(const double *__restric
   for (int t = threadIdx.x; t < DACC * Wc; t += blockDim.x) sacc[t] = 0.0;
   __syncthreads();
 
-  // cluster of (feature a, pose i): ten coalesced streams, loaded one feature ahead of its use
+  // cluster of (feature a, pose i): ten coalesced streams, loaded one feature ahead of its use.  (Two features ahead -- two
+  // register sets, the loop unrolled by two, 226 VGPRs -- measured SLOWER at config 2: 0.584 vs 0.551 ms, round 3; the kernel
+  // moves 2.24 GB at 4.1 TB/s, 64 % of it writes, and is not short of loads in flight.)
   double nxt[10];
   auto fetch = [&](int a, int i) {
     const double *ca = cl + (size_t)a * 10 * W + i;
@@ -311,13 +504,8 @@ __global__ __launch_bounds__(256) void k_feature_factors(const double *__restric
 
   for (int a = f0 + blockIdx.x; a < f1; a += gridDim.x) {
     const double *f = feat + (size_t)a * FEAT_STRIDE;
-    const double NN = f[FT_NN];
-    const double vbar[3] = {f[FT_VBAR], f[FT_VBAR + 1], f[FT_VBAR + 2]};
-    const double u0[3] = {f[FT_U0], f[FT_U0 + 1], f[FT_U0 + 2]};
-    const double u1[3] = {f[FT_U1], f[FT_U1 + 1], f[FT_U1 + 2]};
-    const double u2[3] = {f[FT_U2], f[FT_U2 + 1], f[FT_U2 + 2]};
-    const double c0 = f[FT_C0], c1 = f[FT_C1], c2 = f[FT_C2], coe = f[FT_COE];
-    const double iNN = 1.0 / NN;
+    const FeatRec fr = {f[FT_NN], 1.0 / f[FT_NN], {f[FT_VBAR], f[FT_VBAR + 1], f[FT_VBAR + 2]}, {f[FT_U0], f[FT_U0 + 1], f[FT_U0 + 2]},
+                        {f[FT_U1], f[FT_U1 + 1], f[FT_U1 + 2]}, {f[FT_U2], f[FT_U2 + 1], f[FT_U2 + 2]}, f[FT_C0], f[FT_C1], f[FT_C2], f[FT_COE]};
     const double *ca = cl + (size_t)a * 10 * W;
     double *g0 = Gt + (size_t)(3 * (slot ? slot[a] : a - f0)) * npad;      // slot: the block-sparse plan's column order
 
@@ -338,185 +526,7 @@ __global__ __launch_bounds__(256) void k_feature_factors(const double *__restric
       }
       const double N = il == (int)threadIdx.x ? nxt[9] : ca[(size_t)9 * W + i];
       if (il == (int)threadIdx.x && a + (int)gridDim.x < f1) fetch(a + gridDim.x, i_first);
-      if ((int)N > 0) {
-        double R[9], p[3];
-#pragma unroll
-        for (int c = 0; c < 9; c++) R[c] = sp[c * Wc + il];
-#pragma unroll
-        for (int c = 0; c < 3; c++) p[c] = sp[(9 + c) * Wc + il];
-
-        if (FORM == 0) {
-          // ---- LEFT form, bavoxel.hpp:365-402 -------------------------------------------------
-          Obs o;
-          to_world(P, v, N, R, p, o);
-          // M = TC_i [R_i, p_i - vbar]^T (:368-370):  M_top = P' - b vbar^T ,  M_bot = (b - N vbar)^T
-          const double Pw[3][3] = {{o.Pw[0], o.Pw[1], o.Pw[2]}, {o.Pw[1], o.Pw[3], o.Pw[4]}, {o.Pw[2], o.Pw[4], o.Pw[5]}};
-          double cvec[3];
-#pragma unroll
-          for (int r = 0; r < 3; r++) cvec[r] = o.b[r] - N * vbar[r];
-          double m0[3], m1[3], m2[3];
-          const double vu0 = vbar[0] * u0[0] + vbar[1] * u0[1] + vbar[2] * u0[2];
-          const double vu1 = vbar[0] * u1[0] + vbar[1] * u1[1] + vbar[2] * u1[2];
-          const double vu2 = vbar[0] * u2[0] + vbar[1] * u2[1] + vbar[2] * u2[2];
-#pragma unroll
-          for (int r = 0; r < 3; r++) {
-            m0[r] = Pw[r][0] * u0[0] + Pw[r][1] * u0[1] + Pw[r][2] * u0[2] - o.b[r] * vu0;
-            m1[r] = Pw[r][0] * u1[0] + Pw[r][1] * u1[1] + Pw[r][2] * u1[2] - o.b[r] * vu1;
-            m2[r] = Pw[r][0] * u2[0] + Pw[r][1] * u2[1] + Pw[r][2] * u2[2] - o.b[r] * vu2;
-          }
-          const double s0 = cvec[0] * u0[0] + cvec[1] * u0[1] + cvec[2] * u0[2];
-          const double s1 = cvec[0] * u1[0] + cvec[1] * u1[1] + cvec[2] * u1[2];
-          const double s2 = cvec[0] * u2[0] + cvec[1] * u2[1] + cvec[2] * u2[2];
-          // g_k = (U_k M u_0 + U_0 M u_k)/NN (:371-378) with U_k [x;s] = [x cross u_k ; s u_k]
-          double x00[3], x01[3], x10[3], x02[3], x20[3], bxu[3];
-          cross3(m0, u0, x00);
-          cross3(m0, u1, x01); cross3(m1, u0, x10);
-          cross3(m0, u2, x02); cross3(m2, u0, x20);
-          cross3(o.b, u0, bxu);                       // w = (U_0 TC_i)[:,3] = [b x u0 ; N u0] (:380)
-          double grad[6];
-#pragma unroll
-          for (int r = 0; r < 3; r++) {
-            grad[r] = 2.0 * coe * iNN * x00[r];       // coe * g_0 (:381)
-            grad[3 + r] = 2.0 * coe * iNN * s0 * u0[r];
-            col0[r] = c0 * bxu[r];
-            col0[3 + r] = c0 * N * u0[r];
-            col1[r] = c1 * (x01[r] + x10[r]);
-            col1[3 + r] = c1 * (s0 * u1[r] + s1 * u0[r]);
-            col2[r] = c2 * (x02[r] + x20[r]);
-            col2[3 + r] = c2 * (s0 * u2[r] + s2 * u0[r]);
-          }
-          // B_i = coe (Ell + Ell^T in the top-left 3x3) + (2 coe/NN) U_0 TCT_i U_0^T   (:387-388,:397-402)
-          //   Ell + Ell^T = (u0 m0^T + m0 u0^T - 2 (m0.u0) I)/NN
-          //   U_0 TCT U_0^T = [[K P' K^T, (b x u0) u0^T],[u0 (b x u0)^T, N u0 u0^T]],  K = hat(u0)
-          const double K[3][3] = {{0, -u0[2], u0[1]}, {u0[2], 0, -u0[0]}, {-u0[1], u0[0], 0}};
-          double KP[3][3];
-#pragma unroll
-          for (int r = 0; r < 3; r++)
-#pragma unroll
-            for (int c = 0; c < 3; c++) KP[r][c] = K[r][0] * Pw[0][c] + K[r][1] * Pw[1][c] + K[r][2] * Pw[2][c];
-          const double m0u0 = m0[0] * u0[0] + m0[1] * u0[1] + m0[2] * u0[2];
-          const double k1 = coe * iNN, k2 = 2.0 * coe * iNN;
-          double bd[21];
-          int q = 0;
-#pragma unroll
-          for (int r = 0; r < 3; r++)
-#pragma unroll
-            for (int c = r; c < 3; c++) {          // TL, symmetric
-              double kpk = KP[r][0] * K[c][0] + KP[r][1] * K[c][1] + KP[r][2] * K[c][2];
-              double ell = u0[r] * m0[c] + m0[r] * u0[c] - (r == c ? 2.0 * m0u0 : 0.0);
-              bd[q++] = k1 * ell + k2 * kpk;
-            }
-#pragma unroll
-          for (int r = 0; r < 3; r++)
-#pragma unroll
-            for (int c = 0; c < 3; c++) bd[q++] = k2 * bxu[r] * u0[c];   // TR (rows 0..2, cols 3..5)
-#pragma unroll
-          for (int r = 0; r < 3; r++)
-#pragma unroll
-            for (int c = r; c < 3; c++) bd[q++] = k2 * N * u0[r] * u0[c];   // BR, symmetric
-#pragma unroll
-          for (int k = 0; k < 6; k++) sacc[k * Wc + il] += grad[k];
-#pragma unroll
-          for (int k = 0; k < 21; k++) sacc[(6 + k) * Wc + il] += bd[k];
-        } else {
-          // ---- RIGHT form, bavoxel.hpp:93-130 ("Right update.pdf") ----------------------------
-          const double Pf[3][3] = {{P[0], P[1], P[2]}, {P[1], P[3], P[4]}, {P[2], P[4], P[5]}};
-          const double NNi = (double)(int)NN;            // int NN in the reference (:82)
-          const double jNN = 1.0 / NNi;
-          double r3[3];                                   // R^T u0
-#pragma unroll
-          for (int c = 0; c < 3; c++) r3[c] = R[3 * c] * u0[0] + R[3 * c + 1] * u0[1] + R[3 * c + 2] * u0[2];
-          double ai[3];
-          cross3(v, r3, ai);                              // hat(v) r
-          double ti[3];
-#pragma unroll
-          for (int r = 0; r < 3; r++) ti[r] = p[r] - vbar[r];
-          const double s = u0[0] * ti[0] + u0[1] * ti[1] + u0[2] * ti[2];
-          double Pr[3];
-#pragma unroll
-          for (int r = 0; r < 3; r++) Pr[r] = Pf[r][0] * r3[0] + Pf[r][1] * r3[1] + Pf[r][2] * r3[2];
-          // combo1 = hat(P r) + hat(v) s ; combo2 = R v + n t
-          const double h1[3] = {Pr[0] + v[0] * s, Pr[1] + v[1] * s, Pr[2] + v[2] * s};   // combo1 = hat(h1)
-          const double C1[3][3] = {{0, -h1[2], h1[1]}, {h1[2], 0, -h1[0]}, {-h1[1], h1[0], 0}};
-          const double rh[3][3] = {{0, -r3[2], r3[1]}, {r3[2], 0, -r3[0]}, {-r3[1], r3[0], 0}};
-          double Rv[3], combo2[3];
-#pragma unroll
-          for (int r = 0; r < 3; r++) {
-            Rv[r] = R[r] * v[0] + R[3 + r] * v[1] + R[6 + r] * v[2];
-            combo2[r] = Rv[r] + N * ti[r];
-          }
-          // Auk = [ ((R P + t v^T) rh - R combo1) , (combo2 u0^T + (combo2.u0) I) ] / NN     (3x6)
-          double E[3][3];      // R P + t v^T
-#pragma unroll
-          for (int r = 0; r < 3; r++)
-#pragma unroll
-            for (int c = 0; c < 3; c++)
-              E[r][c] = R[r] * Pf[0][c] + R[3 + r] * Pf[1][c] + R[6 + r] * Pf[2][c] + ti[r] * v[c];
-          double Auk[3][6];
-          const double c2u = combo2[0] * u0[0] + combo2[1] * u0[1] + combo2[2] * u0[2];
-#pragma unroll
-          for (int r = 0; r < 3; r++)
-#pragma unroll
-            for (int c = 0; c < 3; c++) {
-              double erh = E[r][0] * rh[0][c] + E[r][1] * rh[1][c] + E[r][2] * rh[2][c];
-              double rc1 = R[r] * C1[0][c] + R[3 + r] * C1[1][c] + R[6 + r] * C1[2][c];
-              Auk[r][c] = (erh - rc1) * jNN;
-              Auk[r][3 + c] = (combo2[r] * u0[c] + (r == c ? c2u : 0.0)) * jNN;
-            }
-          double jjt[6], a1[6], a2[6];
-#pragma unroll
-          for (int c = 0; c < 6; c++) {
-            jjt[c] = Auk[0][c] * u0[0] + Auk[1][c] * u0[1] + Auk[2][c] * u0[2];
-            a1[c] = Auk[0][c] * u1[0] + Auk[1][c] * u1[1] + Auk[2][c] * u1[2];
-            a2[c] = Auk[0][c] * u2[0] + Auk[1][c] * u2[1] + Auk[2][c] * u2[2];
-          }
-          // Gt columns: c0' [a_i ; n u0], c1' Auk^T u1, c2' Auk^T u2 with the 1/NN already in Auk.
-          // FT_C* carry 1/NN (double NN); the right form divides by the int NN -> rescale.
-          const double r0 = c0 * NN * jNN, r1 = c1 * NN, r2 = c2 * NN;
-#pragma unroll
-          for (int r = 0; r < 3; r++) {
-            col0[r] = r0 * ai[r];
-            col0[3 + r] = r0 * N * u0[r];
-          }
-#pragma unroll
-          for (int c = 0; c < 6; c++) { col1[c] = r1 * a1[c]; col2[c] = r2 * a2[c]; }
-          // B_i (right) = Hess_ii + (Gt Gt^T)_ii:
-          //   TL = coe (2/NN (combo1 - rh P) rh - 0.5 hat(jjt[0:3]))   (general 3x3)
-          //   TR = coe 2/NN a_i u0^T ; BR = coe 2 n/NN u0 u0^T
-          double D1[3][3];
-#pragma unroll
-          for (int r = 0; r < 3; r++)
-#pragma unroll
-            for (int c = 0; c < 3; c++)
-              D1[r][c] = C1[r][c] - (rh[r][0] * Pf[0][c] + rh[r][1] * Pf[1][c] + rh[r][2] * Pf[2][c]);
-          const double hj[3][3] = {{0, -jjt[2], jjt[1]}, {jjt[2], 0, -jjt[0]}, {-jjt[1], jjt[0], 0}};
-          const double k2 = 2.0 * coe * jNN;
-          double bd[24];
-          int q = 0;
-#pragma unroll
-          for (int r = 0; r < 3; r++)
-#pragma unroll
-            for (int c = 0; c < 3; c++) {
-              double d1rh = D1[r][0] * rh[0][c] + D1[r][1] * rh[1][c] + D1[r][2] * rh[2][c];
-              bd[q++] = k2 * d1rh - 0.5 * coe * hj[r][c];
-            }
-#pragma unroll
-          for (int r = 0; r < 3; r++)
-#pragma unroll
-            for (int c = 0; c < 3; c++) bd[q++] = k2 * ai[r] * u0[c];
-#pragma unroll
-          for (int r = 0; r < 3; r++)
-#pragma unroll
-            for (int c = r; c < 3; c++) bd[q++] = k2 * N * u0[r] * u0[c];
-#pragma unroll
-          for (int k = 0; k < 6; k++) sacc[k * Wc + il] += coe * jjt[k];
-#pragma unroll
-          for (int k = 0; k < 24; k++) sacc[(6 + k) * Wc + il] += bd[k];
-        }
-      } else {
-#pragma unroll
-        for (int k = 0; k < 6; k++) col0[k] = col1[k] = col2[k] = 0.0;
-      }
+      obs_factors<FORM>(fr, P, v, N, sp, sacc, Wc, il, col0, col1, col2);
       store6(g0 + 6 * i, col0);
       store6(g0 + (size_t)npad + 6 * i, col1);
       store6(g0 + (size_t)2 * npad + 6 * i, col2);
@@ -528,6 +538,150 @@ __global__ __launch_bounds__(256) void k_feature_factors(const double *__restric
     const int k = t / wc, il = t - k * wc;
     dp[(size_t)k * W + il] = sacc[k * Wc + il];
   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1 + K1b + K2 in ONE pass over the clusters (round 3): the LM loop evaluates the residual at the trial poses (K1, K1b:
+// 800 MB read at config 3) and, if the step is accepted, the factors at the very same poses one iteration later (K2: the same
+// 800 MB again).  Here the trial evaluation also leaves the factors: a workgroup takes one feature at a time like K2 (a lane
+// = a pose), but first reduces the lanes' world-frame clusters to the feature's moments, a dedicated wavefront turns them
+// into the eigen record (the same Jacobi as K1b; ~4 us of dependent arithmetic -- it works on feature a + G while the pose
+// lanes run the factors of feature a, whose record it produced one step earlier), and the pose lanes go on to the factors
+// with the cluster still in their registers.  If the step is accepted the next Hessian evaluation starts at the SYRK; if
+// not, the Gt of the current poses is still there (two Gt buffers).  Windows up to 256 poses (one pose per lane).
+// ------------------------------------------------------------------------------------------------
+template <int FORM>
+__global__ __launch_bounds__(320, 3) void k_moments_factors(const double *__restrict__ cl, const double *__restrict__ poses,
+                                                         const double *__restrict__ fix, const double *__restrict__ coe_in, int W, int npad,
+                                                         int F, double *__restrict__ Gt, double *__restrict__ dpart,
+                                                         const int *__restrict__ slot, double *__restrict__ feat_out,
+                                                         double *__restrict__ rpart) {
+  constexpr int DACC = FORM == 0 ? DACC_LEFT : DACC_RIGHT;
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  const int npl = (int)blockDim.x - 64, npw = npl >> 6;      // pose lanes / waves; the last wave is the eigen wave
+  double *sp = sm;                                           // [12][W] poses
+  double *sacc = sm + 12 * W;                                // [DACC][W]
+  double *mom = sacc + DACC * W;                             // [2][4][10] partial moments per pose wave
+  double *eig = mom + 80;                                    // [2][FEAT_STRIDE] eigen records
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const bool is_pose = tid < npl;
+  for (int t = tid; t < 12 * W; t += blockDim.x) {
+    const int i = t / 12, c = t - 12 * i;
+    sp[c * W + i] = poses[t];
+  }
+  for (int t = tid; t < DACC * W; t += blockDim.x) sacc[t] = 0.0;
+  __syncthreads();
+  const int il = tid, G = gridDim.x, a0 = blockIdx.x;
+  const bool has_pose = is_pose && il < W;
+  double cur[10], nxt[10];
+#pragma unroll
+  for (int c = 0; c < 10; c++) cur[c] = nxt[c] = 0.0;
+  auto fetch = [&](int a, double (&dst)[10]) {
+    const double *ca = cl + (size_t)a * 10 * W + il;
+#pragma unroll
+    for (int c = 0; c < 10; c++) dst[c] = ca[(size_t)c * W];
+  };
+  // the lane's cluster in the world frame, summed over the wave -> mom[buf][wave][10]
+  auto partial_moments = [&](const double (&c10)[10], int buf) {
+    double m[10];
+#pragma unroll
+    for (int c = 0; c < 10; c++) m[c] = 0.0;
+    if (has_pose && (int)c10[9] > 0) {
+      double R[9], p[3];
+#pragma unroll
+      for (int c = 0; c < 9; c++) R[c] = sp[c * W + il];
+#pragma unroll
+      for (int c = 0; c < 3; c++) p[c] = sp[(9 + c) * W + il];
+      Obs o;
+      to_world(c10, c10 + 6, c10[9], R, p, o);
+#pragma unroll
+      for (int c = 0; c < 6; c++) m[c] = o.Pw[c];
+#pragma unroll
+      for (int c = 0; c < 3; c++) m[6 + c] = o.b[c];
+      m[9] = c10[9];
+    }
+#pragma unroll
+    for (int c = 0; c < 10; c++) m[c] = wave_sum(m[c]);
+    if (lane == 0) {
+#pragma unroll
+      for (int c = 0; c < 10; c++) mom[(buf * 4 + wv) * 10 + c] = m[c];
+    }
+  };
+  double res = 0.0;
+  // eigen record of feature a from the partial moments (K1b's arithmetic), wave-uniform
+  auto eigen_step = [&](int a, int buf) {
+    double c[10];
+#pragma unroll
+    for (int k = 0; k < 10; k++) {
+      double t = mom[(buf * 4) * 10 + k];
+      for (int w = 1; w < npw; w++) t += mom[(buf * 4 + w) * 10 + k];
+      c[k] = t;
+    }
+    if (fix) {
+#pragma unroll
+      for (int k = 0; k < 10; k++) c[k] += fix[(size_t)a * 10 + k];
+    }
+    const double NN = c[9], inv = 1.0 / NN;
+    const double vb0 = c[6] * inv, vb1 = c[7] * inv, vb2 = c[8] * inv;
+    double lam[3], U[3][3];
+    eig3_jacobi(c[0] * inv - vb0 * vb0, c[1] * inv - vb0 * vb1, c[2] * inv - vb0 * vb2, c[3] * inv - vb1 * vb1,
+                c[4] * inv - vb1 * vb2, c[5] * inv - vb2 * vb2, lam, U);
+    const double w = coe_in[a];
+    res += w * lam[0];
+    double rec[FEAT_STRIDE];
+#pragma unroll
+    for (int k = 0; k < FEAT_STRIDE; k++) rec[k] = 0.0;
+    rec[FT_NN] = NN;
+    rec[FT_VBAR] = vb0; rec[FT_VBAR + 1] = vb1; rec[FT_VBAR + 2] = vb2;
+    rec[FT_LAM] = lam[0]; rec[FT_LAM + 1] = lam[1]; rec[FT_LAM + 2] = lam[2];
+#pragma unroll
+    for (int k = 0; k < 3; k++) { rec[FT_U0 + k] = U[k][0]; rec[FT_U1 + k] = U[k][1]; rec[FT_U2 + k] = U[k][2]; }
+    rec[FT_C0] = sqrt(2.0 * w) * inv;
+    rec[FT_C1] = sqrt(2.0 * w / (lam[1] - lam[0])) * inv;
+    rec[FT_C2] = sqrt(2.0 * w / (lam[2] - lam[0])) * inv;
+    rec[FT_COE] = w;
+    if (lane == 0) {
+#pragma unroll
+      for (int k = 0; k < FEAT_STRIDE; k++) { eig[buf * FEAT_STRIDE + k] = rec[k]; feat_out[(size_t)a * FEAT_STRIDE + k] = rec[k]; }
+    }
+  };
+
+  if (a0 < F) {
+    if (has_pose) fetch(a0, cur);
+    if (is_pose) partial_moments(cur, 0);
+    if (has_pose && a0 + G < F) fetch(a0 + G, nxt);
+  }
+  __syncthreads();
+  if (!is_pose && a0 < F) eigen_step(a0, 0);
+  __syncthreads();
+  int b = 0;
+  for (int a = a0; a < F; a += G, b ^= 1) {
+    const bool has_next = a + G < F;
+    if (is_pose && has_next) partial_moments(nxt, b ^ 1);
+    __syncthreads();                                           // the next feature's partial moments are in LDS
+    if (!is_pose) {
+      if (has_next) eigen_step(a + G, b ^ 1);
+    } else {
+      const double *f = eig + b * FEAT_STRIDE;
+      const FeatRec fr = {f[FT_NN], 1.0 / f[FT_NN], {f[FT_VBAR], f[FT_VBAR + 1], f[FT_VBAR + 2]}, {f[FT_U0], f[FT_U0 + 1], f[FT_U0 + 2]},
+                          {f[FT_U1], f[FT_U1 + 1], f[FT_U1 + 2]}, {f[FT_U2], f[FT_U2 + 1], f[FT_U2 + 2]}, f[FT_C0], f[FT_C1], f[FT_C2], f[FT_COE]};
+      if (has_pose) {
+        double col0[6], col1[6], col2[6];
+        obs_factors<FORM>(fr, cur, cur + 6, cur[9], sp, sacc, W, il, col0, col1, col2);
+        double *g0 = Gt + (size_t)(3 * (slot ? slot[a] : a)) * npad;
+        store6(g0 + 6 * il, col0);
+        store6(g0 + (size_t)npad + 6 * il, col1);
+        store6(g0 + (size_t)2 * npad + 6 * il, col2);
+#pragma unroll
+        for (int c = 0; c < 10; c++) cur[c] = nxt[c];
+        if (a + 2 * G < F) fetch(a + 2 * G, nxt);
+      }
+    }
+    __syncthreads();                                           // the next record is in LDS; this one and the partial moments are free
+  }
+  double *dp = dpart + (size_t)blockIdx.x * DACC * W;
+  for (int t = tid; t < DACC * W; t += blockDim.x) dp[t] = sacc[t];
+  if (!is_pose && lane == 0) rpart[blockIdx.x] = res;
 }
 
 // poses per workgroup of the factor kernel: the whole window while its accumulators fit in LDS, else chunks
@@ -551,7 +705,22 @@ hipError_t prepare_device_accum() {
   hipError_t e = hipFuncSetAttribute((const void *)k_world_moments, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_feature_factors<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_feature_factors<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_moments_factors<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_moments_factors<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   return e;
+}
+
+// the fused trial evaluation: residual partials (one per workgroup: returns their number), eigen records, Gt, per-pose partials
+int launch_moments_factors(hipStream_t s, int form, const double *cl, const double *poses, const double *fix, const double *coe, int W,
+                           int npad, int F, double *Gt, double *dpart, int nblk, const int *slot, double *feat, double *rpart) {
+  const int dacc = form == 0 ? DACC_LEFT : DACC_RIGHT;
+  const size_t lds = (size_t)((12 + dacc) * W + 80 + 2 * FEAT_STRIDE) * sizeof(double);
+  const int bs = (W <= 64 ? 64 : (W <= 128 ? 128 : 256)) + 64;
+  if (form == 0)
+    hipLaunchKernelGGL(k_moments_factors<0>, dim3(nblk), dim3(bs), lds, s, cl, poses, fix, coe, W, npad, F, Gt, dpart, slot, feat, rpart);
+  else
+    hipLaunchKernelGGL(k_moments_factors<1>, dim3(nblk), dim3(bs), lds, s, cl, poses, fix, coe, W, npad, F, Gt, dpart, slot, feat, rpart);
+  return nblk;
 }
 
 void launch_factors(hipStream_t s, int form, const double *cl, const double *poses, const double *feat, int W,

@@ -169,6 +169,48 @@ def test_damping_iter_follows_oracle_trajectory(case):
     c.close()
 
 
+@pytest.mark.parametrize("case", [
+    # (seed, W, F, pts, drop, with_fix, form, u0, max_iter, graph)
+    (1, 20, 20, 40, 0.0, False, 0, 0.01, 10, False),
+    (1, 20, 20, 40, 0.0, False, 0, 0.01, 10, True),     # replayed hipGraphs hold the (swapped) factor buffers
+    (2, 7, 30, 12, 0.3, True, 0, 0.1, 12, False),       # fix clusters, ragged window
+    (6, 30, 150, 10, 0.4, False, 1, 0.01, 10, False),   # right form, sparse plan (slot order of the columns)
+    (7, 64, 400, 6, 0.0, False, 0, 0.1, 20, False),
+    (11, 200, 900, 6, 0.5, False, 0, 0.1, 8, False),    # the bench window's width, half the observations gone
+    (12, 256, 300, 6, 0.2, True, 1, 0.1, 6, False),     # the widest window the one-pass kernel takes
+    (13, 300, 200, 6, 0.2, False, 0, 0.1, 6, False),    # wider: both runs take K1 + K1b + K2 (the switch is a no-op)
+])
+def test_one_pass_trial_evaluation_matches_the_three_kernel_path(case, monkeypatch):
+    """k_moments_factors (round 3: the trial evaluation of the LM loop reads the clusters ONCE and leaves residual, eigen
+    records AND the factors G~ / diagonal partials of the trial poses, which an accepted step's Hessian evaluation starts
+    from) against the K1 + K1b -> K2 sequence (the default; the one-pass kernel is BALM_FUSE_TRIAL=1): same decisions, residuals to rounding,
+    same poses; and against the oracle.  Then the context must still evaluate correctly (no stale factors are reused)."""
+    seed, W, F, pts, drop, wf, form, u0, mi, graph = case
+    sc, fix = make_scene(seed, W, F, pts, drop, wf)
+    if graph:
+        monkeypatch.setenv("BALM_GRAPH", "1")
+    c = ctx_for(sc, fix)
+    monkeypatch.delenv("BALM_FUSE_TRIAL", raising=False)
+    pa, la = c.damping_iter(sc.poses_init, form=form, u0=u0, max_iter=mi, min_planes=0)
+    monkeypatch.setenv("BALM_FUSE_TRIAL", "1")          # opt-in (it is the slower of the two on the box, see balm_capi.hip)
+    pb, lb = c.damping_iter(sc.poses_init, form=form, u0=u0, max_iter=mi, min_planes=0)
+    monkeypatch.delenv("BALM_FUSE_TRIAL")               # and back: graphs and buffers of the other mode must not leak in
+    pc, lc = c.damping_iter(sc.poses_init, form=form, u0=u0, max_iter=mi, min_planes=0)
+    assert np.array_equal(pa, pc) and np.array_equal(la, lc)
+    assert len(la) == len(lb) and np.array_equal(la[:, 6], lb[:, 6])
+    assert np.allclose(la[:, :2], lb[:, :2], rtol=1e-10, atol=0) and np.allclose(la[:, 2], lb[:, 2], rtol=1e-7)
+    assert np.abs(pa - pb).max() < 1e-9
+    assert la[:, 6].sum() >= 2                          # accepted steps: the factor buffers were swapped in
+    oo, lo = orc.damping_iter(form, sc.clusters, fix, sc.coeffs, sc.poses_init, u0, mi)
+    assert len(lb) == len(lo) and np.allclose(lb[:, :2], lo[:, :2], rtol=1e-8)
+    rot, tr = pose_errors(pb, oo)
+    assert rot.max() <= ROT_TOL_RAD and tr.max() <= TRANS_TOL_M
+    H, g, r = c.evaluate(form, sc.poses_init)
+    Ho, go, ro = orc.evaluate(form, sc.clusters, fix, sc.coeffs, sc.poses_init)
+    assert rel_err(H, Ho) < HTOL and rel_err(g, go) < HTOL and abs(r - ro) / ro < 1e-12
+    c.close()
+
+
 def test_too_few_planes_is_an_error_code_not_exit():
     sc, _ = make_scene(40, 10, 12, 6)
     c = ctx_for(sc)
