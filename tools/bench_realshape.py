@@ -25,9 +25,11 @@ F, W = cl.shape[:2]
 na = (cl[..., 9] > 0).sum(1)
 print("%s: W=%d F=%d S=%d fill=%.1f%%" % (what, W, F, na.sum(), 100.0 * (na * (na + 1) / 2).sum() / (F * W * (W + 1) / 2)))
 for syrk in ("dense", "sparse"):
-    for solve in ("launches", "fused"):
+    for solve in ("launches", "fused", "default"):       # default at this window: k_ldl_chain (round 3)
         os.environ["BALM_SYRK"] = syrk
         os.environ["BALM_SOLVE"] = solve
+        if solve == "default":
+            os.environ.pop("BALM_SOLVE")
         c = capi.Context(W, 0, capi.FLAG_TIMING)
         c.set_features(cl, None, co)
         c.damping_iter(poses, u0=0.01, max_iter=3, force_hess=True, no_stop=True, reanchor=False)
