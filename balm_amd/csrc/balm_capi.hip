@@ -768,12 +768,8 @@ static int one_window_add_scan(balm_ctx *ctx, const float *xyz, long n_pts, cons
   if (int rcw = window_alive(ctx, "balm_window_add_scan")) return rcw;
   if (!xyz || !pose12 || n_pts < 1) { ctx->err = "balm_window_add_scan: bad argument"; return BALM_ERR_ARG; }
   HIP_TRY(hipSetDevice(ctx->device));
-  int rc = stage_begin(ctx, (size_t)n_pts * 12);
-  if (rc) return rc;
-  float *d_xyz = stage_take<float>(ctx, (size_t)n_pts * 3);
-  HIP_TRY(hipMemcpyAsync(d_xyz, xyz, (size_t)n_pts * 3 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
   Span sp(ctx, BALM_T_VOXEL);
-  return window_rc(ctx, "balm_window_add_scan", window_add_scan(ctx->window, d_xyz, n_pts, pose12));
+  return window_rc(ctx, "balm_window_add_scan", window_add_scan(ctx->window, xyz, n_pts, pose12, /*xyz_on_host=*/true));
 }
 
 static int one_window_recut(balm_ctx *ctx) {

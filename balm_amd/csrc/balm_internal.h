@@ -245,7 +245,7 @@ int associate_device(hipStream_t s, const float *d_xyz, const int *d_frame, cons
 // Return codes as associate_device.
 WindowSession *window_open(hipStream_t s, const AssocOpts &o);          // o.W = window size
 void window_close(WindowSession *w);
-int window_add_scan(WindowSession *w, const float *d_xyz_new, long n_new, const double *pose12);
+int window_add_scan(WindowSession *w, const float *xyz_new, long n_new, const double *pose12, bool xyz_on_host);
 int window_recut(WindowSession *w);
 int window_marginalize(WindowSession *w, int mg, const double *poses);
 int window_features(WindowSession *w, int min_observers, int *F_out, double **d_out, double **d_coe, double **d_fix, int **d_layer);

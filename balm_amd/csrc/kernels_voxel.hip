@@ -17,6 +17,9 @@
 //      per-(feature, pose) body clusters copied from the feature's level.
 // HBM-bound: ~20 B/point read a handful of times; the four sorts dominate.
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <type_traits>
 
@@ -202,8 +205,10 @@ __global__ __launch_bounds__(256) void k_seg_clusters_short(const float *__restr
                                                             const unsigned int *__restrict__ idx,
                                                             const unsigned int *__restrict__ seg_start,
                                                             const unsigned long long *__restrict__ seg_ck, long NS,
-                                                            double *__restrict__ seg_body, double *__restrict__ seg_world) {
+                                                            double *__restrict__ seg_body, double *__restrict__ seg_world,
+                                                            const unsigned int *__restrict__ ns_dev = nullptr) {
   const long s = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (ns_dev) NS = *ns_dev;                 // the count is still on the device (the window map's recut): the grid covers a bound
   if (s >= NS) return;
   const unsigned int i0 = seg_start[s], i1 = seg_start[s + 1];
   if (i1 - i0 > SEG_SHORT) return;
@@ -230,10 +235,12 @@ __global__ __launch_bounds__(256) void k_seg_clusters_long(const float *__restri
                                                            const unsigned int *__restrict__ idx,
                                                            const unsigned int *__restrict__ seg_start,
                                                            const unsigned long long *__restrict__ seg_ck, long NS,
-                                                           double *__restrict__ seg_body, double *__restrict__ seg_world) {
+                                                           double *__restrict__ seg_body, double *__restrict__ seg_world,
+                                                           const unsigned int *__restrict__ ns_dev = nullptr) {
   __shared__ double lds[4][SEG_TERMS * SEG_LD];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const long s = (long)blockIdx.x * 4 + wv;
+  if (ns_dev) NS = *ns_dev;
   if (s >= NS) return;
   const unsigned int i0 = seg_start[s], i1 = seg_start[s + 1];
   if (i1 - i0 <= SEG_SHORT) return;

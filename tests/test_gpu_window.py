@@ -85,6 +85,52 @@ def test_sliding_window_matches_reference_octree(seed, W, mg, retransform):
     win.close(); ctx.window_close(); ctx.close()
 
 
+@pytest.mark.parametrize("seed,W,mg", [(11, 8, 2), (13, 6, 3)])
+def test_staged_recut_equals_the_level_by_level_recut(seed, W, mg, monkeypatch):
+    """round 3: balm_window_add_scan's recut runs as stages (all levels of the unseen scan at once, then the children of
+    fresh cuts from the list k_win_descend leaves, one host synchronisation per stage); the level-by-level form of round 2
+    stays selectable (BALM_WINDOW_RECUT=levels) as its comparator: same features, clusters bit for bit, same fix clusters,
+    same point -> feature map, after every slide (only the node ids differ)"""
+    slides = 3
+    total = W + slides * mg
+    poses, frames = cluttered_window(seed, total, 40, 120, 1500)
+    rng = np.random.default_rng(seed)
+    start = noisy(poses, rng, 2e-3, 2e-2)
+    xs_all = [noisy(poses[sl * mg:W + sl * mg], rng, 2e-4, 2e-3) for sl in range(slides)]
+
+    def run(mode):
+        if mode:
+            monkeypatch.setenv("BALM_WINDOW_RECUT", mode)
+        else:
+            monkeypatch.delenv("BALM_WINDOW_RECUT", raising=False)
+        ctx = capi.Context(W)
+        ctx.window_open(voxel_size=1.0)
+        out = []
+
+        def snap():
+            F, feats = ctx.window_features()
+            cl, co, layer, fix = feats
+            o = canon_order(cl)
+            out.append((F, cl[o], co[o], layer[o], fix[o], ctx.window_info()[1:]))
+        for i in range(W):
+            ctx.window_add_scan(frames[i], start[i])
+        snap()
+        nxt = W
+        for sl in range(slides):
+            ctx.window_marginalize(mg, xs_all[sl])
+            for k in range(mg):
+                ctx.window_add_scan(frames[nxt], start[nxt]); nxt += 1
+            snap()
+        ctx.window_close(); ctx.close()
+        return out
+
+    a, b = run("levels"), run(None)
+    assert len(a) == len(b)
+    for (Fa, cla, coa, la, fa, ia), (Fb, clb, cob, lb, fb, ib) in zip(a, b):
+        assert Fa == Fb and Fa > 10 and ia == ib
+        assert np.array_equal(cla, clb) and np.array_equal(coa, cob) and np.array_equal(la, lb) and np.array_equal(fa, fb)
+
+
 def test_window_first_fill_equals_batch_when_nothing_is_cut_early():
     """adding the scans one by one with a recut each is NOT the batch association in general (a voxel cut on the evidence of
     three scans stays cut) -- but on exact, well separated planes no voxel changes its mind, and both must agree"""
