@@ -179,7 +179,7 @@ __global__ void k_seg_heads(const K *__restrict__ cks, const unsigned int *__res
 //   short segments (<= SEG_SHORT points): one lane per segment
 //   long segments: one wave per segment; 64 points at a time are gathered and expanded into their 18 terms in
 //   parallel, parked in LDS, and lanes 0..17 each add one term column in order.
-constexpr int SEG_SHORT = 24;
+constexpr int SEG_SHORT = 8;           // (24 until round 3: a lane's gathers are now issued as one batch, which has to fit its registers)
 constexpr int SEG_TERMS = 18;          // 6 + 3 body, 6 + 3 world; N is the segment length
 constexpr int SEG_LD = 65;             // padded LDS row
 
@@ -201,46 +201,56 @@ __device__ __forceinline__ PointTerms point_terms(const float x[3], const double
   return o;
 }
 
-__global__ __launch_bounds__(256) void k_seg_clusters_short(const float *__restrict__ xyz, const double *__restrict__ poses,
-                                                            const unsigned int *__restrict__ idx,
-                                                            const unsigned int *__restrict__ seg_start,
-                                                            const unsigned long long *__restrict__ seg_ck, long NS,
-                                                            double *__restrict__ seg_body, double *__restrict__ seg_world,
-                                                            const unsigned int *__restrict__ ns_dev = nullptr) {
-  const long s = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (ns_dev) NS = *ns_dev;                 // the count is still on the device (the window map's recut): the grid covers a bound
-  if (s >= NS) return;
-  const unsigned int i0 = seg_start[s], i1 = seg_start[s + 1];
-  if (i1 - i0 > SEG_SHORT) return;
-  const double *pose = poses + 12 * (long)(seg_ck[s] & 511ull);
-  double P[12];
-#pragma unroll
-  for (int c = 0; c < 12; c++) P[c] = pose[c];
-  double acc[SEG_TERMS];
-#pragma unroll
-  for (int c = 0; c < SEG_TERMS; c++) acc[c] = 0.0;
-  for (unsigned int i = i0; i < i1; i++) {
-    const size_t p = idx[i];
-    const float x[3] = {xyz[3 * p], xyz[3 * p + 1], xyz[3 * p + 2]};
-    const PointTerms t = point_terms(x, P);
-#pragma unroll
-    for (int c = 0; c < SEG_TERMS; c++) acc[c] = __dadd_rn(acc[c], t.t[c]);
-  }
-#pragma unroll
-  for (int c = 0; c < 9; c++) { seg_body[s * 10 + c] = acc[c]; seg_world[s * 10 + c] = acc[9 + c]; }
-  seg_body[s * 10 + 9] = seg_world[s * 10 + 9] = (double)(i1 - i0);
-}
-
-__global__ __launch_bounds__(256) void k_seg_clusters_long(const float *__restrict__ xyz, const double *__restrict__ poses,
-                                                           const unsigned int *__restrict__ idx,
-                                                           const unsigned int *__restrict__ seg_start,
-                                                           const unsigned long long *__restrict__ seg_ck, long NS,
-                                                           double *__restrict__ seg_body, double *__restrict__ seg_world,
-                                                           const unsigned int *__restrict__ ns_dev = nullptr) {
+// ONE launch for both classes (round 3): blocks [0, short_blocks) give a lane to every segment and skip the long ones, the
+// blocks behind them give a wavefront to every segment and skip the short ones -- the two classes used to be two launches
+// that ran one after the other; now the long pole (one wavefront walking the longest segment) hides the short ones.
+// ns_dev != NULL: the segment count is still on the device (the window map's recut) and the grid covers a bound.
+__global__ __launch_bounds__(256) void k_seg_clusters(const float *__restrict__ xyz, const double *__restrict__ poses,
+                                                      const unsigned int *__restrict__ idx, const unsigned int *__restrict__ seg_start,
+                                                      const unsigned long long *__restrict__ seg_ck, long NS, int short_blocks,
+                                                      double *__restrict__ seg_body, double *__restrict__ seg_world,
+                                                      const unsigned int *__restrict__ ns_dev) {
   __shared__ double lds[4][SEG_TERMS * SEG_LD];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const long s = (long)blockIdx.x * 4 + wv;
   if (ns_dev) NS = *ns_dev;
+  if ((int)blockIdx.x < short_blocks) {
+    // ---- short segments: one lane each.  The gathers (index -> coordinates) of up to SEG_SHORT points are issued together:
+    // a lane that walked them one by one paid two dependent memory round trips per point (12.7 us per launch on a scan's
+    // 2 000 segments, most of it waiting).
+    const long s = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= NS) return;
+    const unsigned int i0 = seg_start[s], i1 = seg_start[s + 1];
+    const int cnt = (int)(i1 - i0);
+    if (cnt > SEG_SHORT) return;
+    const double *pose = poses + 12 * (long)(seg_ck[s] & 511ull);
+    double P[12];
+#pragma unroll
+    for (int c = 0; c < 12; c++) P[c] = pose[c];
+    double acc[SEG_TERMS];
+#pragma unroll
+    for (int c = 0; c < SEG_TERMS; c++) acc[c] = 0.0;
+    size_t pp[SEG_SHORT];
+#pragma unroll
+    for (int u = 0; u < SEG_SHORT; u++) pp[u] = idx[i0 + (u < cnt ? u : 0)];
+    float xx[SEG_SHORT][3];
+#pragma unroll
+    for (int u = 0; u < SEG_SHORT; u++) { xx[u][0] = xyz[3 * pp[u]]; xx[u][1] = xyz[3 * pp[u] + 1]; xx[u][2] = xyz[3 * pp[u] + 2]; }
+#pragma unroll
+    for (int u = 0; u < SEG_SHORT; u++) {
+      if (u < cnt) {
+        const PointTerms t = point_terms(xx[u], P);
+#pragma unroll
+        for (int c = 0; c < SEG_TERMS; c++) acc[c] = __dadd_rn(acc[c], t.t[c]);
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < 9; c++) { seg_body[s * 10 + c] = acc[c]; seg_world[s * 10 + c] = acc[9 + c]; }
+    seg_body[s * 10 + 9] = seg_world[s * 10 + 9] = (double)cnt;
+    return;
+  }
+  // ---- long segments: one wavefront each; 64 points at a time are gathered and expanded into their 18 terms in parallel,
+  // parked in LDS, and lanes 0..17 each add one term column in order
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const long s = ((long)blockIdx.x - short_blocks) * 4 + wv;
   if (s >= NS) return;
   const unsigned int i0 = seg_start[s], i1 = seg_start[s + 1];
   if (i1 - i0 <= SEG_SHORT) return;
@@ -280,6 +290,14 @@ __global__ __launch_bounds__(256) void k_seg_clusters_long(const float *__restri
   if (lane < 9) seg_body[s * 10 + lane] = acc;
   else if (lane < SEG_TERMS) seg_world[s * 10 + lane - 9] = acc;
   else if (lane == SEG_TERMS) seg_body[s * 10 + 9] = seg_world[s * 10 + 9] = (double)(i1 - i0);
+}
+
+inline void launch_seg_clusters(hipStream_t st, const float *xyz, const double *poses, const unsigned int *idx, const unsigned int *seg_start,
+                                const unsigned long long *seg_ck, long NS_or_bound, double *seg_body, double *seg_world,
+                                const unsigned int *ns_dev = nullptr) {
+  if (NS_or_bound <= 0) return;
+  const int sb = (int)((NS_or_bound + 255) / 256), lb = (int)((NS_or_bound + 3) / 4);
+  hipLaunchKernelGGL(k_seg_clusters, dim3(sb + lb), dim3(256), 0, st, xyz, poses, idx, seg_start, seg_ck, NS_or_bound, sb, seg_body, seg_world, ns_dev);
 }
 
 // tree links over a level's sorted segment list: node -> first segment, node -> parent node,
@@ -716,10 +734,7 @@ int associate_device(hipStream_t s, const float *d_xyz, const int *d_frame, cons
     else
       hipLaunchKernelGGL((k_seg_heads<unsigned long long>), dim3(grid_for(n, B)), dim3(B), 0, s, cks, incl, n, L, fb, seg_start, v.seg_ck);
     hipLaunchKernelGGL(k_set_u32, dim3(1), dim3(1), 0, s, seg_start + v.NS, (unsigned int)n);
-    hipLaunchKernelGGL(k_seg_clusters_short, dim3(grid_for(v.NS, B)), dim3(B), 0, s, d_xyz, d_poses, idxL, seg_start, v.seg_ck,
-                       v.NS, v.seg_body, seg_world);
-    hipLaunchKernelGGL(k_seg_clusters_long, dim3(grid_for(v.NS, 4)), dim3(256), 0, s, d_xyz, d_poses, idxL, seg_start, v.seg_ck,
-                       v.NS, v.seg_body, seg_world);
+    launch_seg_clusters(s, d_xyz, d_poses, idxL, seg_start, v.seg_ck, v.NS, v.seg_body, seg_world);
     hipLaunchKernelGGL((k_head_flags<unsigned long long>), dim3(grid_for(v.NS, B)), dim3(B), 0, s, v.seg_ck, v.NS, 9, sf);
     scan_incl(sc, s, sf, nid, v.NS);
     const int pshift = L == 0 ? 0 : (L == 1 ? 15 : 12);
