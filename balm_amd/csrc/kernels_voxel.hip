@@ -17,6 +17,7 @@
 //      per-(feature, pose) body clusters copied from the feature's level.
 // HBM-bound: ~20 B/point read a handful of times; the four sorts dominate.
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
