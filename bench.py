@@ -31,6 +31,7 @@ import numpy as np  # noqa: E402
 
 FP64_PEAK_TFLOPS = 78.6     # MI355X FP64 matrix = vector peak (MI355X_MICROARCH.md: 157.3 TF fp32 / 2)
 HBM_PEAK_TBS = 8.0          # MI355X_MICROARCH.md: HBM3E ~8 TB/s
+COPY_RATE_TBS = 4.99        # what a plain copy kernel moves on the box (read + write): tools/ubench_f64.hip, profiles/r03f_ubench_f64.txt
 F_SINGLE = 50000            # BASELINE configs[2]
 F_SHARDED_TOTAL = 200000    # BASELINE configs[3]
 GOLDEN_SHARDED = os.path.join(ROOT, "tests", "golden", "lm_big_w200_f200000.npz")       # the reference's own run of configs[3]
@@ -329,11 +330,13 @@ def main():
     t = avg_s("moments")
     if t:      # K1 + K1b: 80 B per observation read (two evaluations per step: Hessian side and residual side)
         secondary["moments"] = {"bound": "hbm", "achieved": 80.0 * S / t / 1e12, "peak": HBM_PEAK_TBS, "unit": "TB/s",
-                                "frac": 80.0 * S / t / 1e12 / HBM_PEAK_TBS, "avg_launch_ms": t * 1e3}
+                                "frac": 80.0 * S / t / 1e12 / HBM_PEAK_TBS, "frac_of_copy_rate": 80.0 * S / t / 1e12 / COPY_RATE_TBS,
+                                "avg_launch_ms": t * 1e3}
     t = avg_s("factors")
     if t:      # K2: 80 B read + 144 B written per observation
         secondary["factors"] = {"bound": "hbm", "achieved": 224.0 * S / t / 1e12, "peak": HBM_PEAK_TBS, "unit": "TB/s",
-                                "frac": 224.0 * S / t / 1e12 / HBM_PEAK_TBS, "avg_launch_ms": t * 1e3}
+                                "frac": 224.0 * S / t / 1e12 / HBM_PEAK_TBS, "frac_of_copy_rate": 224.0 * S / t / 1e12 / COPY_RATE_TBS,
+                                "avg_launch_ms": t * 1e3}
     t = avg_s("solve")
     if t:      # blocked LDL^T: n^3/3 + 2 n^2 flops; a latency chain, priced against the FP64 peak for the record
         fl = n ** 3 / 3.0 + 2.0 * n * n
