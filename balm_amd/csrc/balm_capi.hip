@@ -4,6 +4,8 @@
 // matrix device-resident; only four scalars cross PCIe per iteration.
 #include <algorithm>
 #include <array>
+#include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -131,11 +133,43 @@ int hook_allreduce(balm_ctx *ctx, double *buf, long n) {
   return BALM_OK;
 }
 
-// the damping u of the next solve: through a pinned ring (the copy is asynchronous; 64 solves can be in flight)
+// the damping u of the next solve: a kernel argument of the plain launches (launch_solve) ...
 int set_damping(balm_ctx *ctx, double u) {
+  ctx->u_value = u;
+  ctx->u_on_device = false;
+  return BALM_OK;
+}
+// ... or, for a captured / replayed LM graph, a value in device memory that travels through a pinned ring (the copy is
+// asynchronous; 64 solves can be in flight)
+int push_damping(balm_ctx *ctx) {
   double *slot = ctx->h_scal + 16 + (ctx->u_ring++ & 63);
-  *slot = u;
+  *slot = ctx->u_value;
   HIP_TRY(hipMemcpyAsync(ctx->d_scal + SCAL_U, slot, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  ctx->u_on_device = true;
+  return BALM_OK;
+}
+
+// (kernel timing: the spans' events are read once the stream is known to be idle -- the stamp says it is, the synchronise is then cheap)
+static void collect_timing_if_idle(balm_ctx *ctx) {
+  if (!ctx->timer.on || ctx->timer.pending.empty()) return;
+  if (hipStreamSynchronize(ctx->stream) == hipSuccess) collect_timing(ctx);
+}
+
+// The host's end of k_scalars_mail: poll the stamp in the pinned mirror (a copy command + hipStreamSynchronize cost 15-25 us per
+// LM iteration on this stack -- 5 % of an iteration on the shipped window); after ~300 us of polling the wait becomes a
+// stream synchronise (long iterations: nothing to gain from spinning).  Errors of the stream surface there or at the
+// next synchronising call.
+int wait_scalars(balm_ctx *ctx) {
+  volatile double *stamp = ctx->h_scal + SCAL_STAMP;
+  const double want = (double)ctx->mail_seq;
+  const auto t0 = std::chrono::steady_clock::now();
+  for (int spin = 0;; spin++) {
+    if (*stamp == want) { std::atomic_thread_fence(std::memory_order_acquire); collect_timing_if_idle(ctx); return BALM_OK; }
+    if ((spin & 255) == 255 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(300)) break;
+  }
+  int rc = sync_stream(ctx);
+  if (rc) return rc;
+  if (*stamp != want) { ctx->err = "balm_damping_iter: the iteration's scalars did not arrive"; return BALM_ERR_HIP; }
   return BALM_OK;
 }
 
@@ -150,7 +184,7 @@ void drop_lm_graphs(balm_ctx *ctx) {
 // ranks).  The per-feature eigen records it produces are kept (d_feat_tmp): if the step is accepted
 // they are exactly what the next Hessian evaluation needs at the same poses (the reference recomputes
 // them, bavoxel.hpp:331-351 after :443-457).
-int residual_device(balm_ctx *ctx, const double *d_poses, int f0, int f1, int slot) {
+int residual_device(balm_ctx *ctx, const double *d_poses, int f0, int f1, int slot, bool defer_sum = false) {
   if (f1 <= f0) {          // a shard the requested feature range does not reach: contributes zero
     HIP_TRY(hipMemsetAsync(ctx->d_scal + slot, 0, sizeof(double), ctx->stream));
     ctx->nr_tmp = 0;
@@ -159,9 +193,10 @@ int residual_device(balm_ctx *ctx, const double *d_poses, int f0, int f1, int sl
     launch_world_moments(ctx->stream, ctx->d_cl, d_poses, ctx->W, f0, f1, ctx->d_C);
     ctx->nr_tmp = launch_feature_eigen(ctx->stream, ctx->d_C, ctx->has_fix ? ctx->d_fix : nullptr, ctx->d_coe, f0, f1, ctx->d_feat_tmp,
                                        ctx->d_rpart_tmp);
-    launch_sum_scalar(ctx->stream, ctx->d_rpart_tmp, ctx->nr_tmp, ctx->d_scal + slot);
+    if (!defer_sum) launch_sum_scalar(ctx->stream, ctx->d_rpart_tmp, ctx->nr_tmp, ctx->d_scal + slot);
   }
   HIP_TRY(hipGetLastError());          // k_world_moments: dynamic LDS above the 64 KiB default
+  if (defer_sum) return BALM_OK;       // (no transport: the caller's k_scalars_mail adds the partials up on its way out)
   return hook_allreduce(ctx, ctx->d_scal + slot, 1);
 }
 
@@ -187,7 +222,11 @@ int prepare_evaluate(balm_ctx *ctx, int form, int nf) {
     gcols = (size_t)ctx->sp_nchunks * ctx->sp_nsteps * 4 + 64;
     parts = (size_t)ctx->sp_nitems;
   }
-  if ((rc = ensure(ctx, &ctx->d_Gt, &ctx->cap_Gt, gcols * ctx->npad))) return rc;
+  {
+    const double *before = ctx->d_Gt;
+    if ((rc = ensure(ctx, &ctx->d_Gt, &ctx->cap_Gt, gcols * ctx->npad))) return rc;
+    if (ctx->d_Gt != before) ctx->gt_dirty_cols = ~(size_t)0;        // fresh memory: nothing is known to be zero
+  }
   if ((rc = ensure(ctx, &ctx->d_part, &ctx->cap_part, parts * TILE_ELEMS))) return rc;
   if ((rc = ensure(ctx, &ctx->d_dpart, &ctx->cap_dpart, (size_t)factors_grid(ctx->W, nf, form) * DACC_MAX * ctx->W))) return rc;
   if (nf == ctx->F && fuse_trial(ctx)) {       // the trial poses' factors (same sizes; reallocation invalidates what they held)
@@ -207,8 +246,8 @@ int evaluate_device(balm_ctx *ctx, int form, const double *d_poses, int f0, int 
     HIP_TRY(hipMemsetAsync(ctx->d_red, 0, ctx->red_len * sizeof(double), ctx->stream));
     if ((rc = hook_allreduce(ctx, ctx->d_red, (long)ctx->red_len))) return rc;
     Span sp(ctx, BALM_T_ASSEMBLE);
-    launch_assemble(ctx->stream, form, ctx->d_red, red_dacc_off(ctx), ctx->d_sub, ctx->ntiles, W, ctx->d_H, ctx->d_g);
-    HIP_TRY(hipMemcpyAsync(ctx->d_scal + slot, ctx->d_red + red_r_off(ctx), sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    launch_assemble(ctx->stream, form, ctx->d_red, red_dacc_off(ctx), ctx->d_sub, ctx->ntiles, W, ctx->d_H, ctx->d_g,
+                    ctx->d_red + red_r_off(ctx), ctx->d_scal + slot);
     return BALM_OK;
   }
   SyrkPlan plan = plan_syrk(ctx->ntiles, 3L * nf);
@@ -226,12 +265,17 @@ int evaluate_device(balm_ctx *ctx, int form, const double *d_poses, int f0, int 
   const size_t kpad = sparse ? (size_t)ctx->sp_nchunks * ctx->sp_nsteps * 4 : (size_t)plan.Kpad;
   if (!(ctx->gt_cur_valid && ctx->feat_cur_valid && f0 == 0 && f1 == ctx->F)) {
     Span sp(ctx, BALM_T_FACTORS);
-    // zero the Gt columns the factor kernel does not write: [3 nf, Kpad + 8) and the row padding
-    const size_t k0 = (size_t)3 * nf, k1 = kpad + 64;   // + prefetch overrun of the k-ring
-    HIP_TRY(hipMemsetAsync(ctx->d_Gt + k0 * ctx->npad, 0, (k1 - k0) * ctx->npad * sizeof(double), s));
-    if (ctx->npad > ctx->n)
-      HIP_TRY(hipMemset2DAsync(ctx->d_Gt + ctx->n, (size_t)ctx->npad * sizeof(double), 0,
-                               (size_t)(ctx->npad - ctx->n) * sizeof(double), k0 ? k0 : 1, s));
+    // The Gt columns the factor kernel does not write -- [3 nf, Kpad + 64: the k-ring's prefetch overrun) -- and the row padding
+    // must be zero.  The kernel never writes either, so they are zeroed when they can be dirty: once per (re)allocation, and
+    // when a narrower evaluation (a feature sub-range) follows a wider one -- not by two memsets per evaluation.
+    const size_t k0 = (size_t)3 * nf, k1 = kpad + 64;
+    if (ctx->gt_dirty_cols == ~(size_t)0) {
+      HIP_TRY(hipMemsetAsync(ctx->d_Gt, 0, ctx->cap_Gt * sizeof(double), s));
+      ctx->gt_dirty_cols = 0;
+    } else if (ctx->gt_dirty_cols > k0) {
+      HIP_TRY(hipMemsetAsync(ctx->d_Gt + k0 * ctx->npad, 0, (std::max(ctx->gt_dirty_cols, k1) - k0) * ctx->npad * sizeof(double), s));
+    }
+    ctx->gt_dirty_cols = k0;
     launch_factors(s, form, ctx->d_cl, d_poses, ctx->d_feat, W, ctx->npad, f0, f1, ctx->d_Gt, ctx->d_dpart, nblk,
                    sparse ? ctx->d_slot : nullptr);
     ctx->gt_cur_valid = false;                // (set by the LM loop only, when an accepted trial's factors become current)
@@ -246,16 +290,14 @@ int evaluate_device(balm_ctx *ctx, int form, const double *d_poses, int f0, int 
   }
   {
     Span sp(ctx, BALM_T_ASSEMBLE);
-    HIP_TRY(hipMemsetAsync(ctx->d_red + red_dacc_off(ctx), 0, (size_t)(DACC_MAX * W + 2) * sizeof(double), s));
     launch_reduce(s, ctx->d_part, plan.SG, (long)ctx->ntiles * TILE_ELEMS, ctx->d_dpart, nblk, dacc * W,
                   ctx->d_rpart, nr, ctx->d_red, red_dacc_off(ctx), red_r_off(ctx), sparse ? ctx->d_csr : nullptr);
   }
   if ((rc = hook_allreduce(ctx, ctx->d_red, (long)ctx->red_len))) return rc;
   {
     Span sp(ctx, BALM_T_ASSEMBLE);
-    launch_assemble(s, form, ctx->d_red, red_dacc_off(ctx), ctx->d_sub, ctx->ntiles, W, ctx->d_H, ctx->d_g);
-    HIP_TRY(hipMemcpyAsync(ctx->d_scal + slot, ctx->d_red + red_r_off(ctx), sizeof(double),
-                           hipMemcpyDeviceToDevice, s));
+    launch_assemble(s, form, ctx->d_red, red_dacc_off(ctx), ctx->d_sub, ctx->ntiles, W, ctx->d_H, ctx->d_g, ctx->d_red + red_r_off(ctx),
+                    ctx->d_scal + slot);
   }
   return BALM_OK;
 }
@@ -398,7 +440,9 @@ balm_ctx *balm_create(int win_size, int device, int flags) {
       dalloc(ctx, &ctx->d_perm, (size_t)nA) || dalloc(ctx, &ctx->d_flags, (size_t)2 * (2 * (nA / NB) + 1) * (nA / NB) + (nA / NB) + 8) || dalloc(ctx, &ctx->d_minv, (size_t)(nA / NB) * NB * NB) || dalloc(ctx, &ctx->d_dx, (size_t)n) ||
       dalloc(ctx, &ctx->d_scal, (size_t)16) || dalloc(ctx, &ctx->d_pre, (size_t)W + 2))
     return fail();
-  if (hipHostMalloc((void **)&ctx->h_scal, (16 + 64) * sizeof(double)) != hipSuccess) return fail();
+  if (hipHostMalloc((void **)&ctx->h_scal, (16 + 64 + 8) * sizeof(double), hipHostMallocMapped) != hipSuccess) return fail();
+  if (hipHostGetDevicePointer((void **)&ctx->d_hscal, ctx->h_scal, 0) != hipSuccess) return fail();
+  ctx->h_scal[SCAL_STAMP] = 0.0;
   if (hipMemcpy(ctx->d_jobs, jobs.data(), jobs.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess ||
       hipMemcpy(ctx->d_sub, sub.data(), sub.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess)
     return fail();
@@ -847,6 +891,7 @@ static int one_pose_covariance(balm_ctx *ctx, const double *poses, const double 
   const SyrkPlan plan = plan_syrk(ctx->ntiles, 3L * (F > 0 ? F : 1));
   const size_t gcols = (size_t)plan.Kpad + 64, tiles = (size_t)ctx->ntiles * TILE_ELEMS;
   if ((rc = ensure(ctx, &ctx->d_Gt, &ctx->cap_Gt, 2 * gcols * ctx->npad))) return rc;
+  ctx->gt_dirty_cols = ~(size_t)0;                // X and Y are about to be written all over it
   if ((rc = ensure(ctx, &ctx->d_part, &ctx->cap_part, (size_t)plan.SG * tiles))) return rc;
   const int nblk = cov_factors_grid(W, F > 0 ? F : 1);
   if ((rc = ensure(ctx, &ctx->d_dpart, &ctx->cap_dpart, (size_t)nblk * DACC_MAX * W))) return rc;
@@ -984,22 +1029,24 @@ int balm_solve_damped(balm_ctx *ctx, const double *Hess, const double *JacT, dou
 // as a hipGraph (a window of 20 poses is ~26 launches for ~0.1 ms of device work).  Not with a
 // collective transport (the all-reduce is not ours to capture), not with kernel timing (events), not if a capture ever
 // failed on this context (e.g. a runtime that will not capture the cooperative launch of k_ldl_fused).
-static int lm_enqueue(balm_ctx *ctx, int form, bool evaluated) {
+static int lm_enqueue(balm_ctx *ctx, int form, bool evaluated, bool mail) {
   int rc;
   if (evaluated && (rc = evaluate_device(ctx, form, ctx->d_poses, 0, ctx->F, 0))) return rc;
   {
-    Span sp(ctx, BALM_T_SOLVE);
-    launch_solve(ctx, evaluated);
-  }
-  {
-    Span sp(ctx, BALM_T_UPDATE);
-    launch_update_poses(ctx->stream, form, ctx->W, ctx->d_poses, ctx->d_dx, ctx->d_poses_tmp);
+    Span sp(ctx, BALM_T_SOLVE);       // ... and the trial poses: k_ldl_finish applies the step it has assembled (bavoxel.hpp:1116-1126)
+    launch_solve(ctx, evaluated, form, ctx->d_poses, ctx->d_poses_tmp);
   }
   ctx->gt_trial_valid = false;
+  bool sum_in_mail = false;
   if (fuse_trial(ctx) && ctx->d_Gt2 && ctx->d_dpart2) {
     if ((rc = trial_device(ctx, form, ctx->d_poses_tmp, 1))) return rc;
-  } else if ((rc = residual_device(ctx, ctx->d_poses_tmp, 0, ctx->F, 1))) return rc;
-  HIP_TRY(hipMemcpyAsync(ctx->h_scal, ctx->d_scal, 16 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  } else {
+    sum_in_mail = mail && !has_transport(ctx) && ctx->F > 0;
+    if ((rc = residual_device(ctx, ctx->d_poses_tmp, 0, ctx->F, 1, sum_in_mail))) return rc;
+  }
+  if (mail) launch_scalars_mail(ctx->stream, ctx->d_scal, ctx->d_hscal, (double)++ctx->mail_seq, sum_in_mail ? ctx->d_rpart_tmp : nullptr,
+                                ctx->nr_tmp, 1);      // -> wait_scalars
+  else HIP_TRY(hipMemcpyAsync(ctx->h_scal, ctx->d_scal, 16 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));      // (a replayed graph cannot carry a new stamp)
   return BALM_OK;
 }
 
@@ -1022,9 +1069,10 @@ static int lm_iteration(balm_ctx *ctx, int form, bool evaluated, int it) {
     }
     if (!ctx->lm_graph[slot]) {
       hipGraph_t g = nullptr;
+      ctx->u_on_device = true;               // the captured kernels read the damping from d_scal[SCAL_U]
       bool ok = hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
       if (ok) {
-        const int rc = lm_enqueue(ctx, form, evaluated);
+        const int rc = lm_enqueue(ctx, form, evaluated, false);
         const hipError_t e = hipStreamEndCapture(ctx->stream, &g);
         ok = rc == BALM_OK && e == hipSuccess && g != nullptr;
       }
@@ -1040,13 +1088,16 @@ static int lm_iteration(balm_ctx *ctx, int form, bool evaluated, int it) {
       }
     }
     if (ctx->lm_graph[slot]) {
+      int rcu = push_damping(ctx);
+      if (rcu) return rcu;
       HIP_TRY(hipGraphLaunch(ctx->lm_graph[slot], ctx->stream));
       return sync_stream(ctx);
     }
+    ctx->u_on_device = false;                // (capture failed: plain launches with the damping as an argument)
   }
-  int rc = lm_enqueue(ctx, form, evaluated);
+  int rc = lm_enqueue(ctx, form, evaluated, true);
   if (rc) return rc;
-  return sync_stream(ctx);
+  return wait_scalars(ctx);
 }
 
 static int one_damping_iter(balm_ctx *ctx, const balm_lm_opts *o, double *poses, balm_iter_log *log, int *n_iters) {
@@ -1125,6 +1176,7 @@ static int one_damping_iter(balm_ctx *ctx, const balm_lm_opts *o, double *poses,
       ctx->gt_cur_valid = ctx->gt_trial_valid;        // the trial's factors (fused evaluation) become the current poses'
       if (ctx->gt_trial_valid) {
         std::swap(ctx->d_Gt, ctx->d_Gt2); std::swap(ctx->cap_Gt, ctx->cap_Gt2);
+        ctx->gt_dirty_cols = ~(size_t)0;       // (the other buffer's zero state is the trial kernel's business, not tracked)
         std::swap(ctx->d_dpart, ctx->d_dpart2); std::swap(ctx->cap_dpart, ctx->cap_dpart2);
         ctx->gt_parity ^= 1;
       }

@@ -70,6 +70,7 @@ struct balm_ctx {
   // the fused trial evaluation (k_moments_factors) leaves the TRIAL poses' factors here; swapped in when the step is accepted
   double *d_Gt2 = nullptr, *d_dpart2 = nullptr;
   size_t cap_Gt2 = 0, cap_dpart2 = 0;
+  size_t gt_dirty_cols = ~(size_t)0; // columns [gt_dirty_cols, cap) and the row padding of d_Gt are known to be zero (~0: nothing is)
   bool gt_cur_valid = false;        // d_Gt / d_dpart (and d_feat / d_rpart) describe d_poses: the next evaluation starts at the SYRK
   int gt_parity = 0;                // flips with every (d_Gt, d_Gt2) swap: captured LM graphs hold the pointers
   bool gt_trial_valid = false;      // d_Gt2 / d_dpart2 describe d_poses_tmp (this iteration's trial)
@@ -111,7 +112,11 @@ struct balm_ctx {
   double *d_minv = nullptr;         // [P][48][48] Minv_p = L11^-T D11^-1 of every panel (k_ldl_chain)
   double *d_dx = nullptr;           // [n]
   double *d_scal = nullptr;         // [16] device scalars: 0 r1, 1 r2, 2 q1, 3 flags
-  double *h_scal = nullptr;         // pinned mirror (16) + a ring of damping values on their way to d_scal[SCAL_U] (64)
+  double *h_scal = nullptr;         // pinned mirror (16) + a ring of damping values on their way to d_scal[SCAL_U] (64) + a stamp
+  double *d_hscal = nullptr;        // its device alias: k_scalars_mail writes the mirror and the stamp straight into host memory
+  unsigned long long mail_seq = 0;  // stamp of the last k_scalars_mail launch
+  double u_value = 0.0;             // damping of the next solve (set_damping)
+  bool u_on_device = false;         // ... read by the solve's kernels from d_scal[SCAL_U] (graph capture / replay) instead of their arguments
   int u_ring = 0;
   // one LM iteration as a replayable hipGraph, per (Hessian evaluated?, which pose buffer is current): [4]
   static constexpr int LM_GRAPHS = 32;       // (which factor buffer is current, fused trial evaluation, factors current, evaluated, pose-buffer parity)
@@ -166,7 +171,7 @@ void launch_reduce(hipStream_t s, const double *part, int SG, long tile_elems_to
                    int dacc_len, const double *rpart, int nr, double *red, long red_dacc_off, long red_r_off,
                    const int *csr_ptr = nullptr);
 void launch_assemble(hipStream_t s, int form, const double *red, long red_dacc_off, const int *tileIJ, int ntiles,
-                     int W, double *H, double *g);
+                     int W, double *H, double *g, const double *r_in = nullptr, double *r_out = nullptr);
 void launch_sum_scalar(hipStream_t s, const double *rpart, int nr, double *out);
 
 // balm_multi.hip: one context over several devices of this process, RCCL loaded on first use
@@ -222,9 +227,12 @@ int multi_host_barrier_rc(balm_ctx *ctx, int rc);             // all device thre
 
 // launchers (kernels_solve.hip)
 constexpr int SCAL_U = 5;            // d_scal slot of the damping u
+constexpr int SCAL_STAMP = 16 + 64;  // h_scal slot of k_scalars_mail's stamp (behind the mirror and the damping ring)
 bool solve_is_persistent(const balm_ctx *c);      // the factorisation of this window runs as k_ldl_fused
-void launch_solve(balm_ctx *c, bool new_hessian);      // (H + u diag H) dx = -g, u = d_scal[SCAL_U]; q1 -> d_scal[2]
+void launch_solve(balm_ctx *c, bool new_hessian, int upd_form = 0, const double *upd_poses = nullptr, double *upd_out = nullptr);      // (H + u diag H) dx = -g, u = d_scal[SCAL_U]; q1 -> d_scal[2]
 void launch_update_poses(hipStream_t s, int form, int W, const double *poses, const double *dx, double *out);
+void launch_scalars_mail(hipStream_t s, double *d_scal, double *d_hscal, double stamp, const double *rpart = nullptr, int nr = 0,
+                         int slot = 0);      // [d_scal[slot] = sum rpart;] d_scal[0..15] + stamp -> pinned host mirror
 void launch_reanchor(hipStream_t s, int W, double *poses);
 
 // kernels_voxel.hip

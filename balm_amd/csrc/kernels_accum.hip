@@ -694,6 +694,7 @@ int factors_grid(int W, int nfeat, int form) {
   if (per_cu < 1) per_cu = 1;
   if (per_cu > 4) per_cu = 4;
   int grid = 256 * per_cu;
+  if (const char *e = getenv("BALM_FACTORS_GRID")) { const int g = atoi(e); if (g > 0) grid = g; }      // A/B runs
   if (grid > nfeat) grid = nfeat;
   if (grid < 1) grid = 1;
   return grid;
@@ -922,9 +923,9 @@ void launch_syrk(hipStream_t s, const double *Gt, int npad, int ntiles, const in
 // ------------------------------------------------------------------------------------------------
 // K4a: deterministic reductions into the all-reduce payload  red = [tiles | dacc | r]
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_reduce_tiles(const double *__restrict__ part, int SG, long tile_total,
-                                                      double *__restrict__ red) {
-  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < tile_total; t += (long)gridDim.x * blockDim.x) {
+__device__ __forceinline__ void reduce_tiles(const double *__restrict__ part, int SG, long tile_total, double *__restrict__ red,
+                                             int bid, int nb) {
+  for (long t = (long)bid * blockDim.x + threadIdx.x; t < tile_total; t += (long)nb * blockDim.x) {
     // fixed summation order (deterministic), four independent chains to keep loads in flight
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
     const double *pp = part + t;
@@ -941,9 +942,9 @@ __global__ __launch_bounds__(256) void k_reduce_tiles(const double *__restrict__
 }
 
 // block-sparse plan: the partial tiles of job j are slots ptr[j] .. ptr[j+1]-1 (chunk order: deterministic)
-__global__ __launch_bounds__(256) void k_reduce_tiles_csr(const double *__restrict__ part, const int *__restrict__ ptr,
-                                                          long tile_total, double *__restrict__ red) {
-  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < tile_total; t += (long)gridDim.x * blockDim.x) {
+__device__ __forceinline__ void reduce_tiles_csr(const double *__restrict__ part, const int *__restrict__ ptr, long tile_total,
+                                                 double *__restrict__ red, int bid, int nb) {
+  for (long t = (long)bid * blockDim.x + threadIdx.x; t < tile_total; t += (long)nb * blockDim.x) {
     const int job = (int)(t / TILE_ELEMS);
     const long e = t - (long)job * TILE_ELEMS;
     const int s0 = ptr[job], s1 = ptr[job + 1];
@@ -962,12 +963,12 @@ __global__ __launch_bounds__(256) void k_reduce_tiles_csr(const double *__restri
 
 // per-pose accumulators: sum over the feature_factors workgroups.  64 outputs per workgroup, the
 // workgroup index range split over the four waves, eight loads in flight per lane.
-__global__ __launch_bounds__(256) void k_reduce_dacc(const double *__restrict__ dpart, int nblk, int dacc_len,
-                                                     const double *__restrict__ rpart, int nr,
-                                                     double *__restrict__ red_dacc, double *__restrict__ red_r) {
+__device__ __forceinline__ void reduce_dacc(const double *__restrict__ dpart, int nblk, int dacc_len, int dacc_cap,
+                                            const double *__restrict__ rpart, int nr, double *__restrict__ red_dacc,
+                                            double *__restrict__ red_r, int bid) {
   __shared__ double sq[256];
   const int jl = threadIdx.x & 63, q = threadIdx.x >> 6;
-  const int j = blockIdx.x * 64 + jl;
+  const int j = bid * 64 + jl;
   double s = 0.0;
   if (j < dacc_len) {
     const int chunk = (nblk + 3) / 4;
@@ -986,7 +987,8 @@ __global__ __launch_bounds__(256) void k_reduce_dacc(const double *__restrict__ 
   sq[threadIdx.x] = s;
   __syncthreads();
   if (q == 0 && j < dacc_len) red_dacc[j] = (sq[jl] + sq[64 + jl]) + (sq[128 + jl] + sq[192 + jl]);
-  if (blockIdx.x == 0) {
+  if (q == 0 && j >= dacc_len && j < dacc_cap) red_dacc[j] = 0.0;      // the payload's unused accumulator slots (left form: 27 of 30)
+  if (bid == 0) {
     __syncthreads();
     double r = 0.0;
     for (int t = threadIdx.x; t < nr; t += 256) r += rpart[t];
@@ -996,18 +998,30 @@ __global__ __launch_bounds__(256) void k_reduce_dacc(const double *__restrict__ 
       if (threadIdx.x < k) sq[threadIdx.x] += sq[threadIdx.x + k];
       __syncthreads();
     }
-    if (threadIdx.x == 0) red_r[0] = sq[0];
+    if (threadIdx.x == 0) { red_r[0] = sq[0]; red_r[1] = 0.0; }
+  }
+}
+
+// K4a in ONE launch (round 3: the two reductions are independent -- they used to be two launches one after the other): blocks
+// [0, tile_blocks) sum the split-K partial tiles, the blocks behind them the per-pose accumulators and the residual partials
+__global__ __launch_bounds__(256) void k_reduce_all(const double *__restrict__ part, int SG, const int *__restrict__ csr_ptr, long tile_total,
+                                                    int tile_blocks, const double *__restrict__ dpart, int nblk, int dacc_len, int dacc_cap,
+                                                    const double *__restrict__ rpart, int nr, double *__restrict__ red, long dacc_off, long r_off) {
+  if ((int)blockIdx.x < tile_blocks) {
+    if (csr_ptr) reduce_tiles_csr(part, csr_ptr, tile_total, red, blockIdx.x, tile_blocks);
+    else reduce_tiles(part, SG, tile_total, red, blockIdx.x, tile_blocks);
+  } else {
+    reduce_dacc(dpart, nblk, dacc_len, dacc_cap, rpart, nr, red + dacc_off, red + r_off, (int)blockIdx.x - tile_blocks);
   }
 }
 
 void launch_reduce(hipStream_t s, const double *part, int SG, long tile_total, const double *dpart, int nblk,
                    int dacc_len, const double *rpart, int nr, double *red, long dacc_off, long r_off, const int *csr_ptr) {
+  const int dacc_cap = (int)(r_off - dacc_off);        // every slot of the payload between the tiles and the residual is written
   int grid = (int)((tile_total + 255) / 256);
   if (grid > 8192) grid = 8192;
-  if (csr_ptr) hipLaunchKernelGGL(k_reduce_tiles_csr, dim3(grid), dim3(256), 0, s, part, csr_ptr, tile_total, red);
-  else hipLaunchKernelGGL(k_reduce_tiles, dim3(grid), dim3(256), 0, s, part, SG, tile_total, red);
-  hipLaunchKernelGGL(k_reduce_dacc, dim3((dacc_len + 63) / 64), dim3(256), 0, s, dpart, nblk, dacc_len, rpart, nr,
-                     red + dacc_off, red + r_off);
+  hipLaunchKernelGGL(k_reduce_all, dim3(grid + (dacc_cap + 63) / 64), dim3(256), 0, s, part, SG, csr_ptr, tile_total, grid, dpart, nblk, dacc_len,
+                     dacc_cap, rpart, nr, red, dacc_off, r_off);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1041,8 +1055,10 @@ __device__ __forceinline__ double blockdiag_at(const double *__restrict__ dacc, 
 template <int FORM>
 __global__ __launch_bounds__(256) void k_assemble(const double *__restrict__ red, long dacc_off,
                                                   const int *__restrict__ tileIJ, int ntiles, int W,
-                                                  double *__restrict__ H, double *__restrict__ g) {
+                                                  double *__restrict__ H, double *__restrict__ g, const double *__restrict__ r_in,
+                                                  double *__restrict__ r_out) {
   const int n = 6 * W;
+  if (r_out && blockIdx.x == 0 && threadIdx.x == 0) *r_out = *r_in;      // the residual of the (summed) payload -> the LM loop's scalars
   const long total = (long)ntiles * TILE_ELEMS;
   const double *dacc = red + dacc_off;
   for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
@@ -1076,14 +1092,14 @@ __global__ __launch_bounds__(256) void k_assemble(const double *__restrict__ red
 }
 
 void launch_assemble(hipStream_t s, int form, const double *red, long dacc_off, const int *tileIJ, int ntiles, int W,
-                     double *H, double *g) {
+                     double *H, double *g, const double *r_in, double *r_out) {
   long total = (long)ntiles * TILE_ELEMS;
   int grid = (int)((total + 255) / 256);
   if (grid > 4096) grid = 4096;
   if (form == 0)
-    hipLaunchKernelGGL(k_assemble<0>, dim3(grid), dim3(256), 0, s, red, dacc_off, tileIJ, ntiles, W, H, g);
+    hipLaunchKernelGGL(k_assemble<0>, dim3(grid), dim3(256), 0, s, red, dacc_off, tileIJ, ntiles, W, H, g, r_in, r_out);
   else
-    hipLaunchKernelGGL(k_assemble<1>, dim3(grid), dim3(256), 0, s, red, dacc_off, tileIJ, ntiles, W, H, g);
+    hipLaunchKernelGGL(k_assemble<1>, dim3(grid), dim3(256), 0, s, red, dacc_off, tileIJ, ntiles, W, H, g, r_in, r_out);
 }
 
 }  // namespace balm

@@ -64,10 +64,10 @@ __global__ __launch_bounds__(256) void k_rank_diag(const double *__restrict__ H,
 }
 
 __global__ __launch_bounds__(256) void k_build_A(const double *__restrict__ H, const double *__restrict__ g, int n,
-                                                 int nA, const int *__restrict__ perm, const double *__restrict__ pu,
+                                                 int nA, const int *__restrict__ perm, const double *__restrict__ pu, double u_arg,
                                                  double *__restrict__ A, int *__restrict__ flags, int nflags) {
-  const double u = *pu;                 // the damping lives in device memory: the launch sequence of an LM iteration
-                                        // is then the same for every iteration and can be replayed as a hipGraph
+  const double u = pu ? *pu : u_arg;    // replayed hipGraphs read the damping from device memory (the launch sequence of an LM
+                                        // iteration is then the same for every iteration); plain launches carry it as an argument
   const int ldA = 2 * nA + NB;
   const long total = (long)ldA * nA;
   for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < nflags; t += (long)gridDim.x * blockDim.x) flags[t] = 0;
@@ -661,11 +661,74 @@ __global__ __launch_bounds__(256) void k_ldl_apply(const double *__restrict__ A,
 }
 
 // un-permute, q1 = 0.5 dx.(u D dx - g)    (bavoxel.hpp:1127)
+// ------------------------------------------------------------------------------------------------
+// pose update: left  R <- Exp(dth) R, p <- Exp(dth) p + dt   (bavoxel.hpp:1123-1125)
+//              right R <- R Exp(dth), p <- p + dt            (bavoxel.hpp:1119-1120)
+// Exp = Rodrigues with the reference's 1e-11 threshold (include/tools.hpp:56-71)
+// (defined ahead of k_ldl_finish, which applies it to the step it has just assembled: one launch less per LM iteration)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void exp_so3(const double w[3], double E[3][3]) {
+  const double nn = sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+  E[0][0] = E[1][1] = E[2][2] = 1.0;
+  E[0][1] = E[0][2] = E[1][0] = E[1][2] = E[2][0] = E[2][1] = 0.0;
+  if (nn >= 1e-11) {
+    const double x = w[0] / nn, y = w[1] / nn, z = w[2] / nn;
+    const double K[3][3] = {{0, -z, y}, {z, 0, -x}, {-y, x, 0}};
+    const double s = sin(nn), c1 = 1.0 - cos(nn);
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+        // evaluation order of the reference's `I33 + sin*K + (1-cos)*K*K`: ((1-cos)*K)*K
+        const double kk = (c1 * K[r][0]) * K[0][c] + (c1 * K[r][1]) * K[1][c] + (c1 * K[r][2]) * K[2][c];
+        E[r][c] = (E[r][c] + s * K[r][c]) + kk;
+      }
+  }
+}
+
+__device__ __forceinline__ void update_pose(int form, int j, const double *__restrict__ poses, const double *__restrict__ dx,
+                                            double *__restrict__ out) {
+  const double *q = poses + 12 * j;
+  const double w[3] = {dx[6 * j], dx[6 * j + 1], dx[6 * j + 2]};
+  const double dt[3] = {dx[6 * j + 3], dx[6 * j + 4], dx[6 * j + 5]};
+  double E[3][3];
+  exp_so3(w, E);
+  double R[3][3], p[3] = {q[9], q[10], q[11]};
+#pragma unroll
+  for (int c = 0; c < 3; c++)
+#pragma unroll
+    for (int r = 0; r < 3; r++) R[r][c] = q[3 * c + r];
+  double Rn[3][3], pn[3];
+  if (form == 0) {
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+#pragma unroll
+      for (int c = 0; c < 3; c++) Rn[r][c] = E[r][0] * R[0][c] + E[r][1] * R[1][c] + E[r][2] * R[2][c];
+      pn[r] = E[r][0] * p[0] + E[r][1] * p[1] + E[r][2] * p[2] + dt[r];
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+#pragma unroll
+      for (int c = 0; c < 3; c++) Rn[r][c] = R[r][0] * E[0][c] + R[r][1] * E[1][c] + R[r][2] * E[2][c];
+      pn[r] = p[r] + dt[r];
+    }
+  }
+  double *o = out + 12 * j;
+#pragma unroll
+  for (int c = 0; c < 3; c++)
+#pragma unroll
+    for (int r = 0; r < 3; r++) o[3 * c + r] = Rn[r][c];
+  o[9] = pn[0]; o[10] = pn[1]; o[11] = pn[2];
+}
+
+
 __global__ __launch_bounds__(1024) void k_ldl_finish(const double *__restrict__ x, int nA, int n,
                                                      const int *__restrict__ perm, const double *__restrict__ H,
-                                                     const double *__restrict__ g, const double *__restrict__ pu,
-                                                     double *__restrict__ dx, double *__restrict__ scal, const int *__restrict__ abort_flag) {
-  const double u = *pu;
+                                                     const double *__restrict__ g, const double *__restrict__ pu, double u_arg,
+                                                     double *__restrict__ dx, double *__restrict__ scal, const int *__restrict__ abort_flag,
+                                                     int upd_form, int W, const double *__restrict__ poses, double *__restrict__ poses_out) {
+  const double u = pu ? *pu : u_arg;
   // a persistent factorisation that gave up on a flag (k_ldl_chain's bounded waits) must not pass for a solution
   const double poison = *abort_flag ? __longlong_as_double(0x7ff8000000000000ll) : 0.0;
   __shared__ double red[1024];
@@ -689,6 +752,10 @@ __global__ __launch_bounds__(1024) void k_ldl_finish(const double *__restrict__ 
     __syncthreads();
   }
   if (tid == 0) scal[2] = 0.5 * red[0];
+  if (poses_out) {                       // the trial poses of the LM loop (every dx[] of this workgroup is written: barriers above)
+    __threadfence_block();
+    for (int j = tid; j < W; j += 1024) update_pose(upd_form, j, poses, dx, poses_out);
+  }
 }
 
 #include "kernels_chain.inc"
@@ -797,9 +864,10 @@ static void launch_factor(balm_ctx *c) {
   }
 }
 
-void launch_solve(balm_ctx *c, bool new_hessian) {      // damping u = c->d_scal[SCAL_U], set by the caller on the stream
-  hipStream_t s = c->stream;
+void launch_solve(balm_ctx *c, bool new_hessian, int upd_form, const double *upd_poses, double *upd_out) {      // damping u: c->u_value as a kernel argument, or (c->u_on_device: graph
+  hipStream_t s = c->stream;                            // capture / replay) c->d_scal[SCAL_U], put there on the stream by push_damping
   const int n = c->n, nA = c->nA;
+  const double *pu = c->u_on_device ? c->d_scal + SCAL_U : nullptr;
   if (new_hessian)
     hipLaunchKernelGGL(k_rank_diag, dim3((nA + 15) / 16), dim3(256), (size_t)nA * sizeof(double) + 256 * sizeof(int),
                        s, c->d_H, n, nA, c->d_perm);
@@ -808,15 +876,15 @@ void launch_solve(balm_ctx *c, bool new_hessian) {      // damping u = c->d_scal
     int grid = (int)((total + 255) / 256);
     if (grid > 4096) grid = 4096;
     const int P = nA / NB;
-    hipLaunchKernelGGL(k_build_A, dim3(grid), dim3(256), 0, s, c->d_H, c->d_g, n, nA, c->d_perm, c->d_scal + SCAL_U, c->d_A, c->d_flags,
+    hipLaunchKernelGGL(k_build_A, dim3(grid), dim3(256), 0, s, c->d_H, c->d_g, n, nA, c->d_perm, pu, c->u_value, c->d_A, c->d_flags,
                        2 * (2 * P + 1) * P + P + 8);
   }
   launch_factor(c);
   hipLaunchKernelGGL(k_ldl_apply, dim3((nA + 63) / 64, APPLY_CHUNKS), dim3(256), 0, s, c->d_A, nA, c->d_dvec, c->d_z, c->d_x);
   {
     const int P = nA / NB;
-    hipLaunchKernelGGL(k_ldl_finish, dim3(1), dim3(1024), 0, s, c->d_x, nA, n, c->d_perm, c->d_H, c->d_g, c->d_scal + SCAL_U, c->d_dx,
-                       c->d_scal, c->d_flags + (size_t)2 * (2 * P + 1) * P + P);
+    hipLaunchKernelGGL(k_ldl_finish, dim3(1), dim3(1024), 0, s, c->d_x, nA, n, c->d_perm, c->d_H, c->d_g, pu, c->u_value, c->d_dx,
+                       c->d_scal, c->d_flags + (size_t)2 * (2 * P + 1) * P + P, upd_form, c->W, upd_poses, upd_out);
   }
 }
 
@@ -825,61 +893,10 @@ void launch_solve(balm_ctx *c, bool new_hessian) {      // damping u = c->d_scal
 //              right R <- R Exp(dth), p <- p + dt            (bavoxel.hpp:1119-1120)
 // Exp = Rodrigues with the reference's 1e-11 threshold (include/tools.hpp:56-71)
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void exp_so3(const double w[3], double E[3][3]) {
-  const double nn = sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
-  E[0][0] = E[1][1] = E[2][2] = 1.0;
-  E[0][1] = E[0][2] = E[1][0] = E[1][2] = E[2][0] = E[2][1] = 0.0;
-  if (nn >= 1e-11) {
-    const double x = w[0] / nn, y = w[1] / nn, z = w[2] / nn;
-    const double K[3][3] = {{0, -z, y}, {z, 0, -x}, {-y, x, 0}};
-    const double s = sin(nn), c1 = 1.0 - cos(nn);
-#pragma unroll
-    for (int r = 0; r < 3; r++)
-#pragma unroll
-      for (int c = 0; c < 3; c++) {
-        // evaluation order of the reference's `I33 + sin*K + (1-cos)*K*K`: ((1-cos)*K)*K
-        const double kk = (c1 * K[r][0]) * K[0][c] + (c1 * K[r][1]) * K[1][c] + (c1 * K[r][2]) * K[2][c];
-        E[r][c] = (E[r][c] + s * K[r][c]) + kk;
-      }
-  }
-}
-
 __global__ void k_update_poses(int form, int W, const double *__restrict__ poses, const double *__restrict__ dx,
                                double *__restrict__ out) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= W) return;
-  const double *q = poses + 12 * j;
-  const double w[3] = {dx[6 * j], dx[6 * j + 1], dx[6 * j + 2]};
-  const double dt[3] = {dx[6 * j + 3], dx[6 * j + 4], dx[6 * j + 5]};
-  double E[3][3];
-  exp_so3(w, E);
-  double R[3][3], p[3] = {q[9], q[10], q[11]};
-#pragma unroll
-  for (int c = 0; c < 3; c++)
-#pragma unroll
-    for (int r = 0; r < 3; r++) R[r][c] = q[3 * c + r];
-  double Rn[3][3], pn[3];
-  if (form == 0) {
-#pragma unroll
-    for (int r = 0; r < 3; r++) {
-#pragma unroll
-      for (int c = 0; c < 3; c++) Rn[r][c] = E[r][0] * R[0][c] + E[r][1] * R[1][c] + E[r][2] * R[2][c];
-      pn[r] = E[r][0] * p[0] + E[r][1] * p[1] + E[r][2] * p[2] + dt[r];
-    }
-  } else {
-#pragma unroll
-    for (int r = 0; r < 3; r++) {
-#pragma unroll
-      for (int c = 0; c < 3; c++) Rn[r][c] = R[r][0] * E[0][c] + R[r][1] * E[1][c] + R[r][2] * E[2][c];
-      pn[r] = p[r] + dt[r];
-    }
-  }
-  double *o = out + 12 * j;
-#pragma unroll
-  for (int c = 0; c < 3; c++)
-#pragma unroll
-    for (int r = 0; r < 3; r++) o[3 * c + r] = Rn[r][c];
-  o[9] = pn[0]; o[10] = pn[1]; o[11] = pn[2];
+  if (j < W) update_pose(form, j, poses, dx, out);
 }
 
 void launch_update_poses(hipStream_t s, int form, int W, const double *poses, const double *dx, double *out) {
@@ -911,6 +928,34 @@ __global__ __launch_bounds__(256) void k_reanchor(int W, double *__restrict__ po
 
 void launch_reanchor(hipStream_t s, int W, double *poses) {
   hipLaunchKernelGGL(k_reanchor, dim3(1), dim3(256), 0, s, W, poses);
+}
+
+// The 16 scalars of an LM iteration (residuals, q1, ...) straight into the pinned host mirror, the stamp behind them: the host
+// polls the stamp instead of paying a copy command and a hipStreamSynchronize per iteration (balm_capi.hip: wait_scalars)
+// rpart != NULL: scal[slot] = sum of the nr residual partials first (k_sum_scalar's fixed order), in the same launch
+__global__ __launch_bounds__(256) void k_scalars_mail(double *__restrict__ scal, volatile double *__restrict__ host, double stamp,
+                                                      const double *__restrict__ rpart, int nr, int slot) {
+  __shared__ double sred[256];
+  if (rpart) {
+    double s = 0.0;
+    for (int t = threadIdx.x; t < nr; t += 256) s += rpart[t];
+    sred[threadIdx.x] = s;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) {
+      if (threadIdx.x < k) sred[threadIdx.x] += sred[threadIdx.x + k];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) scal[slot] = sred[0];
+    __syncthreads();
+  }
+  if (threadIdx.x < 16) host[threadIdx.x] = (rpart && (int)threadIdx.x == slot) ? sred[0] : scal[threadIdx.x];
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) { host[SCAL_STAMP] = stamp; __threadfence_system(); }
+}
+
+void launch_scalars_mail(hipStream_t s, double *d_scal, double *d_hscal, double stamp, const double *rpart, int nr, int slot) {
+  hipLaunchKernelGGL(k_scalars_mail, dim3(1), dim3(256), 0, s, d_scal, d_hscal, stamp, rpart, nr, slot);
 }
 
 }  // namespace balm
