@@ -339,15 +339,22 @@ int read_scalars(balm_ctx *ctx) {
 // the work model, and the degenerate inputs the evaluators cannot digest: a feature nobody observes and without a
 // fix cluster has NN = 0 (1/NN poisons H, g and the residual of the whole window), a negative weight has no
 // real square-root scaling (the Hessian's rank-3 factors carry sqrt(2 coe)).
-int feature_bookkeeping(balm_ctx *ctx, int F, const double *clusters, const double *fix, const double *coeffs) {
+// obs[a * W + i] != 0: pose i observes feature a (obs_of: from a host table; launch_obs_mask: from a table built on the device)
+std::vector<unsigned char> obs_of(const double *clusters, int F, int W) {
+  std::vector<unsigned char> obs((size_t)F * W);
+  for (size_t t = 0; t < obs.size(); t++) obs[t] = clusters[t * 10 + 9] != 0 ? 1 : 0;
+  return obs;
+}
+
+int feature_bookkeeping(balm_ctx *ctx, int F, const unsigned char *obs, const double *fix, const double *coeffs) {
   const int W = ctx->W;
   ctx->planes_per_pose.assign(W, 0);
   double S = 0, B = 0;
   for (int a = 0; a < F; a++) {
     int na = 0;
-    const double *ca = clusters + (size_t)a * W * 10;
+    const unsigned char *oa = obs + (size_t)a * W;
     for (int i = 0; i < W; i++)
-      if (ca[(size_t)i * 10 + 9] != 0) { ctx->planes_per_pose[i]++; na++; }
+      if (oa[i]) { ctx->planes_per_pose[i]++; na++; }
     if (na == 0 && !(fix && fix[(size_t)a * 10 + 9] != 0)) {
       ctx->err = "feature " + std::to_string(a) + " has no observation and no fix cluster (zero point count)";
       return BALM_ERR_NUMERIC;
@@ -485,7 +492,7 @@ static void one_destroy(balm_ctx *ctx) {
 // (features) are ordered by which 80-row blocks they touch -- features that see the same stretch of the trajectory
 // become neighbours -- and cut into chunks of C features; an item (job, chunk) exists only where the chunk touches
 // the job's row blocks.  Chosen when it issues < 80 % of the dense plan's MFMAs (BALM_SYRK=dense|sparse forces).
-static int build_sparse_plan(balm_ctx *ctx, int F, const double *clusters) {
+static int build_sparse_plan(balm_ctx *ctx, int F, const unsigned char *obs) {
   ctx->sparse = false;
   const char *mode = getenv("BALM_SYRK");
   if (mode && !strcmp(mode, "dense")) return BALM_OK;
@@ -495,9 +502,9 @@ static int build_sparse_plan(balm_ctx *ctx, int F, const double *clusters) {
   std::vector<Key> keys((size_t)F);
   for (int a = 0; a < F; a++) {
     uint64_t hi = 0, lo = 0;
-    const double *ca = clusters + (size_t)a * W * 10;
+    const unsigned char *oa = obs + (size_t)a * W;
     for (int i = 0; i < W; i++)
-      if (ca[(size_t)i * 10 + 9] != 0)
+      if (oa[i])
         for (int b = (6 * i) / TILE; b <= (6 * i + 5) / TILE; b++) {      // a pose's six rows may straddle two blocks
           if (b < 64) hi |= 1ull << (63 - b); else lo |= 1ull << (127 - b);   // block 0 = most significant bit
         }
@@ -572,16 +579,17 @@ static int build_sparse_plan(balm_ctx *ctx, int F, const double *clusters) {
   return BALM_OK;
 }
 
-static int install_feature_buffers(balm_ctx *ctx, int F, const double *fix, const double *coeffs) {
+static int install_feature_buffers(balm_ctx *ctx, int F, const double *fix, const double *coeffs,
+                                   hipMemcpyKind kind = hipMemcpyHostToDevice) {       // (DeviceToDevice: a table built on the device)
   int rc;
   drop_lm_graphs(ctx);
   ctx->has_fix = fix != nullptr;
   if (fix) {
     if ((rc = keep(ctx, &ctx->d_fix, &ctx->cap_fix, (size_t)F * 10))) return rc;
-    HIP_TRY(hipMemcpyAsync(ctx->d_fix, fix, (size_t)F * 10 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(ctx->d_fix, fix, (size_t)F * 10 * sizeof(double), kind, ctx->stream));
   }
   if ((rc = keep(ctx, &ctx->d_coe, &ctx->cap_coe, (size_t)F))) return rc;
-  HIP_TRY(hipMemcpyAsync(ctx->d_coe, coeffs, (size_t)F * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(ctx->d_coe, coeffs, (size_t)F * sizeof(double), kind, ctx->stream));
   if ((rc = keep(ctx, &ctx->d_C, &ctx->cap_C, (size_t)F * 10))) return rc;
   if ((rc = keep(ctx, &ctx->d_feat, &ctx->cap_feat, (size_t)F * FEAT_STRIDE))) return rc;
   if ((rc = keep(ctx, &ctx->d_feat_tmp, &ctx->cap_feat_tmp, (size_t)F * FEAT_STRIDE))) return rc;
@@ -592,6 +600,8 @@ static int install_feature_buffers(balm_ctx *ctx, int F, const double *fix, cons
   return BALM_OK;
 }
 
+static int assoc_clusters_host(balm_ctx *ctx);
+
 static int one_set_features(balm_ctx *ctx, int F, const double *clusters, const double *fix, const double *coeffs) {
   if (!ctx) return BALM_ERR_ARG;
   if (ctx->multi && F == 0) { ctx->F = 0; ctx->feat_cur_valid = false; ctx->gt_cur_valid = false; return BALM_OK; }      // a shard without features
@@ -600,6 +610,7 @@ static int one_set_features(balm_ctx *ctx, int F, const double *clusters, const 
   const int W = ctx->W;
   const size_t count = (size_t)F * W * 10;
   int rc;
+  if ((rc = assoc_clusters_host(ctx))) return rc;          // (an association's table not fetched yet: d_cl is about to be overwritten)
   ctx->F = 0;
   if ((rc = keep(ctx, &ctx->d_cl, &ctx->cap_cl, count))) return rc;
   if ((rc = stage_begin(ctx, count * sizeof(double)))) return rc;
@@ -610,8 +621,11 @@ static int one_set_features(balm_ctx *ctx, int F, const double *clusters, const 
     e = hipStreamSynchronize(ctx->stream);
   }
   HIP_TRY(e);
-  if (!ctx->multi && (rc = feature_bookkeeping(ctx, F, clusters, fix, coeffs))) return rc;    // sharded: done once on the whole table
-  if ((rc = build_sparse_plan(ctx, F, clusters))) return rc;
+  {
+    const std::vector<unsigned char> obs = obs_of(clusters, F, W);
+    if (!ctx->multi && (rc = feature_bookkeeping(ctx, F, obs.data(), fix, coeffs))) return rc;    // sharded: done once on the whole table
+    if ((rc = build_sparse_plan(ctx, F, obs.data()))) return rc;
+  }
   if ((rc = install_feature_buffers(ctx, F, fix, coeffs))) return rc;
   return sync_stream(ctx);
 }
@@ -626,6 +640,7 @@ static int one_build_clusters(balm_ctx *ctx, int F, const float *xyz, const int 
   const int W = ctx->W;
   const size_t count = (size_t)F * W * 10;
   int rc;
+  if ((rc = assoc_clusters_host(ctx))) return rc;
   ctx->F = 0;
   if ((rc = keep(ctx, &ctx->d_cl, &ctx->cap_cl, count))) return rc;
   const size_t np1 = (size_t)(n_pts ? n_pts : 1);
@@ -665,8 +680,11 @@ static int one_build_clusters(balm_ctx *ctx, int F, const float *xyz, const int 
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
   HIP_TRY(e);
   if (clusters_out) std::memcpy(clusters_out, host.data(), count * sizeof(double));
-  if ((rc = feature_bookkeeping(ctx, F, host.data(), fix, coeffs))) return rc;
-  if ((rc = build_sparse_plan(ctx, F, host.data()))) return rc;
+  {
+    const std::vector<unsigned char> obs = obs_of(host.data(), F, W);
+    if ((rc = feature_bookkeeping(ctx, F, obs.data(), fix, coeffs))) return rc;
+    if ((rc = build_sparse_plan(ctx, F, obs.data()))) return rc;
+  }
   if ((rc = install_feature_buffers(ctx, F, fix, coeffs))) return rc;
   return sync_stream(ctx);
 }
@@ -687,31 +705,59 @@ static int install_associated(balm_ctx *ctx, int F, double *d_out, double *d_coe
                               bool has_fix, bool owned = true) {
   const int W = ctx->W;
   const size_t count = (size_t)F * W * 10;
-  ctx->assoc_clusters.resize(count); ctx->assoc_coeffs.resize(F); ctx->assoc_layer.resize(F); ctx->assoc_fix.resize((size_t)F * 10);
+  // The table never leaves the device on this path (round 3): d_out -> d_cl by a transpose, weights and fix clusters device to
+  // device.  The host gets what its bookkeeping needs -- one byte per (feature, pose), the weights, fix clusters and layers --
+  // and the clusters themselves only if somebody asks (balm_get_features fetches them from d_cl): 32 MB of pageable D2H per
+  // association of the shipped window, 3 of balm_associate's 10.5 ms through the C ABI.
+  ctx->assoc_clusters.clear(); ctx->assoc_cl_on_device = false;
+  ctx->assoc_coeffs.resize(F); ctx->assoc_layer.resize(F); ctx->assoc_fix.resize((size_t)F * 10);
   if (d_pf) ctx->assoc_point_feat.resize((size_t)n_pts);
+  std::vector<unsigned char> obs((size_t)F * W);
   hipError_t e = hipSuccess;
   int rc = keep(ctx, &ctx->d_cl, &ctx->cap_cl, count);
+  if (!rc) rc = stage_begin(ctx, obs.size());
   if (!rc) {
+    unsigned char *d_obs = stage_take<unsigned char>(ctx, obs.size());
     launch_transpose_clusters(ctx->stream, d_out, ctx->d_cl, F, W);
-    e = hipMemcpyAsync(ctx->assoc_clusters.data(), d_out, count * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+    launch_obs_mask(ctx->stream, ctx->d_cl, F, W, d_obs);
+    e = hipMemcpyAsync(obs.data(), d_obs, obs.size(), hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(ctx->assoc_coeffs.data(), d_coe, (size_t)F * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(ctx->assoc_fix.data(), d_fix, (size_t)F * 10 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(ctx->assoc_layer.data(), d_lay, (size_t)F * sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess && d_pf)
       e = hipMemcpyAsync(ctx->assoc_point_feat.data(), d_pf, (size_t)n_pts * sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) rc = BALM_ERR_HIP;
   }
+  if (!rc) rc = feature_bookkeeping(ctx, F, obs.data(), has_fix ? ctx->assoc_fix.data() : nullptr, ctx->assoc_coeffs.data());
+  if (!rc) rc = build_sparse_plan(ctx, F, obs.data());
+  if (!rc) rc = install_feature_buffers(ctx, F, has_fix ? d_fix : nullptr, d_coe, hipMemcpyDeviceToDevice);
+  if (!rc) rc = sync_stream(ctx);
   if (owned) {
     hipFree(d_out); hipFree(d_coe); hipFree(d_fix); hipFree(d_lay);
     if (d_pf) hipFree(d_pf);
   }
+  if (rc == BALM_ERR_HIP && e != hipSuccess) { ctx->err = hipGetErrorString(e); return rc; }
   if (rc) return rc;
-  HIP_TRY(e);
-  const double *fix = has_fix ? ctx->assoc_fix.data() : nullptr;
-  if ((rc = feature_bookkeeping(ctx, F, ctx->assoc_clusters.data(), fix, ctx->assoc_coeffs.data()))) return rc;
-  if ((rc = build_sparse_plan(ctx, F, ctx->assoc_clusters.data()))) return rc;
-  if ((rc = install_feature_buffers(ctx, F, fix, ctx->assoc_coeffs.data()))) return rc;
-  return sync_stream(ctx);
+  ctx->assoc_cl_on_device = true;
+  return BALM_OK;
+}
+
+// the association's clusters on the host ([F][W][10], the caller's layout), fetched from d_cl the first time somebody wants them
+static int assoc_clusters_host(balm_ctx *ctx) {
+  if (!ctx->assoc_clusters.empty() || !ctx->assoc_cl_on_device) return BALM_OK;
+  const int F = (int)ctx->assoc_coeffs.size(), W = ctx->W;
+  const size_t count = (size_t)F * W * 10;
+  HIP_TRY(hipSetDevice(ctx->device));
+  int rc = stage_begin(ctx, count * sizeof(double));
+  if (rc) return rc;
+  double *d_aos = stage_take<double>(ctx, count);
+  ctx->assoc_clusters.resize(count);
+  launch_soa_to_aos(ctx->stream, ctx->d_cl, d_aos, F, W);
+  HIP_TRY(hipMemcpyAsync(ctx->assoc_clusters.data(), d_aos, count * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  ctx->assoc_cl_on_device = false;
+  return BALM_OK;
 }
 
 static int one_associate(balm_ctx *ctx, const balm_voxel_opts *opts, const float *xyz, const int *frame_id, long n_pts,
@@ -857,7 +903,11 @@ static int one_window_features(balm_ctx *ctx, int *F_out) {
 int balm_get_features(balm_ctx *ctx, double *clusters, double *coeffs, int *layer) {
   if (!ctx) return BALM_ERR_ARG;
   if (ctx->assoc_coeffs.empty()) { ctx->err = "balm_get_features: no balm_associate result"; return BALM_ERR_STATE; }
-  if (clusters) std::memcpy(clusters, ctx->assoc_clusters.data(), ctx->assoc_clusters.size() * sizeof(double));
+  if (clusters) {
+    if (int rc = assoc_clusters_host(ctx)) return rc;
+    if (ctx->assoc_clusters.empty()) { ctx->err = "balm_get_features: the association's table is gone"; return BALM_ERR_STATE; }
+    std::memcpy(clusters, ctx->assoc_clusters.data(), ctx->assoc_clusters.size() * sizeof(double));
+  }
   if (coeffs) std::memcpy(coeffs, ctx->assoc_coeffs.data(), ctx->assoc_coeffs.size() * sizeof(double));
   if (layer) std::memcpy(layer, ctx->assoc_layer.data(), ctx->assoc_layer.size() * sizeof(int));
   return BALM_OK;
@@ -1250,7 +1300,7 @@ int balm_comm_init_rank(balm_ctx *ctx, int n_ranks, int rank, const void *id128)
 static int multi_set_features(balm_ctx *ctx, balm_multi *m, int F, const double *clusters, const double *fix, const double *coeffs) {
   if (F < 1 || !clusters || !coeffs) { ctx->err = "balm_set_features: bad argument"; return BALM_ERR_ARG; }
   m->F = 0;
-  int rc = feature_bookkeeping(ctx, F, clusters, fix, coeffs);
+  int rc = feature_bookkeeping(ctx, F, obs_of(clusters, F, ctx->W).data(), fix, coeffs);
   if (rc) return rc;
   // contiguous shards of equal COST: a feature costs its observed pose pairs n_a (n_a + 1) / 2 (the block-sparse SYRK
   // plan skips what it does not observe; with dense co-visibility every feature costs the same and this is an equal split)
@@ -1313,6 +1363,7 @@ int balm_associate(balm_ctx *ctx, const balm_voxel_opts *opts, const float *xyz,
   ctx->multi = m;
   m->F = 0;
   if (rc || *F_out == 0) return rc;
+  if ((rc = assoc_clusters_host(ctx))) return rc;          // the shards are cut from the host copy
   return multi_set_features(ctx, m, *F_out, ctx->assoc_clusters.data(), opts->fix_frames > 0 ? ctx->assoc_fix.data() : nullptr,
                             ctx->assoc_coeffs.data());
 }
@@ -1331,6 +1382,7 @@ int balm_window_features(balm_ctx *ctx, int *F_out) {
   ctx->multi = m;
   m->F = 0;
   if (rc || *F_out == 0) return rc;
+  if ((rc = assoc_clusters_host(ctx))) return rc;
   return multi_set_features(ctx, m, *F_out, ctx->assoc_clusters.data(), ctx->assoc_fix.data(), ctx->assoc_coeffs.data());
 }
 int balm_window_info(balm_ctx *ctx, int *scans, long *points, long *nodes) {

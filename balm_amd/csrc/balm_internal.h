@@ -127,7 +127,8 @@ struct balm_ctx {
   // host bookkeeping
   std::vector<int> planes_per_pose;
   double work_S = 0, work_B = 0;
-  std::vector<double> assoc_clusters, assoc_coeffs;   // host copies of the last balm_associate
+  std::vector<double> assoc_clusters, assoc_coeffs;   // host copies of the last balm_associate (the clusters: fetched from d_cl on first use)
+  bool assoc_cl_on_device = false;  // d_cl still holds that association's table and assoc_clusters has not been fetched yet
   std::vector<int> assoc_layer, assoc_point_feat;
   std::vector<double> assoc_fix;
   balm::WindowSession *window = nullptr;   // balm_window_*: the sliding-window map (kernels_window.inc)
@@ -279,5 +280,6 @@ void launch_build_clusters(hipStream_t s, const float *xyz, const int *feat_id, 
 void launch_build_clusters_any(hipStream_t s, const float *xyz, const int *feat_id, const int *pose_id, long n_pts,
                                int F, int W, double *soa);                       // any order: atomics
 void launch_soa_to_aos(hipStream_t s, const double *soa, double *aos, int F, int W);
+void launch_obs_mask(hipStream_t s, const double *soa, int F, int W, unsigned char *mask);      // N != 0 per (feature, pose)
 
 }  // namespace balm

@@ -74,6 +74,25 @@ __global__ void k_transpose_clusters(const double *__restrict__ aos, double *__r
   }
 }
 
+// which (feature, pose) pairs are observed (N != 0), one byte each, from the per-feature SoA table: all the host needs of a
+// feature table that was built on the device (planes per pose, work model, block-sparse plan) -- F x W bytes instead of the
+// F x W x 80 bytes of the table itself
+__global__ void k_obs_mask(const double *__restrict__ soa, int F, int W, unsigned char *__restrict__ mask) {
+  const size_t total = (size_t)F * W;
+  for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+    const size_t a = t / W;
+    const int i = (int)(t - a * W);
+    mask[t] = soa[a * 10 * W + (size_t)9 * W + i] != 0.0 ? 1 : 0;
+  }
+}
+
+void launch_obs_mask(hipStream_t s, const double *soa, int F, int W, unsigned char *mask) {
+  const size_t total = (size_t)F * W;
+  int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  if (grid < 1) grid = 1;
+  hipLaunchKernelGGL(k_obs_mask, dim3(grid), dim3(256), 0, s, soa, F, W, mask);
+}
+
 void launch_transpose_clusters(hipStream_t s, const double *aos, double *soa, int F, int W) {
   size_t total = (size_t)F * W;
   int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
