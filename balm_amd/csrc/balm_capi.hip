@@ -465,6 +465,7 @@ balm_ctx *balm_create(int win_size, int device, int flags) {
   }
   if (hipMemset(ctx->d_scal, 0, 16 * sizeof(double)) != hipSuccess) return fail();
   if (hipMemset(ctx->d_red, 0, ctx->red_len * sizeof(double)) != hipSuccess) return fail();
+  if (hipMemset(ctx->d_minv, 0, (size_t)(nA / NB) * NB * NB * sizeof(double)) != hipSuccess) return fail();
   return ctx;
 }
 
@@ -979,7 +980,9 @@ static int one_pose_covariance(balm_ctx *ctx, const double *poses, const double 
     launch_cov_assemble(s, redx, redy, sdiag, ctx->d_sub, ctx->ntiles, W, Rraw);
     hipMemsetAsync(ctx->d_g, 0, (size_t)n * sizeof(double), s);
     set_damping(ctx, 0.0);
+    ctx->need_minv = true;                               // M = L^-T D^+ is what the congruence below multiplies with
     launch_solve(ctx, true);                             // P H P^T = L D L^T stays in d_A / d_dvec / d_perm
+    ctx->need_minv = false;
     launch_congruence_inverse(ctx, Rraw, T0, T1, Rc);
     if (Rcov) e = hipMemcpyAsync(Rcov, Rc, nn * sizeof(double), hipMemcpyDeviceToHost, s);
     if (e == hipSuccess && Rcov_raw) e = hipMemcpyAsync(Rcov_raw, Rraw, nn * sizeof(double), hipMemcpyDeviceToHost, s);

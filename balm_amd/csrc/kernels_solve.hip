@@ -65,12 +65,14 @@ __global__ __launch_bounds__(256) void k_rank_diag(const double *__restrict__ H,
 
 __global__ __launch_bounds__(256) void k_build_A(const double *__restrict__ H, const double *__restrict__ g, int n,
                                                  int nA, const int *__restrict__ perm, const double *__restrict__ pu, double u_arg,
-                                                 double *__restrict__ A, int *__restrict__ flags, int nflags) {
+                                                 double *__restrict__ A, int *__restrict__ flags, int nflags, double *__restrict__ xs) {
   const double u = pu ? *pu : u_arg;    // replayed hipGraphs read the damping from device memory (the launch sequence of an LM
                                         // iteration is then the same for every iteration); plain launches carry it as an argument
   const int ldA = 2 * nA + NB;
   const long total = (long)ldA * nA;
   for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < nflags; t += (long)gridDim.x * blockDim.x) flags[t] = 0;
+  // k_ldl_backsolve's exchange buffer: "not there yet" = all ones (kernels_chain.inc)
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < nA; t += (long)gridDim.x * blockDim.x) xs[t] = __longlong_as_double(-1ll);
   for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
     const int c = (int)(t / ldA), r = (int)(t - (long)c * ldA);
     const int pc = perm[c];
@@ -727,7 +729,8 @@ __global__ __launch_bounds__(1024) void k_ldl_finish(const double *__restrict__ 
                                                      const int *__restrict__ perm, const double *__restrict__ H,
                                                      const double *__restrict__ g, const double *__restrict__ pu, double u_arg,
                                                      double *__restrict__ dx, double *__restrict__ scal, const int *__restrict__ abort_flag,
-                                                     int upd_form, int W, const double *__restrict__ poses, double *__restrict__ poses_out) {
+                                                     int upd_form, int W, const double *__restrict__ poses, double *__restrict__ poses_out,
+                                                     int nchunks) {
   const double u = pu ? *pu : u_arg;
   // a persistent factorisation that gave up on a flag (k_ldl_chain's bounded waits) must not pass for a solution
   const double poison = *abort_flag ? __longlong_as_double(0x7ff8000000000000ll) : 0.0;
@@ -738,8 +741,7 @@ __global__ __launch_bounds__(1024) void k_ldl_finish(const double *__restrict__ 
     const int p = perm[r];
     if (p < n) {
       double xv = 0.0;
-#pragma unroll
-      for (int k = 0; k < APPLY_CHUNKS; k++) xv += x[(size_t)k * nA + r];       // partial products of k_ldl_apply
+      for (int k = 0; k < nchunks; k++) xv += x[(size_t)k * nA + r];            // partial products of k_ldl_apply (or k_ldl_backsolve's x)
       xv += poison;
       dx[p] = xv;
       q += xv * (u * H[(size_t)p * n + p] * xv - g[p]);
@@ -780,6 +782,18 @@ constexpr int FUSED_MAX_P = 40;              // the persistent kernel wins for 1
 // wherever a persistent kernel is the choice at all -- it beats k_ldl_fused at every size (profiles/r03d_solve_paths_by_window.txt:
 // n = 1200: 0.283 vs 0.428 ms) and the launch path from 5 to 40 panels (n = 240: 0.086 vs 0.089, n = 1920: 0.73 vs 0.84).
 constexpr int CHAIN_MIN_P = 5, CHAIN_MAX_P = 40;
+// ... and above that, up to 100 panels (n = 4800), k_ldl_chain on [A ; rhs] alone followed by the block back-substitution
+// k_ldl_backsolve (kernels_chain.inc): the identity rows that yield L^-T D^+ are 70 % of the far updates at P = 63.  Not when the
+// caller needs that inverse (balm_pose_covariance: c->need_minv).  BALM_SOLVE=chainb forces it from CHAIN_MIN_P panels on.
+constexpr int CHAINB_MIN_P = 31, CHAINB_MAX_P = 100;      // (the capacity check of the launch decides above ~100)
+static bool solve_wants_backsub(const balm_ctx *c) {
+  const int P = c->nA / NB;
+  const char *mode = getenv("BALM_SOLVE");
+  if (c->need_minv || c->chain_cap == 0 || (c->multi && c->multi->n > 1)) return false;
+  if (mode && !strcmp(mode, "chainb")) return P >= CHAIN_MIN_P && P <= CHAINB_MAX_P;
+  if (mode) return false;                              // launches / fused / chain: the other paths, as asked
+  return P >= CHAINB_MIN_P && P <= CHAINB_MAX_P;
+}
 static bool solve_wants_chain(const balm_ctx *c, const char *mode) {
   if (mode && !strcmp(mode, "chain")) return true;
   if (mode && !strcmp(mode, "fused")) return false;
@@ -796,6 +810,7 @@ bool solve_is_persistent(const balm_ctx *c) {
   // solve at n = 1200); one process per GPU (balm_comm_init_rank) is not affected.
   if (c->multi && c->multi->n > 1) return false;
   if (mode && !strcmp(mode, "launches")) return false;
+  if (solve_wants_backsub(c)) return true;
   if (forced) return P >= 2 && (c->fused_cap != 0 || c->chain_cap != 0);
   return (P >= CHAIN_MIN_P && P <= CHAIN_MAX_P && c->chain_cap != 0) || (P >= 18 && P <= FUSED_MAX_P && c->fused_cap != 0);
 }
@@ -803,10 +818,14 @@ bool solve_is_persistent(const balm_ctx *c) {
 static void launch_factor(balm_ctx *c) {
   hipStream_t s = c->stream;
   const int nA = c->nA, P = nA / NB;
-  const bool want_fused = solve_is_persistent(c);
-  {
+  bool want_fused = solve_is_persistent(c);
+  c->solve_backsub = false;
+  if (want_fused && solve_wants_backsub(c)) {
+    if (launch_factor_chain(c, /*ident=*/getenv("BALM_CHAINB_IDENT") != nullptr)) { c->solve_backsub = true; return; }      // (debug: identity rows kept)
+    if (P > FUSED_MAX_P) want_fused = false;             // (refused: such a window is the launch path's, not k_ldl_fused's)
+  } else {
     const char *mode = getenv("BALM_SOLVE");
-    if (want_fused && solve_wants_chain(c, mode) && launch_factor_chain(c)) return;
+    if (want_fused && solve_wants_chain(c, mode) && launch_factor_chain(c, true)) return;
   }
   if (want_fused) {
     const size_t lds = (size_t)(12 * FLR + 2 * NB * NB + NB) * sizeof(double);
@@ -877,14 +896,20 @@ void launch_solve(balm_ctx *c, bool new_hessian, int upd_form, const double *upd
     if (grid > 4096) grid = 4096;
     const int P = nA / NB;
     hipLaunchKernelGGL(k_build_A, dim3(grid), dim3(256), 0, s, c->d_H, c->d_g, n, nA, c->d_perm, pu, c->u_value, c->d_A, c->d_flags,
-                       2 * (2 * P + 1) * P + P + 8);
+                       2 * (2 * P + 1) * P + P + 8, c->d_x + nA);
   }
   launch_factor(c);
-  hipLaunchKernelGGL(k_ldl_apply, dim3((nA + 63) / 64, APPLY_CHUNKS), dim3(256), 0, s, c->d_A, nA, c->d_dvec, c->d_z, c->d_x);
+  if (c->solve_backsub) {           // x (permuted order) -> chunk 0 of d_x; chunk 1 is the workgroups' exchange buffer
+    const int P = nA / NB;
+    hipLaunchKernelGGL(k_ldl_backsolve, dim3(P), dim3(256), 0, s, c->d_A, nA, P, c->d_minv, c->d_dvec, c->d_z, c->d_x + nA, c->d_x,
+                       c->d_flags + (size_t)2 * (2 * P + 1) * P + P);
+  } else {
+    hipLaunchKernelGGL(k_ldl_apply, dim3((nA + 63) / 64, APPLY_CHUNKS), dim3(256), 0, s, c->d_A, nA, c->d_dvec, c->d_z, c->d_x);
+  }
   {
     const int P = nA / NB;
     hipLaunchKernelGGL(k_ldl_finish, dim3(1), dim3(1024), 0, s, c->d_x, nA, n, c->d_perm, c->d_H, c->d_g, pu, c->u_value, c->d_dx,
-                       c->d_scal, c->d_flags + (size_t)2 * (2 * P + 1) * P + P, upd_form, c->W, upd_poses, upd_out);
+                       c->d_scal, c->d_flags + (size_t)2 * (2 * P + 1) * P + P, upd_form, c->W, upd_poses, upd_out, c->solve_backsub ? 1 : APPLY_CHUNKS);
   }
 }
 

@@ -164,6 +164,31 @@ def test_large_window_solve_of_an_lm_hessian_matches_lapack():
     c.close()
 
 
+@pytest.mark.parametrize("W", [40, 41, 64, 100, 200, 328, 336, 400, 500, 640, 700, 800])
+@pytest.mark.parametrize("kind", ["spd", "indefinite"])
+def test_chain_kernel_with_back_substitution_matches_lapack(W, kind):
+    """k_ldl_chain on [A ; rhs] alone + k_ldl_backsolve (round 3: the default from 41 to 100 panels, i.e. 328 .. 800 poses;
+    BALM_SOLVE=chainb forces it from 5 panels on) against LAPACK and against the launch path, solve after solve (the exchange
+    buffer and the flags are re-armed per solve); a vanished pivot (indefinite case aside: an exactly singular block) is the
+    pseudo-inverse in both"""
+    H, g = _test_matrix(W, kind, 31 * W + (kind == "spd"))
+    u = 0.1
+    ref = np.linalg.solve(H + u * np.diag(np.diag(H)), -g)
+    c = capi.Context(W)
+    os.environ["BALM_SOLVE"] = "chainb"
+    try:
+        for _ in range(3):
+            dx, q1 = c.solve_damped(H, g, u)
+            assert np.all(np.isfinite(dx)), "k_ldl_chain / k_ldl_backsolve gave up on a flag (bounded waits) or was not launched"
+            assert rel_err(dx, ref) < 1e-9
+        os.environ["BALM_SOLVE"] = "launches"
+        dx0, q0 = c.solve_damped(H, g, u)
+        assert rel_err(dx, dx0) < 1e-10 and abs(q1 - q0) <= 1e-10 * abs(q0)
+    finally:
+        os.environ.pop("BALM_SOLVE", None)
+    c.close()
+
+
 @pytest.mark.parametrize("W", [8, 9, 16, 17, 24, 33, 48, 64, 100, 144, 177, 200, 256, 320, 400, 500])
 @pytest.mark.parametrize("kind", ["spd", "indefinite"])
 def test_chain_kernel_matches_lapack(W, kind):

@@ -18,8 +18,8 @@ for W in Ws:
     g = rng.standard_normal(n)
     c = capi.Context(W, 0, capi.FLAG_TIMING)
     row = []
-    for mode in ("launches", "lookahead", "fused", "chain"):
-        os.environ["BALM_SOLVE"] = mode if mode in ("fused", "chain") else "launches"
+    for mode in ("launches", "lookahead", "fused", "chain", "chainb"):
+        os.environ["BALM_SOLVE"] = mode if mode in ("fused", "chain", "chainb") else "launches"
         os.environ["BALM_LOOKAHEAD"] = "1" if mode == "lookahead" else "0"
         for _ in range(3):
             dx, _ = c.solve_damped(H, g, 0.1)
@@ -29,7 +29,7 @@ for W in Ws:
         ms, cnt = c.timing()["solve"]
         row.append(ms / cnt)
     ref = np.linalg.solve(H + 0.1 * np.diag(np.diag(H)), -g)
-    err = np.abs(dx - ref).max() / np.abs(ref).max()
+    err_b = np.abs(dx - ref).max() / np.abs(ref).max()      # (the last forced mode: chainb)
     os.environ.pop("BALM_SOLVE", None); os.environ.pop("BALM_LOOKAHEAD", None)
     for _ in range(3):
         dx, _ = c.solve_damped(H, g, 0.1)
@@ -37,8 +37,9 @@ for W in Ws:
     for _ in range(10):
         dx, _ = c.solve_damped(H, g, 0.1)
     ms, cnt = c.timing()["solve"]
-    print("W=%4d n=%5d  launches %.3f ms   + lookahead %.3f ms   fused (r2) %.3f ms   chain (r3) %.3f ms   default %.3f ms   err %.1e"
-          % (W, n, row[0], row[1], row[2], row[3], ms / cnt, err), flush=True)
+    err = np.abs(dx - ref).max() / np.abs(ref).max()
+    print("W=%4d n=%5d  launches %.3f ms   + lookahead %.3f ms   fused (r2) %.3f ms   chain (r3) %.3f ms   chain+backsolve %.3f ms   default %.3f ms   err %.1e (backsolve %.1e)"
+          % (W, n, row[0], row[1], row[2], row[3], row[4], ms / cnt, err, err_b), flush=True)
     c.close()
 
 if os.environ.get("BALM_SOLVE_TRACE"):
