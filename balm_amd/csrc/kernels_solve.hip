@@ -785,12 +785,12 @@ constexpr int CHAIN_MIN_P = 5, CHAIN_MAX_P = 40;
 // ... and above that, up to 100 panels (n = 4800), k_ldl_chain on [A ; rhs] alone followed by the block back-substitution
 // k_ldl_backsolve (kernels_chain.inc): the identity rows that yield L^-T D^+ are 70 % of the far updates at P = 63.  Not when the
 // caller needs that inverse (balm_pose_covariance: c->need_minv).  BALM_SOLVE=chainb forces it from CHAIN_MIN_P panels on.
-constexpr int CHAINB_MIN_P = 31, CHAINB_MAX_P = 100;      // (the capacity check of the launch decides above ~100)
+constexpr int CHAINB_MIN_P = 31, CHAINB_MAX_P = 66;       // n = 1488 .. 3168 (profiles/r03t_solve_paths_by_window.txt); forced: up to 100 panels
 static bool solve_wants_backsub(const balm_ctx *c) {
   const int P = c->nA / NB;
   const char *mode = getenv("BALM_SOLVE");
   if (c->need_minv || c->chain_cap == 0 || (c->multi && c->multi->n > 1)) return false;
-  if (mode && !strcmp(mode, "chainb")) return P >= CHAIN_MIN_P && P <= CHAINB_MAX_P;
+  if (mode && !strcmp(mode, "chainb")) return P >= CHAIN_MIN_P && P <= 100;
   if (mode) return false;                              // launches / fused / chain: the other paths, as asked
   return P >= CHAINB_MIN_P && P <= CHAINB_MAX_P;
 }
