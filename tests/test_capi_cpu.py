@@ -59,3 +59,15 @@ def test_syrk_accumulators_stay_pinned():
     if not os.path.exists(obj) or not os.path.exists(check_syrk_agprs.LLVM + "/llvm-objdump"):
         pytest.skip("object file or llvm-objdump not present")
     assert check_syrk_agprs.check(obj, verbose=False) == []
+
+
+def test_persistent_solve_kernels_keep_their_coherent_stores_and_loads():
+    """the hand-over protocol of k_ldl_chain / k_ldl_fused / k_ldl_backsolve rests on agent-scope atomics being lowered to
+    write-through (sc1) stores, coherent loads and buffer_inv -- and on no buffer_wbl2 (tools/check_solve_sync.py
+    disassembles the built object); a changed lowering would only show on a GPU, as rare wrong solutions"""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import check_solve_sync
+    obj = os.path.join(ROOT, "balm_amd", "lib", "kernels_solve.o")
+    if not os.path.exists(obj) or not os.path.exists(check_solve_sync.LLVM + "/llvm-objdump"):
+        pytest.skip("no built object / no llvm-objdump")
+    assert check_solve_sync.check(obj, verbose=False) == []
