@@ -2,6 +2,7 @@
 include/balm_hip.h declares; without a GPU the product path fails loudly (no CPU fallback)."""
 import os
 import re
+import sys
 
 import pytest
 
