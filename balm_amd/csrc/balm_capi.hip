@@ -447,7 +447,7 @@ balm_ctx *balm_create(int win_size, int device, int flags) {
       dalloc(ctx, &ctx->d_perm, (size_t)nA) || dalloc(ctx, &ctx->d_flags, (size_t)2 * (2 * (nA / NB) + 1) * (nA / NB) + (nA / NB) + 8) || dalloc(ctx, &ctx->d_minv, (size_t)(nA / NB) * NB * NB) || dalloc(ctx, &ctx->d_dx, (size_t)n) ||
       dalloc(ctx, &ctx->d_scal, (size_t)16) || dalloc(ctx, &ctx->d_pre, (size_t)W + 2))
     return fail();
-  if (hipHostMalloc((void **)&ctx->h_scal, (16 + 64 + 8) * sizeof(double), hipHostMallocMapped) != hipSuccess) return fail();
+  if (hipHostMalloc((void **)&ctx->h_scal, (16 + 64 + 8) * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) return fail();
   if (hipHostGetDevicePointer((void **)&ctx->d_hscal, ctx->h_scal, 0) != hipSuccess) return fail();
   ctx->h_scal[SCAL_STAMP] = 0.0;
   if (hipMemcpy(ctx->d_jobs, jobs.data(), jobs.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess ||
