@@ -29,7 +29,10 @@ for W, mode in ((200, "chain"), (300, "chainb"), (400, "chainb"), (500, "chainb"
     NH = min(NH, (P - 2) * P if mode == "chain" else P * (P - 1) // 2 - 1)
     st = t[off:off + 4 * NH].reshape(NH, 4)
     upd, busy, idle = st[:, 0], st[:, 1] / 100.0, st[:, 2] / 100.0      # 100 MHz ticks -> us
+    load, mfma = (st[:, 3] >> 32) / 100.0, (st[:, 3] & 0xffffffff) / 100.0
     ch = t[:P * 16].reshape(P, 16)
     print("W=%d n=%d P=%d %s: solve %.3f ms; %d helpers: updates %d total (%.0f..%.0f per helper), busy %.0f us avg (%.2f us per update), idle %.0f us avg, max busy %.0f us"
           % (W, n, P, mode, ms, NH, upd.sum(), upd.min(), upd.max(), busy.mean(), busy.sum() / max(upd.sum(), 1), idle.mean(), busy.max()))
+    print("      per update: %.2f us until tile + operands are in LDS, %.2f us MFMAs + choice of the next job, %.2f us store / publish"
+          % (load.sum() / max(upd.sum(), 1), mfma.sum() / max(upd.sum(), 1), (busy.sum() - load.sum() - mfma.sum()) / max(upd.sum(), 1)))
     c.close()

@@ -7,4 +7,4 @@ timeout 1500 python -m pytest tests/test_gpu_solve.py tests/test_gpu_parity.py t
 { echo "# tools/bench_solve.py on MI355X, device ms per balm_solve_damped (HIP events); chain+backsolve = k_ldl_chain on [A ; rhs] + k_ldl_backsolve (default for 31..66 panels)"
   timeout 900 python tools/bench_solve.py 2>&1 | cut -c1-230; } | tee gpurun_out/r03t_solve_paths_by_window.txt
 { echo "# tools/chain_helpers.py (BALM_SOLVE_TRACE=1): the helper workgroups of k_ldl_chain during one factorisation"
-  timeout 600 python tools/chain_helpers.py 2>&1 | tail -5; } | tee gpurun_out/r03t_chain_helpers.txt
+  timeout 600 python tools/chain_helpers.py 2>&1 | tail -8; } | tee gpurun_out/r03t_chain_helpers.txt
