@@ -116,6 +116,7 @@ struct balm_ctx {
   double *d_hscal = nullptr;        // its device alias: k_scalars_mail writes the mirror and the stamp straight into host memory
   unsigned long long mail_seq = 0;  // stamp of the last k_scalars_mail launch
   bool need_minv = false;           // the caller wants M = L^-T D^+ in the identity rows of d_A (balm_pose_covariance): no back-substitution path
+  bool solve_tiled = false;         // d_A holds [A ; rhs] tile by tile (k_build_A -> k_ldl_chain without identity rows -> k_ldl_backsolve)
   bool solve_backsub = false;       // the last factorisation ran without identity rows: k_ldl_backsolve instead of k_ldl_apply
   double u_value = 0.0;             // damping of the next solve (set_damping)
   bool u_on_device = false;         // ... read by the solve's kernels from d_scal[SCAL_U] (graph capture / replay) instead of their arguments

@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void k_rank_diag(const double *__restrict__ H,
 
 __global__ __launch_bounds__(256) void k_build_A(const double *__restrict__ H, const double *__restrict__ g, int n,
                                                  int nA, const int *__restrict__ perm, const double *__restrict__ pu, double u_arg,
-                                                 double *__restrict__ A, int *__restrict__ flags, int nflags, double *__restrict__ xs) {
+                                                 double *__restrict__ A, int *__restrict__ flags, int nflags, double *__restrict__ xs, int tiled) {
   const double u = pu ? *pu : u_arg;    // replayed hipGraphs read the damping from device memory (the launch sequence of an LM
                                         // iteration is then the same for every iteration); plain launches carry it as an argument
   const int ldA = 2 * nA + NB;
@@ -73,6 +73,31 @@ __global__ __launch_bounds__(256) void k_build_A(const double *__restrict__ H, c
   for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < nflags; t += (long)gridDim.x * blockDim.x) flags[t] = 0;
   // k_ldl_backsolve's exchange buffer: "not there yet" = all ones (kernels_chain.inc)
   for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < nA; t += (long)gridDim.x * blockDim.x) xs[t] = __longlong_as_double(-1ll);
+  if (tiled) {      // [A ; rhs] tile by tile (kernels_chain.inc: ch_tile), no identity rows: t runs over the tiled layout itself
+    const int P = nA / NB;
+    const long ttotal = (long)(P + 1) * P * NB * NB;
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < ttotal; t += (long)gridDim.x * blockDim.x) {
+      const long tile = t / (NB * NB);
+      const int e = (int)(t - tile * (NB * NB));
+      const int cb = (int)(tile / (P + 1)), rb = (int)(tile - (long)cb * (P + 1));
+      const int c = NB * cb + e / NB, rl = e % NB;
+      const int pc = perm[c];
+      double v;
+      if (rb < P) {
+        const int r = NB * rb + rl, pr = perm[r];
+        if (pr < n && pc < n) {
+          v = H[(size_t)pc * n + pr];
+          if (r == c) v += u * v;
+        } else {
+          v = (r == c) ? 1.0 : 0.0;
+        }
+      } else {
+        v = (rl == 0 && pc < n) ? -g[pc] : 0.0;
+      }
+      A[t] = v;
+    }
+    return;
+  }
   for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
     const int c = (int)(t / ldA), r = (int)(t - (long)c * ldA);
     const int pc = perm[c];
@@ -815,14 +840,25 @@ bool solve_is_persistent(const balm_ctx *c) {
   return (P >= CHAIN_MIN_P && P <= CHAIN_MAX_P && c->chain_cap != 0) || (P >= 18 && P <= FUSED_MAX_P && c->fused_cap != 0);
 }
 
+static void launch_build_A(balm_ctx *c) {
+  const int n = c->n, nA = c->nA, P = nA / NB;
+  const double *pu = c->u_on_device ? c->d_scal + SCAL_U : nullptr;
+  long total = (long)(2 * nA + NB) * nA;
+  int grid = (int)((total + 255) / 256);
+  if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(k_build_A, dim3(grid), dim3(256), 0, c->stream, c->d_H, c->d_g, n, nA, c->d_perm, pu, c->u_value, c->d_A, c->d_flags,
+                     2 * (2 * P + 1) * P + P + 8, c->d_x + nA, c->solve_tiled ? 1 : 0);
+}
+
 static void launch_factor(balm_ctx *c) {
   hipStream_t s = c->stream;
   const int nA = c->nA, P = nA / NB;
   bool want_fused = solve_is_persistent(c);
   c->solve_backsub = false;
   if (want_fused && solve_wants_backsub(c)) {
-    if (launch_factor_chain(c, /*ident=*/getenv("BALM_CHAINB_IDENT") != nullptr)) { c->solve_backsub = true; return; }      // (debug: identity rows kept)
+    if (launch_factor_chain(c, /*ident=*/getenv("BALM_CHAINB_IDENT") != nullptr, c->solve_tiled)) { c->solve_backsub = true; return; }      // (debug: identity rows kept)
     if (P > FUSED_MAX_P) want_fused = false;             // (refused: such a window is the launch path's, not k_ldl_fused's)
+    if (c->solve_tiled) { c->solve_tiled = false; launch_build_A(c); }      // ... and the other paths read the column-major matrix
   } else {
     const char *mode = getenv("BALM_SOLVE");
     if (want_fused && solve_wants_chain(c, mode) && launch_factor_chain(c, true)) return;
@@ -890,18 +926,16 @@ void launch_solve(balm_ctx *c, bool new_hessian, int upd_form, const double *upd
   if (new_hessian)
     hipLaunchKernelGGL(k_rank_diag, dim3((nA + 15) / 16), dim3(256), (size_t)nA * sizeof(double) + 256 * sizeof(int),
                        s, c->d_H, n, nA, c->d_perm);
+  // [A ; rhs] tile by tile for k_ldl_chain + k_ldl_backsolve (no identity rows, nobody else reads the matrix); BALM_TILED=0: A/B
   {
-    long total = (long)(2 * nA + NB) * nA;
-    int grid = (int)((total + 255) / 256);
-    if (grid > 4096) grid = 4096;
-    const int P = nA / NB;
-    hipLaunchKernelGGL(k_build_A, dim3(grid), dim3(256), 0, s, c->d_H, c->d_g, n, nA, c->d_perm, pu, c->u_value, c->d_A, c->d_flags,
-                       2 * (2 * P + 1) * P + P + 8, c->d_x + nA);
+    const char *te = getenv("BALM_TILED");
+    c->solve_tiled = solve_wants_backsub(c) && !getenv("BALM_CHAINB_IDENT") && !(te && te[0] == '0');
   }
+  launch_build_A(c);
   launch_factor(c);
   if (c->solve_backsub) {           // x (permuted order) -> chunk 0 of d_x; chunk 1 is the workgroups' exchange buffer
     const int P = nA / NB;
-    hipLaunchKernelGGL(k_ldl_backsolve, dim3(P), dim3(256), 0, s, c->d_A, nA, P, c->d_minv, c->d_dvec, c->d_z, c->d_x + nA, c->d_x,
+    hipLaunchKernelGGL(k_ldl_backsolve, dim3(P), dim3(256), 0, s, c->d_A, nA, P, c->solve_tiled ? 1 : 0, c->d_minv, c->d_dvec, c->d_z, c->d_x + nA, c->d_x,
                        c->d_flags + (size_t)2 * (2 * P + 1) * P + P);
   } else {
     hipLaunchKernelGGL(k_ldl_apply, dim3((nA + 63) / 64, APPLY_CHUNKS), dim3(256), 0, s, c->d_A, nA, c->d_dvec, c->d_z, c->d_x);
