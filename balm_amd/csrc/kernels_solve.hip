@@ -806,7 +806,7 @@ constexpr int FUSED_MAX_P = 40;              // the persistent kernel wins for 1
 // Which persistent kernel: BALM_SOLVE=chain forces k_ldl_chain (round 3), =fused k_ldl_fused (round 2).  Default: k_ldl_chain
 // wherever a persistent kernel is the choice at all -- it beats k_ldl_fused at every size (profiles/r03d_solve_paths_by_window.txt:
 // n = 1200: 0.283 vs 0.428 ms) and the launch path from 5 to 40 panels (n = 240: 0.086 vs 0.089, n = 1920: 0.73 vs 0.84).
-constexpr int CHAIN_MIN_P = 5, CHAIN_MAX_P = 40;
+constexpr int CHAIN_MIN_P = 5, CHAIN_MAX_P = 40;      // (from 31 panels on the default is its form without identity rows: below)
 // ... and above that, up to 100 panels (n = 4800), k_ldl_chain on [A ; rhs] alone followed by the block back-substitution
 // k_ldl_backsolve (kernels_chain.inc): the identity rows that yield L^-T D^+ are 70 % of the far updates at P = 63.  Not when the
 // caller needs that inverse (balm_pose_covariance: c->need_minv).  BALM_SOLVE=chainb forces it from CHAIN_MIN_P panels on.
