@@ -855,6 +855,9 @@ static void launch_factor(balm_ctx *c) {
   const int nA = c->nA, P = nA / NB;
   bool want_fused = solve_is_persistent(c);
   c->solve_backsub = false;
+  static const bool dbg = getenv("BALM_SOLVE_DEBUG") != nullptr;      // one line per factorisation: which path, and why not another
+  if (dbg) fprintf(stderr, "balm_hip: solve P=%d persistent=%d backsub=%d chain_cap=%d fused_cap=%d multi=%d\n", P, (int)want_fused,
+                   (int)solve_wants_backsub(c), c->chain_cap, c->fused_cap, c->multi ? c->multi->n : 0);
   if (want_fused && solve_wants_backsub(c)) {
     if (launch_factor_chain(c, /*ident=*/getenv("BALM_CHAINB_IDENT") != nullptr, c->solve_tiled)) { c->solve_backsub = true; return; }      // (debug: identity rows kept)
     if (P > FUSED_MAX_P) want_fused = false;             // (refused: such a window is the launch path's, not k_ldl_fused's)
