@@ -766,7 +766,12 @@ __global__ __launch_bounds__(1024) void k_ldl_finish(const double *__restrict__ 
     const int p = perm[r];
     if (p < n) {
       double xv = 0.0;
-      for (int k = 0; k < nchunks; k++) xv += x[(size_t)k * nA + r];            // partial products of k_ldl_apply (or k_ldl_backsolve's x)
+      if (nchunks == APPLY_CHUNKS) {                                             // partial products of k_ldl_apply: all loads in flight
+#pragma unroll
+        for (int k = 0; k < APPLY_CHUNKS; k++) xv += x[(size_t)k * nA + r];
+      } else {
+        xv = x[r];                                                               // k_ldl_backsolve's x
+      }
       xv += poison;
       dx[p] = xv;
       q += xv * (u * H[(size_t)p * n + p] * xv - g[p]);
