@@ -115,6 +115,7 @@ struct balm_ctx {
   double *h_scal = nullptr;         // pinned mirror (16) + a ring of damping values on their way to d_scal[SCAL_U] (64) + a stamp
   double *d_hscal = nullptr;        // its device alias: k_scalars_mail writes the mirror and the stamp straight into host memory
   unsigned long long mail_seq = 0;  // stamp of the last k_scalars_mail launch
+  double comm_host_us = 0.0; long comm_calls = 0;      // BALM_COMM_DEBUG: host time inside the transport's calls
   bool need_minv = false;           // the caller wants M = L^-T D^+ in the identity rows of d_A (balm_pose_covariance): no back-substitution path
   bool solve_tiled = false;         // d_A holds [A ; rhs] tile by tile (k_build_A -> k_ldl_chain without identity rows -> k_ldl_backsolve)
   bool solve_backsub = false;       // the last factorisation ran without identity rows: k_ldl_backsolve instead of k_ldl_apply

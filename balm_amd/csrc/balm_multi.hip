@@ -19,6 +19,9 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <thread>
@@ -107,7 +110,15 @@ void comm_query(const balm_ctx *ctx, int *count, int *rank) {
 
 int comm_allreduce(balm_ctx *ctx, double *buf, long n) {
   const Rccl *r = rccl();
+  static const bool dbg = getenv("BALM_COMM_DEBUG") != nullptr;      // host time spent INSIDE the collective calls (does the call wait for the stream?)
+  const auto t0 = std::chrono::steady_clock::now();
   const ncclResult_t e = r->AllReduce(buf, buf, (size_t)n, ncclDouble, ncclSum, (ncclComm_t)ctx->comm, ctx->stream);
+  if (dbg) {
+    ctx->comm_host_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+    if ((++ctx->comm_calls % 64) == 0)
+      fprintf(stderr, "balm_hip: %ld ncclAllReduce calls, %.1f us of host time per call (last: %ld doubles)\n", ctx->comm_calls,
+              ctx->comm_host_us / ctx->comm_calls, n);
+  }
   if (e != ncclSuccess) { ctx->err = std::string("ncclAllReduce: ") + r->GetErrorString(e); return BALM_ERR_HIP; }
   return BALM_OK;
 }
