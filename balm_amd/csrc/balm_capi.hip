@@ -160,6 +160,8 @@ static void collect_timing_if_idle(balm_ctx *ctx) {
 // stream synchronise (long iterations: nothing to gain from spinning).  Errors of the stream surface there or at the
 // next synchronising call.
 int wait_scalars(balm_ctx *ctx) {
+  static const bool no_poll = getenv("BALM_NO_POLL") != nullptr;      // A/B: the plain stream synchronise
+  if (no_poll) return sync_stream(ctx);
   volatile double *stamp = ctx->h_scal + SCAL_STAMP;
   const double want = (double)ctx->mail_seq;
   const auto t0 = std::chrono::steady_clock::now();
