@@ -111,6 +111,8 @@ void comm_query(const balm_ctx *ctx, int *count, int *rank) {
 int comm_allreduce(balm_ctx *ctx, double *buf, long n) {
   const Rccl *r = rccl();
   static const bool dbg = getenv("BALM_COMM_DEBUG") != nullptr;      // host time spent INSIDE the collective calls (does the call wait for the stream?)
+  static const bool skip = getenv("BALM_COMM_SKIP_ONE_RANK") != nullptr;      // experiment (tools/exp_dist_overhead.py): a one-rank sum is the identity
+  if (skip && ctx->nranks == 1) return BALM_OK;
   const auto t0 = std::chrono::steady_clock::now();
   const ncclResult_t e = r->AllReduce(buf, buf, (size_t)n, ncclDouble, ncclSum, (ncclComm_t)ctx->comm, ctx->stream);
   if (dbg) {
