@@ -85,6 +85,29 @@ def test_device_association_feeds_the_optimizer():
     c.close(); c2.close()
 
 
+def test_association_table_is_fetched_lazily_and_survives_a_new_table():
+    """round 3: balm_associate leaves the feature table on the device; balm_get_features fetches the clusters on first use --
+    also after balm_set_features has replaced the table the optimizer works on (the host copy is taken before d_cl is
+    overwritten), and twice in a row"""
+    import ctypes as C
+    poses, frames = synthetic_window(3, 12, 120, 30)
+    c = capi.Context(12)
+    xyz = np.concatenate(frames).astype(np.float32)
+    fid = np.concatenate([np.full(len(f), i, np.int32) for i, f in enumerate(frames)])
+    F, nroot, feats = c.associate(xyz, fid, poses, voxel_size=1.0)              # fetches at once: the reference copy
+    cl_ref, co_ref, lay_ref = feats
+    F2, _, _ = c.associate(xyz, fid, poses, voxel_size=1.0, want_features=False)   # nothing fetched
+    assert F2 == F
+    other = np.zeros((5, 12, 10)); other[:, :, 9] = 3.0; other[:, :, 0] = other[:, :, 3] = other[:, :, 5] = 1.0
+    other[:, :, 6] = np.arange(12)[None, :] * 0.1
+    c.set_features(other, None, np.ones(5))                                         # d_cl now holds another table
+    for _ in range(2):
+        cl, co, lay = np.zeros_like(cl_ref), np.zeros_like(co_ref), np.zeros_like(lay_ref)
+        c._check(c.L.balm_get_features(c.h, cl.ctypes.data_as(C.c_void_p), co.ctypes.data_as(C.c_void_p), lay.ctypes.data_as(C.c_void_p)))
+        assert np.array_equal(cl, cl_ref) and np.array_equal(co, co_ref) and np.array_equal(lay, lay_ref)
+    c.close()
+
+
 def test_device_association_edge_cases():
     c = capi.Context(4)
     # nothing planar / too few points: zero features is a result, not an error; the context stays usable

@@ -22,8 +22,13 @@ ctx = capi.Context(W, 0, capi.FLAG_TIMING)
 ctx.set_features(sc.clusters, None, sc.coeffs)
 if mode == "both":
     bdist.install_rccl(ctx)
-elif mode == "rccl_only":
+elif mode in ("rccl_only", "rccl_affinity"):
+    before = sorted(os.sched_getaffinity(0))
     ctx.comm_init_rank(1, 0, ctx.comm_unique_id())
+    after = sorted(os.sched_getaffinity(0))
+    print("cpu affinity of the calling thread: %d cores before ncclCommInitRank, %d after%s" % (len(before), len(after), "" if before == after else " (CHANGED: %s...)" % after[:8]))
+    if mode == "rccl_affinity":
+        os.sched_setaffinity(0, before)
 ctx.damping_iter(sc.poses_init, form=0, u0=0.1, max_iter=5, force_hess=True, no_stop=True, reanchor=False)
 ctx.reset_timing()
 torch.cuda.synchronize(); t0 = time.perf_counter()
