@@ -500,7 +500,8 @@ static int build_sparse_plan(balm_ctx *ctx, int F, const unsigned char *obs) {
   const char *mode = getenv("BALM_SYRK");
   if (mode && !strcmp(mode, "dense")) return BALM_OK;
   const int W = ctx->W, T = ctx->T, ntiles = ctx->ntiles;
-  if (T > 128 || F < 64) return BALM_OK;
+  if (T > 128 || T <= 2 || F < 64) return BALM_OK;      // (two row blocks: three tile jobs, nothing a plan could skip -- and a 20-pose
+                                                         //  sliding window installs a table per slide: the plan's host time is not free)
   struct Key { uint64_t hi, lo; int a; };
   std::vector<Key> keys((size_t)F);
   for (int a = 0; a < F; a++) {
