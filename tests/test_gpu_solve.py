@@ -189,6 +189,40 @@ def test_chain_kernel_with_back_substitution_matches_lapack(W, kind):
     c.close()
 
 
+@pytest.mark.parametrize("W", [40, 264])
+def test_blind_poses_leave_zero_pivots_in_every_path(W):
+    """poses that observe nothing have exactly zero 6x6 blocks in H and D: the damped matrix is singular, Eigen's LDLT leaves
+    zero pivots and its solve returns 0 there (D^+).  Every factorisation path -- the product form with L^-T D^+ and the block
+    back-substitution with Minv_b D_bb -- must return exact zeros for those poses and the pseudo-inverse solution elsewhere"""
+    rng = np.random.default_rng(W)
+    n = 6 * W
+    blind = rng.choice(W, size=max(2, W // 10), replace=False)
+    live = np.ones(n, bool)
+    for b in blind:
+        live[6 * b:6 * b + 6] = False
+    m = int(live.sum())
+    B = rng.standard_normal((m, 96))
+    Hl = B @ B.T / 96 + np.diag(rng.uniform(0.5, 50.0, m))
+    H = np.zeros((n, n)); H[np.ix_(live, live)] = Hl
+    g = np.zeros(n); g[live] = rng.standard_normal(m)
+    u = 0.1
+    ref = np.zeros(n)
+    ref[live] = np.linalg.solve(Hl + u * np.diag(np.diag(Hl)), -g[live])
+    c = capi.Context(W)
+    try:
+        for mode in (None, "chainb", "chain", "fused", "launches"):
+            if mode:
+                os.environ["BALM_SOLVE"] = mode
+            else:
+                os.environ.pop("BALM_SOLVE", None)
+            dx, q1 = c.solve_damped(H, g, u)
+            assert np.all(dx[~live] == 0.0), mode
+            assert rel_err(dx[live], ref[live]) < 1e-9, (mode, rel_err(dx[live], ref[live]))
+    finally:
+        os.environ.pop("BALM_SOLVE", None)
+    c.close()
+
+
 @pytest.mark.parametrize("W", [8, 9, 16, 17, 24, 33, 48, 64, 100, 144, 177, 200, 256, 320, 400, 500])
 @pytest.mark.parametrize("kind", ["spd", "indefinite"])
 def test_chain_kernel_matches_lapack(W, kind):
