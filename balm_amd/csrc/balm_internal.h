@@ -110,6 +110,8 @@ struct balm_ctx {
   int fused_cap = -1;               // co-resident workgroups of k_ldl_fused on this device (-1 = not asked yet, 0 = unavailable)
   int chain_cap = -1;               // ... of k_ldl_chain
   double *d_minv = nullptr;         // [P][48][48] Minv_p = L11^-T D11^-1 of every panel (k_ldl_chain)
+  int *d_macro_tab = nullptr;       // [NH][64] the macro-tiles every helper of k_ldl_chain owns (chain_macro_table), built at the first such launch
+  int macro_tab_P = 0, macro_tab_NH = 0;
   double *d_dx = nullptr;           // [n]
   double *d_scal = nullptr;         // [16] device scalars: 0 r1, 1 r2, 2 q1, 3 flags
   double *h_scal = nullptr;         // pinned mirror (16) + a ring of damping values on their way to d_scal[SCAL_U] (64) + a stamp

@@ -16,6 +16,7 @@
 //                     launches), which turns the backward solve  L^T x = z  -- a chain of one launch per panel
 //                     -- into ONE matrix-vector product  x = M (D z)  (k_ldl_apply).
 // Pose update kernels (bavoxel.hpp:1116-1126, 1159-1164) live here too.
+#include <algorithm>
 #include <cfloat>
 #include <cstdlib>
 #include <cstring>
@@ -815,7 +816,7 @@ constexpr int CHAIN_MIN_P = 5, CHAIN_MAX_P = 40;      // (from 31 panels on the 
 // ... and above that, up to 100 panels (n = 4800), k_ldl_chain on [A ; rhs] alone followed by the block back-substitution
 // k_ldl_backsolve (kernels_chain.inc): the identity rows that yield L^-T D^+ are 70 % of the far updates at P = 63.  Not when the
 // caller needs that inverse (balm_pose_covariance: c->need_minv).  BALM_SOLVE=chainb forces it from CHAIN_MIN_P panels on.
-constexpr int CHAINB_MIN_P = 31, CHAINB_MAX_P = 66;       // n = 1488 .. 3168 (profiles/r03t_solve_paths_by_window.txt); forced: up to 100 panels
+constexpr int CHAINB_MIN_P = 31, CHAINB_MAX_P = 100;      // n = 1488 .. 4800 (profiles/r03z_solve_paths_by_window.txt: n = 3600 1.44 vs 2.11 ms on the launch path, n = 4800 3.00 vs 4.10)
 static bool solve_wants_backsub(const balm_ctx *c) {
   const int P = c->nA / NB;
   const char *mode = getenv("BALM_SOLVE");

@@ -167,7 +167,7 @@ def test_large_window_solve_of_an_lm_hessian_matches_lapack():
 @pytest.mark.parametrize("W", [40, 41, 64, 100, 200, 328, 336, 400, 500, 640, 700, 800])
 @pytest.mark.parametrize("kind", ["spd", "indefinite"])
 def test_chain_kernel_with_back_substitution_matches_lapack(W, kind):
-    """k_ldl_chain on [A ; rhs] alone + k_ldl_backsolve (round 3: the default from 41 to 100 panels, i.e. 328 .. 800 poses;
+    """k_ldl_chain on [A ; rhs] alone + k_ldl_backsolve (round 3: the default from 31 to 100 panels, i.e. 248 .. 800 poses;
     BALM_SOLVE=chainb forces it from 5 panels on) against LAPACK and against the launch path, solve after solve (the exchange
     buffer and the flags are re-armed per solve); a vanished pivot (indefinite case aside: an exactly singular block) is the
     pseudo-inverse in both"""

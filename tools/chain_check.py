@@ -59,7 +59,7 @@ if os.environ.get("BALM_SOLVE_TRACE"):
     W = Ws[-1]
     H, g = matrix(W, "spd")
     c = capi.Context(W, 0, capi.FLAG_TIMING)
-    os.environ["BALM_SOLVE"] = "chain"
+    os.environ["BALM_SOLVE"] = os.environ.get("CHAIN_TRACE_MODE", "chain")          # "chainb": without identity rows + k_ldl_backsolve
     for _ in range(3):
         c.solve_damped(H, g, 0.1)
     raw = c.solve_trace().astype(np.float64).reshape(-1) * 0.01                                              # us (100 MHz ticks)
