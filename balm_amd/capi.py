@@ -23,7 +23,7 @@ EXPORTS = ["balm_create", "balm_create_multi", "balm_destroy", "balm_set_feature
            "balm_solve_damped", "balm_damping_iter", "balm_build_clusters", "balm_voxel_defaults", "balm_associate", "balm_get_features", "balm_get_association", "balm_pose_covariance",
            "balm_window_open", "balm_window_add_scan", "balm_window_recut", "balm_window_get_points", "balm_window_features", "balm_window_marginalize", "balm_window_info", "balm_window_close",
            "balm_set_allreduce", "balm_comm_unique_id", "balm_comm_init_rank", "balm_comm_info",
-           "balm_get_timing", "balm_get_solve_trace", "balm_reset_timing", "balm_work_model", "balm_last_error", "balm_version"]
+           "balm_get_timing", "balm_get_solve_trace", "balm_chain_macro_plan", "balm_reset_timing", "balm_work_model", "balm_last_error", "balm_version"]
 
 
 class IterLog(C.Structure):
@@ -99,6 +99,7 @@ def lib():
         L.balm_comm_info.argtypes = [C.c_void_p, C.c_void_p]
         L.balm_get_timing.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.balm_get_solve_trace.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_void_p]
+        L.balm_chain_macro_plan.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_long]
         L.balm_reset_timing.argtypes = [C.c_void_p]
         L.balm_work_model.argtypes = [C.c_void_p, C.c_void_p]
         L.balm_last_error.restype = C.c_char_p
@@ -106,6 +107,16 @@ def lib():
         L.balm_version.restype = C.c_char_p
         _LIB = L
     return _LIB
+
+
+def chain_macro_plan(panels, helpers):
+    """host-only: the macro-tiles every helper workgroup of k_ldl_chain owns -> list (per helper) of (r0, j0)"""
+    tab = np.empty(helpers * 64, np.int32)
+    rc = lib().balm_chain_macro_plan(int(panels), int(helpers), tab.ctypes.data_as(C.c_void_p), tab.size)
+    if rc != OK:
+        raise BalmError(rc, "balm_chain_macro_plan(%d, %d)" % (panels, helpers))
+    tab = tab.reshape(helpers, 64)
+    return [[(int(e) & 0xffff, int(e) >> 16) for e in row if e >= 0] for row in tab]
 
 
 def _p(a):

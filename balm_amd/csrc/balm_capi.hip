@@ -1491,6 +1491,14 @@ int balm_get_timing(balm_ctx *ctx, double *ms, long *count) {
   return BALM_OK;
 }
 
+int balm_chain_macro_plan(int panels, int helpers, int *table, long capacity) {
+  if (!table || panels < 3 || helpers < 1 || capacity < (long)helpers * 64) return BALM_ERR_ARG;
+  std::vector<int> tab;
+  if (!balm::chain_macro_plan(panels, helpers, tab)) return BALM_ERR_ARG;
+  memcpy(table, tab.data(), tab.size() * sizeof(int));
+  return BALM_OK;
+}
+
 int balm_reset_timing(balm_ctx *ctx) {
   if (!ctx) return BALM_ERR_ARG;
   for (int k = 0; k < BALM_T_COUNT; k++) { ctx->timer.ms[k] = 0; ctx->timer.cnt[k] = 0; }

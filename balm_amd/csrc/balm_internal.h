@@ -235,6 +235,7 @@ int multi_host_barrier_rc(balm_ctx *ctx, int rc);             // all device thre
 // launchers (kernels_solve.hip)
 constexpr int SCAL_U = 5;            // d_scal slot of the damping u
 constexpr int SCAL_STAMP = 16 + 64;  // h_scal slot of k_scalars_mail's stamp (behind the mirror and the damping ring)
+bool chain_macro_plan(int P, int NH, std::vector<int> &tab);      // who owns which 2 x 2 macro-tile in k_ldl_chain (kernels_chain.inc; host only)
 bool solve_is_persistent(const balm_ctx *c);      // the factorisation of this window runs as k_ldl_fused
 void launch_solve(balm_ctx *c, bool new_hessian, int upd_form = 0, const double *upd_poses = nullptr, double *upd_out = nullptr);      // (H + u diag H) dx = -g, u = d_scal[SCAL_U]; q1 -> d_scal[2]
 void launch_update_poses(hipStream_t s, int form, int W, const double *poses, const double *dx, double *out);

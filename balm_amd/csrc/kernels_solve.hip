@@ -81,6 +81,7 @@ __global__ __launch_bounds__(256) void k_build_A(const double *__restrict__ H, c
       const long tile = t / (NB * NB);
       const int e = (int)(t - tile * (NB * NB));
       const int cb = (int)(tile / (P + 1)), rb = (int)(tile - (long)cb * (P + 1));
+      if (tiled == 2 && rb < cb) continue;      // (BALM_BUILD_A=lower, unmeasured: nothing on this path reads a tile above the diagonal)
       const int c = NB * cb + e / NB, rl = e % NB;
       const int pc = perm[c];
       double v;
@@ -852,8 +853,12 @@ static void launch_build_A(balm_ctx *c) {
   long total = (long)(2 * nA + NB) * nA;
   int grid = (int)((total + 255) / 256);
   if (grid > 4096) grid = 4096;
+  // BALM_BUILD_A=lower (round 3, written after the GPU budget ended: NOT yet run): the tile-major build skips the tiles above the
+  // diagonal -- k_build_A is 114 us of the 0.99 ms solve at n = 3000 (a gather through the pivot permutation at 1.3 TB/s,
+  // profiles/r03z_solve_kernels_n3000.txt) and nothing reads that half.  First thing to measure in round 4.
+  static const bool lower_only = getenv("BALM_BUILD_A") && !strcmp(getenv("BALM_BUILD_A"), "lower");
   hipLaunchKernelGGL(k_build_A, dim3(grid), dim3(256), 0, c->stream, c->d_H, c->d_g, n, nA, c->d_perm, pu, c->u_value, c->d_A, c->d_flags,
-                     2 * (2 * P + 1) * P + P + 8, c->d_x + nA, c->solve_tiled ? 1 : 0);
+                     2 * (2 * P + 1) * P + P + 8, c->d_x + nA, c->solve_tiled ? (lower_only ? 2 : 1) : 0);
 }
 
 static void launch_factor(balm_ctx *c) {

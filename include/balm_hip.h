@@ -265,6 +265,13 @@ int balm_get_timing(balm_ctx *ctx, double *ms, long *count);
 int balm_get_solve_trace(balm_ctx *ctx, long long *ticks, long capacity, int *dims3);
 int balm_reset_timing(balm_ctx *ctx);
 
+/* Host-only diagnostic (no device needed): the ownership table of k_ldl_chain's macro-tile helpers for a window of `panels`
+ * 48-column panels and `helpers` helper workgroups -- table[h * 64 + i] = r0 | j0 << 16 of helper h's i-th 2 x 2 macro-tile
+ * (rows r0, r0+1 x columns j0, j0+1 of the tall matrix [A ; rhs]; r0 = panels is the right-hand side row), -1 = none;
+ * a helper's entries ascend by column.  capacity >= helpers * 64 ints.  BALM_ERR_ARG: fewer than 3 panels, no helper, a
+ * helper with more than 64 macro-tiles, or a short buffer.  (Here so that the CPU tests cover the scheduling logic.) */
+int balm_chain_macro_plan(int panels, int helpers, int *table, long capacity);
+
 /* Work model of the last balm_set_features: out[0] = S = sum_a n_a, out[1] = sum_a n_a(n_a+1)/2,
  * out[2] = algorithmic FLOPs of one hessian_syrk launch = 216 * out[1] (three 6x6 rank-1 updates per observed
  * unordered pose pair incl. the diagonal; 108*F*W*(W+1) when every pose sees every feature), out[3] = FLOPs the

@@ -72,3 +72,39 @@ def test_persistent_solve_kernels_keep_their_coherent_stores_and_loads():
     if not os.path.exists(obj) or not os.path.exists(check_solve_sync.LLVM + "/llvm-objdump"):
         pytest.skip("no built object / no llvm-objdump")
     assert check_solve_sync.check(obj, verbose=False) == []
+
+
+@pytest.mark.parametrize("P,NH", [(31, 223), (38, 189), (63, 191), (75, 179), (100, 154), (5, 3), (64, 8)])
+def test_macro_tile_ownership_plan_is_a_balanced_partition(P, NH):
+    """k_ldl_chain's helpers on 2 x 2 macro-tiles (csrc/kernels_chain.inc: chain_macro_plan, host code): every macro-tile of
+    the tall matrix [A ; rhs] below the first column pair has exactly one owner, a helper's list ascends by column (its lowest
+    ready lane is then the most urgent job), nobody holds more than the 64 a wavefront can schedule, and the work -- panels x
+    (2 + live tiles), the cost the plan balances -- is even: dealt out boustrophedon the busiest helper did 354 tile updates
+    at 63 panels and the idlest 92 (profiles/r03z_chain_helpers.txt)"""
+    from balm_amd import capi
+    want = {(r0, j0) for j0 in range(2, P, 2) for r0 in range(j0, P + 1, 2)}
+    try:
+        plan = capi.chain_macro_plan(P, NH)
+    except capi.BalmError:
+        assert len(want) > 64 * NH
+        return
+    got = [t for row in plan for t in row]
+    assert len(got) == len(set(got)) and set(got) == want
+    assert all(len(row) <= 64 for row in plan)
+    for row in plan:
+        assert [(j0, r0) for r0, j0 in row] == sorted((j0, r0) for r0, j0 in row)
+
+    def cost(r0, j0):
+        w = 0
+        for q in range(P):
+            n_on = sum(1 for dr in (0, 1) for dc in (0, 1)
+                       if r0 + dr <= P and j0 + dc < P and r0 + dr >= j0 + dc and q <= ((j0 + dc - 3) if r0 + dr == j0 + dc else (j0 + dc - 2)))
+            w += 2 + n_on if n_on else 0
+        return w
+    loads = [sum(cost(*t) for t in row) for row in plan]
+    heaviest = max(cost(*t) for t in want)
+    if len(want) >= NH:
+        assert min(len(row) for row in plan) >= 1
+    assert max(loads) <= sum(loads) / NH + heaviest          # longest-processing-time-first's bound
+    if P == 63:
+        assert max(loads) <= 1.12 * sum(loads) / NH
