@@ -1,0 +1,22 @@
+#!/bin/bash
+# FIRST GPU call of round 4 (written at the end of round 3, after its GPU minutes were gone; every step has its own timeout and no
+# step reads stdin -- round 3's last call hung on `head <empty file name>` for eleven minutes):
+#   1. the full GPU suite, smoke() and the default bench on the tree round 3 left (the helpers' global_load_lds staging and the
+#      macro-tile helpers were verified by tests/test_gpu_solve.py + tools/bench_solve.py only)
+#   2. the solve by window size, default and with BALM_BUILD_A=lower (never run)
+#   3. per-kernel times of one solve at n = 3000 and n = 1200 (read from rocprofv3's database: tools/rocprof_kernels.py)
+REPO=$(pwd); OUT=$REPO/gpurun_out/r04a; mkdir -p $OUT
+timeout 1500 python -m pytest tests -q -m gpu -x > $OUT/pytest_gpu.txt 2>&1 < /dev/null; echo "pytest rc=$?"; tail -3 $OUT/pytest_gpu.txt
+timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $OUT/smoke.txt 2>&1 < /dev/null; tail -1 $OUT/smoke.txt
+timeout 600 python bench.py > $OUT/bench.json 2> $OUT/bench.err < /dev/null; tail -c 1500 $OUT/bench.json
+timeout 600 python tools/bench_solve.py 100 177 200 256 300 350 400 500 600 800 > $OUT/solve_default.txt 2>&1 < /dev/null
+BALM_BUILD_A=lower timeout 600 python tools/bench_solve.py 256 300 400 500 600 800 > $OUT/solve_build_a_lower.txt 2>&1 < /dev/null
+cut -c1-30,100-250 $OUT/solve_default.txt; sed 's/^/lower /' $OUT/solve_build_a_lower.txt | cut -c1-36,106-256
+cd /tmp; export TMPDIR=/tmp
+for W in 500 200; do
+  rm -rf $OUT/prof_solve$W
+  timeout 300 rocprofv3 --kernel-trace -d $OUT/prof_solve$W -o s -- python $REPO/tools/bench_solve_one.py $W > /dev/null 2>&1 < /dev/null
+  timeout 60 python $REPO/tools/rocprof_kernels.py $OUT/prof_solve$W k_ > $OUT/solve_kernels_W$W.txt 2>&1 < /dev/null
+  tail -8 $OUT/solve_kernels_W$W.txt
+  find $OUT/prof_solve$W -name "*.db" -size +8M -delete
+done
