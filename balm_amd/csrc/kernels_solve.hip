@@ -121,6 +121,106 @@ __global__ __launch_bounds__(256) void k_build_A(const double *__restrict__ H, c
   }
 }
 
+// ---- round 3, written after its GPU minutes were gone: NOT yet run, opt-in by BALM_BUILD_A=rows[+lower] (tools/gpu_r04a.sh) --------
+// k_build_A above is a gather through the pivot permutation, H[perm[c] * n + perm[r]]: consecutive lanes read 8 bytes from 64-byte
+// sectors scattered over a row -- 114 us at n = 3000 (145 MB at 1.3 TB/s, profiles/r03z_solve_kernels_n3000.txt), 11 % of that
+// solve.  Here ONE workgroup builds ONE column c of the tall matrix: row perm[c] of H is contiguous, goes into LDS with coalesced
+// loads (all in flight at once: the loop is unrolled over a compile-time bound -- a rolled copy loop is one memory round trip per
+// iteration), and the column is the LDS gather hrow[perm[r]], written in 384-byte segments.  Same values as
+// k_build_A, bit for bit.  MAXI: nA <= 256 MAXI.  tiled: 0 = column-major with identity rows, 1 = tile-major [A ; rhs], 2 = the same
+// without the tiles above the diagonal (nothing reads them).
+template <int MAXI>
+__global__ __launch_bounds__(256) void k_build_A_rows(const double *__restrict__ H, const double *__restrict__ g, int n, int nA,
+                                                      const int *__restrict__ perm, const double *__restrict__ pu, double u_arg,
+                                                      double *__restrict__ A, int *__restrict__ flags, int nflags, double *__restrict__ xs, int tiled) {
+  extern __shared__ __attribute__((aligned(16))) double hrow[];       // [n] row perm[c] of H
+  const double u = pu ? *pu : u_arg;
+  const int tid = threadIdx.x, c = blockIdx.x;
+  for (long t = (long)c * 256 + tid; t < nflags; t += (long)gridDim.x * 256) flags[t] = 0;
+  for (long t = (long)c * 256 + tid; t < nA; t += (long)gridDim.x * 256) xs[t] = __longlong_as_double(-1ll);
+  const int P = nA / NB, cb = c / NB, cl = c - NB * cb;
+  const int ldA = 2 * nA + NB;
+  const int pc = perm[c];
+  const int r_begin = tiled == 2 ? NB * cb : 0;
+  double hv[MAXI];
+  int prv[MAXI];
+  const double *row = H + (size_t)(pc < n ? pc : 0) * n;
+#pragma unroll
+  for (int it = 0; it < MAXI; it++) {
+    const int i = tid + 256 * it, r = r_begin + i;
+    hv[it] = (i < n && pc < n) ? row[i] : 0.0;
+    prv[it] = r < nA ? perm[r] : n;
+  }
+  const double gv = pc < n ? -g[pc] : 0.0;
+#pragma unroll
+  for (int it = 0; it < MAXI; it++) {
+    const int i = tid + 256 * it;
+    if (i < n) hrow[i] = hv[it];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < MAXI; it++) {               // the rows of A proper
+    const int r = r_begin + tid + 256 * it;
+    if (r < nA) {
+      const int pr = prv[it];
+      double v;
+      if (pr < n && pc < n) {
+        v = hrow[pr];
+        if (r == c) v += u * v;                     // D = diag(H)  (bavoxel.hpp:1113)
+      } else {
+        v = (r == c) ? 1.0 : 0.0;
+      }
+      const int rb = r / NB, rl = r - NB * rb;
+      A[tiled ? ((size_t)cb * (P + 1) + rb) * (NB * NB) + (size_t)cl * NB + rl : (size_t)c * ldA + r] = v;
+    }
+  }
+  const int rows = tiled ? nA + NB : ldA;            // right-hand side rows (and, column-major, the identity rows): no loads
+  for (int r = nA + tid; r < rows; r += 256) {
+    const double v = r < nA + NB ? (r == nA ? gv : 0.0) : ((r - (nA + NB) == c) ? 1.0 : 0.0);
+    A[tiled ? ((size_t)cb * (P + 1) + P) * (NB * NB) + (size_t)cl * NB + (r - nA) : (size_t)c * ldA + r] = v;
+  }
+}
+
+// k_rank_diag with the diagonal's loads in flight at once (as a rolled loop every one of the nA / 16 workgroups walks nA / 256 dependent
+// memory round trips through it: 23 us at n = 3000).  Same ranks.  Not yet run either.
+template <int MAXI>
+__global__ __launch_bounds__(256) void k_rank_diag_u(const double *__restrict__ H, int n, int nA, int *__restrict__ perm) {
+  extern __shared__ __attribute__((aligned(16))) double dabs[];   // [nA] then int part[256]
+  int *part = reinterpret_cast<int *>(dabs + nA);
+  double dv[MAXI];
+#pragma unroll
+  for (int it = 0; it < MAXI; it++) {
+    const int i = threadIdx.x + 256 * it;
+    dv[it] = i < n ? fabs(H[(size_t)i * n + i]) : -1.0;
+  }
+#pragma unroll
+  for (int it = 0; it < MAXI; it++) {
+    const int i = threadIdx.x + 256 * it;
+    if (i < nA) dabs[i] = dv[it] == dv[it] ? dv[it] : -0.5;
+  }
+  __syncthreads();
+  const int il = threadIdx.x & 15, q = threadIdx.x >> 4;
+  const int i = blockIdx.x * 16 + il;
+  int rank = 0;
+  if (i < nA) {
+    const double di = dabs[i];
+    const int chunk = (nA + 15) / 16;
+    const int j0 = q * chunk, j1 = min(nA, j0 + chunk);
+    for (int j = j0; j < j1; j++) {
+      const double dj = dabs[j];
+      rank += (dj > di) || (dj == di && j < i);
+    }
+  }
+  part[threadIdx.x] = rank;
+  __syncthreads();
+  if (q == 0 && i < nA) {
+    rank = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) rank += part[16 * k + il];
+    perm[rank] = i;
+  }
+}
+
 // wave-uniform broadcast of lane `src`'s value (src is a compile-time constant after unrolling)
 __device__ __forceinline__ double bcast(double v, int src) {
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
@@ -853,12 +953,25 @@ static void launch_build_A(balm_ctx *c) {
   long total = (long)(2 * nA + NB) * nA;
   int grid = (int)((total + 255) / 256);
   if (grid > 4096) grid = 4096;
-  // BALM_BUILD_A=lower (round 3, written after the GPU budget ended: NOT yet run): the tile-major build skips the tiles above the
-  // diagonal -- k_build_A is 114 us of the 0.99 ms solve at n = 3000 (a gather through the pivot permutation at 1.3 TB/s,
-  // profiles/r03z_solve_kernels_n3000.txt) and nothing reads that half.  First thing to measure in round 4.
-  static const bool lower_only = getenv("BALM_BUILD_A") && !strcmp(getenv("BALM_BUILD_A"), "lower");
+  // BALM_BUILD_A=lower | rows | rows+lower (round 3, written after the GPU budget ended: NOT yet run; first thing to measure in
+  // round 4, tools/gpu_r04a.sh).  lower: the tile-major build skips the tiles above the diagonal -- nothing reads them.  rows: a
+  // workgroup per column with the row of H staged in LDS instead of the 8-byte gather (k_build_A_rows), and k_rank_diag_u.
+  static const char *ba = getenv("BALM_BUILD_A");
+  static const bool lower_only = ba && strstr(ba, "lower"), by_rows = ba && strstr(ba, "rows");
+  const int tiled = c->solve_tiled ? (lower_only ? 2 : 1) : 0;
+  const int nflags = 2 * (2 * P + 1) * P + P + 8;
+  if (by_rows && nA <= 256 * 20 && n >= 1) {
+    const size_t lds = (size_t)n * sizeof(double);
+#define BALM_BUILD_ROWS(M) hipLaunchKernelGGL(k_build_A_rows<M>, dim3(nA), dim3(256), lds, c->stream, c->d_H, c->d_g, n, nA, c->d_perm, pu, c->u_value, \
+                                              c->d_A, c->d_flags, nflags, c->d_x + nA, tiled)
+    if (nA <= 256 * 5) BALM_BUILD_ROWS(5);
+    else if (nA <= 256 * 10) BALM_BUILD_ROWS(10);
+    else BALM_BUILD_ROWS(20);
+#undef BALM_BUILD_ROWS
+    return;
+  }
   hipLaunchKernelGGL(k_build_A, dim3(grid), dim3(256), 0, c->stream, c->d_H, c->d_g, n, nA, c->d_perm, pu, c->u_value, c->d_A, c->d_flags,
-                     2 * (2 * P + 1) * P + P + 8, c->d_x + nA, c->solve_tiled ? (lower_only ? 2 : 1) : 0);
+                     nflags, c->d_x + nA, tiled);
 }
 
 static void launch_factor(balm_ctx *c) {
@@ -937,9 +1050,17 @@ void launch_solve(balm_ctx *c, bool new_hessian, int upd_form, const double *upd
   hipStream_t s = c->stream;                            // capture / replay) c->d_scal[SCAL_U], put there on the stream by push_damping
   const int n = c->n, nA = c->nA;
   const double *pu = c->u_on_device ? c->d_scal + SCAL_U : nullptr;
-  if (new_hessian)
-    hipLaunchKernelGGL(k_rank_diag, dim3((nA + 15) / 16), dim3(256), (size_t)nA * sizeof(double) + 256 * sizeof(int),
-                       s, c->d_H, n, nA, c->d_perm);
+  if (new_hessian) {
+    static const char *ba = getenv("BALM_BUILD_A");
+    const size_t lds = (size_t)nA * sizeof(double) + 256 * sizeof(int);
+    if (ba && strstr(ba, "rows") && nA <= 256 * 20) {       // (not yet run: see launch_build_A)
+      if (nA <= 256 * 5) hipLaunchKernelGGL(k_rank_diag_u<5>, dim3((nA + 15) / 16), dim3(256), lds, s, c->d_H, n, nA, c->d_perm);
+      else if (nA <= 256 * 10) hipLaunchKernelGGL(k_rank_diag_u<10>, dim3((nA + 15) / 16), dim3(256), lds, s, c->d_H, n, nA, c->d_perm);
+      else hipLaunchKernelGGL(k_rank_diag_u<20>, dim3((nA + 15) / 16), dim3(256), lds, s, c->d_H, n, nA, c->d_perm);
+    } else {
+      hipLaunchKernelGGL(k_rank_diag, dim3((nA + 15) / 16), dim3(256), lds, s, c->d_H, n, nA, c->d_perm);
+    }
+  }
   // [A ; rhs] tile by tile for k_ldl_chain + k_ldl_backsolve (no identity rows, nobody else reads the matrix); BALM_TILED=0: A/B
   {
     const char *te = getenv("BALM_TILED");

@@ -3,15 +3,19 @@
 # step reads stdin -- round 3's last call hung on `head <empty file name>` for eleven minutes):
 #   1. the full GPU suite, smoke() and the default bench on the tree round 3 left (the helpers' global_load_lds staging and the
 #      macro-tile helpers were verified by tests/test_gpu_solve.py + tools/bench_solve.py only)
-#   2. the solve by window size, default and with BALM_BUILD_A=lower (never run)
+#   2. the solve by window size, default and with BALM_BUILD_A=lower / rows / rows+lower (never run), and the solve tests with the last
 #   3. per-kernel times of one solve at n = 3000 and n = 1200 (read from rocprofv3's database: tools/rocprof_kernels.py)
 REPO=$(pwd); OUT=$REPO/gpurun_out/r04a; mkdir -p $OUT
 timeout 1500 python -m pytest tests -q -m gpu -x > $OUT/pytest_gpu.txt 2>&1 < /dev/null; echo "pytest rc=$?"; tail -3 $OUT/pytest_gpu.txt
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $OUT/smoke.txt 2>&1 < /dev/null; tail -1 $OUT/smoke.txt
 timeout 600 python bench.py > $OUT/bench.json 2> $OUT/bench.err < /dev/null; tail -c 1500 $OUT/bench.json
 timeout 600 python tools/bench_solve.py 100 177 200 256 300 350 400 500 600 800 > $OUT/solve_default.txt 2>&1 < /dev/null
-BALM_BUILD_A=lower timeout 600 python tools/bench_solve.py 256 300 400 500 600 800 > $OUT/solve_build_a_lower.txt 2>&1 < /dev/null
-cut -c1-30,100-250 $OUT/solve_default.txt; sed 's/^/lower /' $OUT/solve_build_a_lower.txt | cut -c1-36,106-256
+cut -c1-30,100-250 $OUT/solve_default.txt
+for mode in lower rows rows+lower; do      # never run: k_build_A without the upper tiles / with the row of H staged in LDS (+ k_rank_diag_u)
+  BALM_BUILD_A=$mode timeout 600 python tools/bench_solve.py 100 200 256 300 400 500 600 800 > $OUT/solve_build_a_$mode.txt 2>&1 < /dev/null
+  sed "s/^/$mode /" $OUT/solve_build_a_$mode.txt | cut -c1-42,112-262
+done
+BALM_BUILD_A=rows+lower timeout 900 python -m pytest tests/test_gpu_solve.py -q -m gpu -x > $OUT/pytest_solve_rows_lower.txt 2>&1 < /dev/null; tail -2 $OUT/pytest_solve_rows_lower.txt
 cd /tmp; export TMPDIR=/tmp
 for W in 500 200; do
   rm -rf $OUT/prof_solve$W
