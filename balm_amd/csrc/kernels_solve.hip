@@ -1070,8 +1070,13 @@ void launch_solve(balm_ctx *c, bool new_hessian, int upd_form, const double *upd
   launch_factor(c);
   if (c->solve_backsub) {           // x (permuted order) -> chunk 0 of d_x; chunk 1 is the workgroups' exchange buffer
     const int P = nA / NB;
-    hipLaunchKernelGGL(k_ldl_backsolve, dim3(P), dim3(256), 0, s, c->d_A, nA, P, c->solve_tiled ? 1 : 0, c->d_minv, c->d_dvec, c->d_z, c->d_x + nA, c->d_x,
-                       c->d_flags + (size_t)2 * (2 * P + 1) * P + P);
+    static const bool bs_fused = getenv("BALM_BACKSOLVE") && !strcmp(getenv("BALM_BACKSOLVE"), "fused");      // (not yet run: kernels_chain.inc)
+    if (bs_fused)
+      hipLaunchKernelGGL(k_ldl_backsolve2, dim3(P), dim3(256), 0, s, c->d_A, nA, P, c->solve_tiled ? 1 : 0, c->d_minv, c->d_dvec, c->d_z, c->d_x + nA, c->d_x,
+                         c->d_flags + (size_t)2 * (2 * P + 1) * P + P);
+    else
+      hipLaunchKernelGGL(k_ldl_backsolve, dim3(P), dim3(256), 0, s, c->d_A, nA, P, c->solve_tiled ? 1 : 0, c->d_minv, c->d_dvec, c->d_z, c->d_x + nA, c->d_x,
+                         c->d_flags + (size_t)2 * (2 * P + 1) * P + P);
   } else {
     hipLaunchKernelGGL(k_ldl_apply, dim3((nA + 63) / 64, APPLY_CHUNKS), dim3(256), 0, s, c->d_A, nA, c->d_dvec, c->d_z, c->d_x);
   }

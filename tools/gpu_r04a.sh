@@ -16,6 +16,10 @@ for mode in lower rows rows+lower; do      # never run: k_build_A without the up
   sed "s/^/$mode /" $OUT/solve_build_a_$mode.txt | cut -c1-42,112-262
 done
 BALM_BUILD_A=rows+lower timeout 900 python -m pytest tests/test_gpu_solve.py -q -m gpu -x > $OUT/pytest_solve_rows_lower.txt 2>&1 < /dev/null; tail -2 $OUT/pytest_solve_rows_lower.txt
+# never run: k_ldl_backsolve2 (the last hop as ONE matrix-vector product)
+BALM_BACKSOLVE=fused timeout 600 python tools/bench_solve.py 256 300 400 500 600 800 > $OUT/solve_backsolve_fused.txt 2>&1 < /dev/null
+sed "s/^/bs-fused /" $OUT/solve_backsolve_fused.txt | cut -c1-39,109-259
+BALM_BACKSOLVE=fused timeout 900 python -m pytest tests/test_gpu_solve.py -q -m gpu -x > $OUT/pytest_solve_bs_fused.txt 2>&1 < /dev/null; tail -2 $OUT/pytest_solve_bs_fused.txt
 cd /tmp; export TMPDIR=/tmp
 for W in 500 200; do
   rm -rf $OUT/prof_solve$W
