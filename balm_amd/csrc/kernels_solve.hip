@@ -892,6 +892,72 @@ __global__ __launch_bounds__(1024) void k_ldl_finish(const double *__restrict__ 
   }
 }
 
+// ---- round 3, written after its GPU minutes were gone: NOT yet run, opt-in by BALM_FINISH=fast (tools/gpu_r04a.sh) ----------------------
+// k_ldl_finish is ONE workgroup on the critical path of every LM iteration, 16.5 us at n = 1200 (profiles/r03v_kernel_stats.csv) for what is
+// a handful of memory latencies: as written above, the row loop is rolled with a dependent chain inside (perm -> H diagonal, g), the sum
+// is a ten-step tree with ten barriers over sixteen wavefronts, and the pose update reads dx back from global memory.  Here: every load
+// of a stage in flight at once (compile-time bound MAXI: nA <= 1024 MAXI), the sum by wavefront shuffles + one exchange, dx also kept in
+// LDS for the pose update.  Same dx bit for bit; q1 (scal[2]) is the same terms added in a different order (~1e-16 relative).
+template <int MAXI>
+__global__ __launch_bounds__(1024) void k_ldl_finish_u(const double *__restrict__ x, int nA, int n,
+                                                       const int *__restrict__ perm, const double *__restrict__ H,
+                                                       const double *__restrict__ g, const double *__restrict__ pu, double u_arg,
+                                                       double *__restrict__ dx, double *__restrict__ scal, const int *__restrict__ abort_flag,
+                                                       int upd_form, int W, const double *__restrict__ poses, double *__restrict__ poses_out,
+                                                       int nchunks) {
+  extern __shared__ __attribute__((aligned(16))) double dxl[];      // [n] the step, then [16] the wavefronts' partial sums
+  double *wsum = dxl + n;
+  const double u = pu ? *pu : u_arg;
+  const double poison = *abort_flag ? __longlong_as_double(0x7ff8000000000000ll) : 0.0;
+  const int tid = threadIdx.x;
+  int pv[MAXI];
+  double xv[MAXI];
+#pragma unroll
+  for (int it = 0; it < MAXI; it++) {
+    const int r = tid + 1024 * it;
+    pv[it] = r < nA ? perm[r] : n;
+    double s = 0.0;
+    if (r < nA) {
+      if (nchunks == APPLY_CHUNKS) {
+#pragma unroll
+        for (int k = 0; k < APPLY_CHUNKS; k++) s += x[(size_t)k * nA + r];
+      } else {
+        s = x[r];
+      }
+    }
+    xv[it] = s + poison;
+  }
+  double hv[MAXI], gv[MAXI];
+#pragma unroll
+  for (int it = 0; it < MAXI; it++) {
+    const int p = pv[it];
+    hv[it] = p < n ? H[(size_t)p * n + p] : 0.0;
+    gv[it] = p < n ? g[p] : 0.0;
+  }
+  double q = 0.0;
+#pragma unroll
+  for (int it = 0; it < MAXI; it++) {
+    const int p = pv[it];
+    if (p < n) {
+      dx[p] = xv[it];
+      dxl[p] = xv[it];
+      q += xv[it] * (u * hv[it] * xv[it] - gv[it]);
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) q += __shfl_xor(q, off);
+  if ((tid & 63) == 0) wsum[tid >> 6] = q;
+  __syncthreads();                                   // (also: every dxl[] of this workgroup is written)
+  if (tid == 0) {
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) t += wsum[k];
+    scal[2] = 0.5 * t;
+  }
+  if (poses_out)
+    for (int j = tid; j < W; j += 1024) update_pose(upd_form, j, poses, dxl, poses_out);
+}
+
 #include "kernels_chain.inc"
 
 // Co-resident workgroups of k_ldl_fused on the current device (0 = the cooperative launch is not available).
@@ -1082,8 +1148,19 @@ void launch_solve(balm_ctx *c, bool new_hessian, int upd_form, const double *upd
   }
   {
     const int P = nA / NB;
+    static const bool fin_fast = getenv("BALM_FINISH") && !strcmp(getenv("BALM_FINISH"), "fast");      // (not yet run: k_ldl_finish_u)
+    int *abortf = c->d_flags + (size_t)2 * (2 * P + 1) * P + P;
+    const int nch = c->solve_backsub ? 1 : APPLY_CHUNKS;
+    const size_t flds = ((size_t)n + 16) * sizeof(double);
+    if (fin_fast && nA <= 2048)
+      hipLaunchKernelGGL(k_ldl_finish_u<2>, dim3(1), dim3(1024), flds, s, c->d_x, nA, n, c->d_perm, c->d_H, c->d_g, pu, c->u_value, c->d_dx,
+                         c->d_scal, abortf, upd_form, c->W, upd_poses, upd_out, nch);
+    else if (fin_fast && nA <= 5120)
+      hipLaunchKernelGGL(k_ldl_finish_u<5>, dim3(1), dim3(1024), flds, s, c->d_x, nA, n, c->d_perm, c->d_H, c->d_g, pu, c->u_value, c->d_dx,
+                         c->d_scal, abortf, upd_form, c->W, upd_poses, upd_out, nch);
+    else
     hipLaunchKernelGGL(k_ldl_finish, dim3(1), dim3(1024), 0, s, c->d_x, nA, n, c->d_perm, c->d_H, c->d_g, pu, c->u_value, c->d_dx,
-                       c->d_scal, c->d_flags + (size_t)2 * (2 * P + 1) * P + P, upd_form, c->W, upd_poses, upd_out, c->solve_backsub ? 1 : APPLY_CHUNKS);
+                       c->d_scal, abortf, upd_form, c->W, upd_poses, upd_out, nch);
   }
 }
 
