@@ -74,14 +74,16 @@ __global__ __launch_bounds__(256) void k_build_A(const double *__restrict__ H, c
   for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < nflags; t += (long)gridDim.x * blockDim.x) flags[t] = 0;
   // k_ldl_backsolve's exchange buffer: "not there yet" = all ones (kernels_chain.inc)
   for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < nA; t += (long)gridDim.x * blockDim.x) xs[t] = __longlong_as_double(-1ll);
-  if (tiled) {      // [A ; rhs] tile by tile (kernels_chain.inc: ch_tile), no identity rows: t runs over the tiled layout itself
+  if (tiled) {      // tile by tile (kernels_chain.inc: ch_tile): t runs over the tiled layout itself.  Bits: 1 tile-major [A ; rhs], 2 without the
+                    // tiles above the diagonal (BALM_BUILD_A=lower), 4 with the identity rows behind the right-hand side (BALM_TILED=ident)
     const int P = nA / NB;
-    const long ttotal = (long)(P + 1) * P * NB * NB;
+    const int RBT = (tiled & 4) ? 2 * P + 1 : P + 1;
+    const long ttotal = (long)RBT * P * NB * NB;
     for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < ttotal; t += (long)gridDim.x * blockDim.x) {
       const long tile = t / (NB * NB);
       const int e = (int)(t - tile * (NB * NB));
-      const int cb = (int)(tile / (P + 1)), rb = (int)(tile - (long)cb * (P + 1));
-      if (tiled == 2 && rb < cb) continue;      // (BALM_BUILD_A=lower, unmeasured: nothing on this path reads a tile above the diagonal)
+      const int cb = (int)(tile / RBT), rb = (int)(tile - (long)cb * RBT);
+      if ((tiled & 2) && rb < cb) continue;      // (nothing on this path reads a tile of A above the diagonal)
       const int c = NB * cb + e / NB, rl = e % NB;
       const int pc = perm[c];
       double v;
@@ -93,8 +95,10 @@ __global__ __launch_bounds__(256) void k_build_A(const double *__restrict__ H, c
         } else {
           v = (r == c) ? 1.0 : 0.0;
         }
-      } else {
+      } else if (rb == P) {
         v = (rl == 0 && pc < n) ? -g[pc] : 0.0;
+      } else {
+        v = (NB * (rb - P - 1) + rl == c) ? 1.0 : 0.0;     // identity rows -> L^-T D^+
       }
       A[t] = v;
     }
@@ -128,7 +132,7 @@ __global__ __launch_bounds__(256) void k_build_A(const double *__restrict__ H, c
 // loads (all in flight at once: the loop is unrolled over a compile-time bound -- a rolled copy loop is one memory round trip per
 // iteration), and the column is the LDS gather hrow[perm[r]], written in 384-byte segments.  Same values as
 // k_build_A, bit for bit.  MAXI: nA <= 256 MAXI.  tiled: 0 = column-major with identity rows, 1 = tile-major [A ; rhs], 2 = the same
-// without the tiles above the diagonal (nothing reads them).
+// without the tiles above the diagonal (nothing reads them); as bits (k_build_A): 1 tile-major, 2 no upper tiles, 4 identity rows.
 template <int MAXI>
 __global__ __launch_bounds__(256) void k_build_A_rows(const double *__restrict__ H, const double *__restrict__ g, int n, int nA,
                                                       const int *__restrict__ perm, const double *__restrict__ pu, double u_arg,
@@ -141,7 +145,7 @@ __global__ __launch_bounds__(256) void k_build_A_rows(const double *__restrict__
   const int P = nA / NB, cb = c / NB, cl = c - NB * cb;
   const int ldA = 2 * nA + NB;
   const int pc = perm[c];
-  const int r_begin = tiled == 2 ? NB * cb : 0;
+  const int r_begin = (tiled & 2) ? NB * cb : 0;
   double hv[MAXI];
   int prv[MAXI];
   const double *row = H + (size_t)(pc < n ? pc : 0) * n;
@@ -171,13 +175,15 @@ __global__ __launch_bounds__(256) void k_build_A_rows(const double *__restrict__
         v = (r == c) ? 1.0 : 0.0;
       }
       const int rb = r / NB, rl = r - NB * rb;
-      A[tiled ? ((size_t)cb * (P + 1) + rb) * (NB * NB) + (size_t)cl * NB + rl : (size_t)c * ldA + r] = v;
+      A[tiled ? ((size_t)cb * ((tiled & 4) ? 2 * P + 1 : P + 1) + rb) * (NB * NB) + (size_t)cl * NB + rl : (size_t)c * ldA + r] = v;
     }
   }
-  const int rows = tiled ? nA + NB : ldA;            // right-hand side rows (and, column-major, the identity rows): no loads
+  const int RBT = (tiled & 4) ? 2 * P + 1 : P + 1;
+  const int rows = (tiled && !(tiled & 4)) ? nA + NB : ldA;      // right-hand side rows and (column-major or bit 4) the identity rows: no loads
   for (int r = nA + tid; r < rows; r += 256) {
     const double v = r < nA + NB ? (r == nA ? gv : 0.0) : ((r - (nA + NB) == c) ? 1.0 : 0.0);
-    A[tiled ? ((size_t)cb * (P + 1) + P) * (NB * NB) + (size_t)cl * NB + (r - nA) : (size_t)c * ldA + r] = v;
+    const int rb = P + (r - nA) / NB, rl = (r - nA) % NB;         // row block P = right-hand side, P + 1 + t = identity block t
+    A[tiled ? ((size_t)cb * RBT + rb) * (NB * NB) + (size_t)cl * NB + rl : (size_t)c * ldA + r] = v;
   }
 }
 
@@ -789,6 +795,33 @@ __global__ __launch_bounds__(256) void k_ldl_apply(const double *__restrict__ A,
   if (q == 0 && r < nA) xpart[(size_t)blockIdx.y * nA + r] = (sq[rl] + sq[64 + rl]) + (sq[128 + rl] + sq[192 + rl]);
 }
 
+// k_ldl_apply for the tile-major matrix with identity rows (BALM_TILED=ident; not yet run): M(r, c) lives in identity block r / 48 of
+// column block c / 48 -- a group of 16 columns never straddles a column block.  Same sums in the same order.
+__global__ __launch_bounds__(256) void k_ldl_apply_tiled(const double *__restrict__ A, int nA, const double *__restrict__ dvec,
+                                                         const double *__restrict__ z, double *__restrict__ xpart) {
+  __shared__ double sq[256];
+  const int P = nA / NB, RBT = 2 * P + 1;
+  const int rl = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int r0 = blockIdx.x * 64, r = r0 + rl;
+  const int span = ((nA - r0) / 16 + APPLY_CHUNKS - 1) / APPLY_CHUNKS * 16;
+  const int cbeg = r0 + blockIdx.y * span, cend = min(nA, cbeg + span);
+  double acc0 = 0.0, acc1 = 0.0;
+  const int rr = min(r, nA - 1);
+  const double *Mr = A + (size_t)(P + 1 + rr / NB) * (NB * NB) + rr % NB;        // + column block * RBT tiles + column in block * 48
+  for (int cb = cbeg + 16 * q; cb < cend; cb += 64) {
+    const double *Mc = Mr + (size_t)(cb / NB) * RBT * (NB * NB) + (size_t)(cb % NB) * NB;
+#pragma unroll
+    for (int k = 0; k < 16; k += 2) {
+      const int c = cb + k;
+      acc0 = __builtin_fma(Mc[(size_t)k * NB], dvec[c] * z[c], acc0);
+      acc1 = __builtin_fma(Mc[(size_t)(k + 1) * NB], dvec[c + 1] * z[c + 1], acc1);
+    }
+  }
+  sq[threadIdx.x] = acc0 + acc1;
+  __syncthreads();
+  if (q == 0 && r < nA) xpart[(size_t)blockIdx.y * nA + r] = (sq[rl] + sq[64 + rl]) + (sq[128 + rl] + sq[192 + rl]);
+}
+
 // un-permute, q1 = 0.5 dx.(u D dx - g)    (bavoxel.hpp:1127)
 // ------------------------------------------------------------------------------------------------
 // pose update: left  R <- Exp(dth) R, p <- Exp(dth) p + dt   (bavoxel.hpp:1123-1125)
@@ -1024,7 +1057,7 @@ static void launch_build_A(balm_ctx *c) {
   // workgroup per column with the row of H staged in LDS instead of the 8-byte gather (k_build_A_rows), and k_rank_diag_u.
   static const char *ba = getenv("BALM_BUILD_A");
   static const bool lower_only = ba && strstr(ba, "lower"), by_rows = ba && strstr(ba, "rows");
-  const int tiled = c->solve_tiled ? (lower_only ? 2 : 1) : 0;
+  const int tiled = c->solve_tiled ? (lower_only ? 3 : 1) : (c->solve_tiled_ident ? 5 : 0);       // bits: k_build_A
   const int nflags = 2 * (2 * P + 1) * P + P + 8;
   if (by_rows && nA <= 256 * 20 && n >= 1) {
     const size_t lds = (size_t)n * sizeof(double);
@@ -1054,7 +1087,8 @@ static void launch_factor(balm_ctx *c) {
     if (c->solve_tiled) { c->solve_tiled = false; launch_build_A(c); }      // ... and the other paths read the column-major matrix
   } else {
     const char *mode = getenv("BALM_SOLVE");
-    if (want_fused && solve_wants_chain(c, mode) && launch_factor_chain(c, true)) return;
+    if (want_fused && solve_wants_chain(c, mode) && launch_factor_chain(c, true, c->solve_tiled_ident)) return;
+    if (c->solve_tiled_ident) { c->solve_tiled_ident = false; launch_build_A(c); }      // (refused: the other paths read the column-major matrix)
   }
   if (want_fused) {
     const size_t lds = (size_t)(12 * FLR + 2 * NB * NB + NB) * sizeof(double);
@@ -1131,6 +1165,14 @@ void launch_solve(balm_ctx *c, bool new_hessian, int upd_form, const double *upd
   {
     const char *te = getenv("BALM_TILED");
     c->solve_tiled = solve_wants_backsub(c) && !getenv("BALM_CHAINB_IDENT") && !(te && te[0] == '0');
+    // BALM_TILED=ident (round 3, written after the GPU minutes were gone: NOT yet run): the tile-major layout for k_ldl_chain WITH its
+    // identity rows too (5..30 panels, the bench's n = 1200).  The chain workgroup stages L[p+1, p-1] in 1.0 us out of the tile-major
+    // matrix (n = 3000's tail, profiles/r03z_chain_trace_n3000.txt) and in 2-3 us out of the column-major one (48 segments of 384
+    // bytes ~20 KB apart, profiles/r03d_chain_trace_n1200.txt) -- on the critical path of every panel.  Not for the covariance
+    // (kernels_cov.hip reads M column-major).
+    const char *mode = getenv("BALM_SOLVE");
+    c->solve_tiled_ident = te && !strcmp(te, "ident") && !c->solve_tiled && !c->need_minv && !solve_wants_backsub(c) &&
+                           solve_is_persistent(c) && solve_wants_chain(c, mode) && c->chain_cap != 0 && !(mode && !strcmp(mode, "fused"));
   }
   launch_build_A(c);
   launch_factor(c);
@@ -1144,7 +1186,8 @@ void launch_solve(balm_ctx *c, bool new_hessian, int upd_form, const double *upd
       hipLaunchKernelGGL(k_ldl_backsolve, dim3(P), dim3(256), 0, s, c->d_A, nA, P, c->solve_tiled ? 1 : 0, c->d_minv, c->d_dvec, c->d_z, c->d_x + nA, c->d_x,
                          c->d_flags + (size_t)2 * (2 * P + 1) * P + P);
   } else {
-    hipLaunchKernelGGL(k_ldl_apply, dim3((nA + 63) / 64, APPLY_CHUNKS), dim3(256), 0, s, c->d_A, nA, c->d_dvec, c->d_z, c->d_x);
+    if (c->solve_tiled_ident) hipLaunchKernelGGL(k_ldl_apply_tiled, dim3((nA + 63) / 64, APPLY_CHUNKS), dim3(256), 0, s, c->d_A, nA, c->d_dvec, c->d_z, c->d_x);
+    else hipLaunchKernelGGL(k_ldl_apply, dim3((nA + 63) / 64, APPLY_CHUNKS), dim3(256), 0, s, c->d_A, nA, c->d_dvec, c->d_z, c->d_x);
   }
   {
     const int P = nA / NB;

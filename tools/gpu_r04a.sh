@@ -4,7 +4,7 @@
 #   1. the full GPU suite, smoke() and the default bench on the tree round 3 left (the helpers' global_load_lds staging and the
 #      macro-tile helpers were verified by tests/test_gpu_solve.py + tools/bench_solve.py only)
 #   2. the solve by window size, default and with BALM_BUILD_A=lower / rows / rows+lower (never run), and the solve tests with the last
-#   2b. k_ldl_backsolve2 (BALM_BACKSOLVE=fused) and k_ldl_finish_u (BALM_FINISH=fast), never run; then all opt-ins together: suite + bench
+#   2b. k_ldl_backsolve2 (BALM_BACKSOLVE=fused), k_ldl_finish_u (BALM_FINISH=fast), the tile-major matrix with identity rows (BALM_TILED=ident), never run; then all opt-ins together: suite + bench
 #   3. per-kernel times of one solve at n = 3000 and n = 1200 (read from rocprofv3's database: tools/rocprof_kernels.py)
 REPO=$(pwd); OUT=$REPO/gpurun_out/r04a; mkdir -p $OUT
 timeout 1500 python -m pytest tests -q -m gpu -x > $OUT/pytest_gpu.txt 2>&1 < /dev/null; echo "pytest rc=$?"; tail -3 $OUT/pytest_gpu.txt
@@ -24,13 +24,19 @@ BALM_BACKSOLVE=fused timeout 900 python -m pytest tests/test_gpu_solve.py -q -m 
 # never run: k_ldl_finish_u (one workgroup, every load of a stage in flight, shuffle reduction)
 BALM_FINISH=fast timeout 600 python tools/bench_solve.py 100 200 300 500 > $OUT/solve_finish_fast.txt 2>&1 < /dev/null
 sed "s/^/finish-fast /" $OUT/solve_finish_fast.txt | cut -c1-42,112-262
-# all four together: the solve by window, the tests that drive whole LM runs, the default bench
-export BALM_BUILD_A=rows+lower BALM_BACKSOLVE=fused BALM_FINISH=fast
+# never run: the tile-major layout WITH identity rows for k_ldl_chain at 5..30 panels (the bench's n = 1200)
+BALM_TILED=ident timeout 600 python tools/bench_solve.py 40 100 177 200 240 > $OUT/solve_tiled_ident.txt 2>&1 < /dev/null
+sed "s/^/tiled-ident /" $OUT/solve_tiled_ident.txt | cut -c1-42,112-262
+BALM_TILED=ident timeout 900 python -m pytest tests/test_gpu_solve.py -q -m gpu -x > $OUT/pytest_solve_tiled_ident.txt 2>&1 < /dev/null; tail -2 $OUT/pytest_solve_tiled_ident.txt
+BALM_TILED=ident BALM_SOLVE_TRACE=1 timeout 300 python tools/chain_check.py 200 > $OUT/chain_trace_n1200_tiled_ident.txt 2>&1 < /dev/null; sed -n 4,12p $OUT/chain_trace_n1200_tiled_ident.txt | cut -c1-150
+BALM_SOLVE_TRACE=1 timeout 300 python tools/chain_check.py 200 > $OUT/chain_trace_n1200.txt 2>&1 < /dev/null; sed -n 4,12p $OUT/chain_trace_n1200.txt | cut -c1-150
+# all five together: the solve by window, the tests that drive whole LM runs, the default bench
+export BALM_BUILD_A=rows+lower BALM_BACKSOLVE=fused BALM_FINISH=fast BALM_TILED=ident
 timeout 600 python tools/bench_solve.py 100 177 200 256 300 400 500 600 800 > $OUT/solve_all_optins.txt 2>&1 < /dev/null
 sed "s/^/all /" $OUT/solve_all_optins.txt | cut -c1-34,104-254
 timeout 1500 python -m pytest tests -q -m gpu -x > $OUT/pytest_gpu_all_optins.txt 2>&1 < /dev/null; echo "pytest (opt-ins) rc=$?"; tail -3 $OUT/pytest_gpu_all_optins.txt
 timeout 600 python bench.py --no-cpu > $OUT/bench_all_optins.json 2> $OUT/bench_all_optins.err < /dev/null; tail -c 600 $OUT/bench_all_optins.json
-unset BALM_BUILD_A BALM_BACKSOLVE BALM_FINISH
+unset BALM_BUILD_A BALM_BACKSOLVE BALM_FINISH BALM_TILED
 cd /tmp; export TMPDIR=/tmp
 for W in 500 200; do
   rm -rf $OUT/prof_solve$W
