@@ -2,7 +2,9 @@
 """bench.py -- BA iterations/s of the MI355X hot path on synthetic plane clouds.
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+  N > 1, any of:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (one rank per GPU, RCCL)
+                  python bench.py --gpus N ...   (no launcher: re-executes itself under torch.distributed.run on 127.0.0.1; if that
+                                                  launch fails, ONE process drives the N GPUs through balm_create_multi)
 
 One *step* = one LM iteration of BALM2::damping_iter (bavoxel.hpp:1104-1157) on the device:
 Hessian/gradient evaluation (moments -> factors -> f64-MFMA SYRK -> assemble) + damped LDL^T solve
@@ -181,7 +183,63 @@ def cpu_baseline(sc, ctx, target_seconds=20.0):
     }
 
 
-def main():
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def self_launch(n, argv):
+    """`python bench.py --gpus N` without a launcher: run this same command line as N ranks under torch.distributed.run
+    (what the driver's own N > 1 command does), pass rank 0's JSON line through.  Returns (exit code, the JSON line or None)."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["BALM_BENCH_SELF_LAUNCHED"] = "1"
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    try:
+        p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stdin=subprocess.DEVNULL, text=True,
+                           timeout=float(os.environ.get("BALM_BENCH_LAUNCH_TIMEOUT", "1500")))
+    except subprocess.TimeoutExpired:
+        return 124, None
+    line = None
+    for ln in p.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+    return p.returncode, line
+
+
+def resolve_launch(args, world, argv, cuda_available, device_count):
+    """How `--gpus N` is going to run.  Returns one of
+         ("ranks", None)     started by a launcher (WORLD_SIZE set) or N = 1: this process is one rank
+         ("self", None)      N > 1 without a launcher: re-execute under torch.distributed.run, fall back to "inproc"
+         ("inproc", None)    N > 1 in ONE process through balm_create_multi (BALM_BENCH_INPROC=1 forces it)
+         ("exit", (code, message))
+    Only a missing GPU or fewer than N visible devices is an error; the launcher is never the caller's problem."""
+    if not cuda_available:
+        return "exit", (3, "bench.py: no GPU visible; the HIP path has no CPU fallback")
+    if world > 1:
+        if device_count < 1:
+            return "exit", (3, "bench.py: no GPU visible; the HIP path has no CPU fallback")
+        return "ranks", None
+    if args.gpus <= 1:
+        return "ranks", None
+    if os.environ.get("BALM_BENCH_LOOPBACK") == "1":      # testing on a one-GPU box: the N shards of the one-process path on ONE device
+        return "inproc", None
+    if device_count < args.gpus:
+        return "exit", (4, "bench.py: --gpus %d, but only %d GPU(s) are visible to this process" % (args.gpus, device_count))
+    if os.environ.get("BALM_BENCH_INPROC") == "1":
+        return "inproc", None
+    return "self", None
+
+
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -198,21 +256,28 @@ def main():
     ap.add_argument("--no-accept", action="store_true", help="N > 1: skip the untimed acceptance run against the reference's golden trace")
     ap.add_argument("--transport", default="rccl", choices=["rccl", "hook"],
                     help="N > 1: RCCL inside the library (stream-ordered) or the torch.distributed hook")
-    args = ap.parse_args()
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = ap.parse_args(argv)
 
     import torch
     from balm_amd import capi, dist as bdist, scene
 
     rank, local_rank, world = bdist.env_rank()
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            print("bench.py: --gpus %d needs torch.distributed.run (WORLD_SIZE=%d)" % (args.gpus, world),
-                  file=sys.stderr)
-            sys.exit(2)
+    mode, why = resolve_launch(args, world, argv, torch.cuda.is_available(), torch.cuda.device_count() if torch.cuda.is_available() else 0)
+    if mode == "exit":
+        print(why[1], file=sys.stderr)
+        sys.exit(why[0])
+    if mode == "self":
+        rc, line = self_launch(args.gpus, argv)
+        if line is not None and rc == 0:
+            print(line, flush=True)
+            return
+        print("bench.py: launching %d ranks under torch.distributed.run failed (exit code %s); running the %d GPUs from this one "
+              "process through balm_create_multi instead" % (args.gpus, rc, args.gpus), file=sys.stderr)
+        mode = "inproc"
+    inproc = mode == "inproc"
+    n_gpus = args.gpus if inproc else world
     multi = world > 1 or os.environ.get("BALM_BENCH_FORCE_DIST") == "1"   # the latter: exercise the N>1 code path on one GPU
-    if not torch.cuda.is_available():
-        print("bench.py: no GPU visible; the HIP path has no CPU fallback", file=sys.stderr)
-        sys.exit(3)
     torch.cuda.set_device(local_rank)
     if multi:
         bdist.init_process_group("nccl")
@@ -220,17 +285,22 @@ def main():
     W = args.win
     if args.features > 0:
         Fg = args.features
-    elif world > 1 and not args.weak:
-        Fg = F_SHARDED_TOTAL // world
+    elif n_gpus > 1 and not args.weak:
+        Fg = F_SHARDED_TOTAL // n_gpus
     else:
         Fg = F_SINGLE
     # every rank draws its own shard of one global scene: same trajectory and initial pose noise on all ranks
     # (engine(seed)), disjoint per-feature streams (feature_offset)
-    sc = scene.generate(args.seed, W, Fg, args.pts, mode=1, feature_offset=rank * Fg)
+    # (one process driving all N GPUs draws the whole scene -- the same features -- and the context shards it)
+    sc = scene.generate(args.seed, W, Fg * n_gpus if inproc else Fg, args.pts, mode=1, feature_offset=0 if inproc else rank * Fg)
 
-    ctx = capi.Context(W, local_rank, capi.FLAG_TIMING)
+    loopback = inproc and os.environ.get("BALM_BENCH_LOOPBACK") == "1"
+    ctx = (capi.Context(W, 0, capi.FLAG_TIMING | (capi.FLAG_LOOPBACK_SHARDS if loopback else 0), n_devices=n_gpus) if inproc
+           else capi.Context(W, local_rank, capi.FLAG_TIMING))
     ctx.set_features(sc.clusters, None, sc.coeffs)
     transport = None
+    if inproc:
+        transport = "loopback shards on one device (testing)" if loopback else "rccl-in-library, one process (balm_create_multi)"
     if multi:
         if args.transport == "rccl":
             transport = bdist.install_rccl(ctx)
@@ -239,7 +309,8 @@ def main():
             transport = "torch.distributed hook (host-synchronised)"
 
     def barrier():
-        torch.cuda.synchronize()
+        for d in (range(n_gpus) if (inproc and not loopback) else [local_rank]):
+            torch.cuda.synchronize(d)
         if multi:
             import torch.distributed as dist
             dist.barrier()
@@ -284,8 +355,8 @@ def main():
     wm = ctx.work_model()
     comm = ctx.comm_info()
     accept = None
-    if multi and not args.no_accept:
-        accept = acceptance_check(ctx, sc.poses_init, args.seed, W, Fg * world, args.pts)
+    if (multi or inproc) and not args.no_accept:
+        accept = acceptance_check(ctx, sc.poses_init, args.seed, W, Fg * n_gpus, args.pts)
     if multi:
         import torch.distributed as dist
         if args.transport == "hook":
@@ -295,7 +366,7 @@ def main():
     if rank != 0:
         return
 
-    F_total = Fg * world
+    F_total = Fg * n_gpus
     iters_per_s = args.steps / dt
     n = 6 * W
     per_step = {k: v[0] / args.steps for k, v in timing.items()}
@@ -345,22 +416,25 @@ def main():
     out = {
         "metric": "BA iterations/sec (W poses x F plane features)",
         "value": iters_per_s, "unit": "iter/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-        "scaling": None if world == 1 else ("weak" if (args.weak or args.features > 0) else "strong"),
+        "scaling": None if n_gpus == 1 else ("weak" if (args.weak or args.features > 0) else "strong"),
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": "BASELINE configs[%d]: W=%d poses, %d plane features in total (%d per GPU), "
                                "%d pts per (feature,pose), full HIP accumulate + LDL^T LM solve"
-                               % (2 if world == 1 else 3, W, F_total, Fg, args.pts),
+                               % (2 if n_gpus == 1 else 3, W, F_total, Fg, args.pts),
                    "W": W, "features_per_gpu": Fg, "features_total": F_total, "form": "left",
                    "parallelism": ("features sharded x%d, one all-reduce of [tiles|blockdiag|r] per evaluation via %s"
-                                   % (world, transport)) if multi else "single GPU"},
+                                   % (n_gpus, transport)) if (multi or inproc) else "single GPU",
+                   "launch": "one process, balm_create_multi" if inproc else
+                             ("torch.distributed.run started by bench.py itself" if os.environ.get("BALM_BENCH_SELF_LAUNCHED") == "1" and world > 1
+                              else ("torch.distributed.run" if world > 1 else "plain python"))},
         "feature_iterations_per_sec": iters_per_s * F_total,     # size-normalised aggregate, comparable across N and F
-        "comm": {"transport": comm["transport"], "ranks_reported_by_transport": comm["ranks"], "world_size": world,
+        "comm": {"transport": comm["transport"], "ranks_reported_by_transport": comm["ranks"], "world_size": n_gpus,
                  "payload_bytes_per_evaluation": comm["payload_doubles"] * 8,
                  "allreduce_ms_per_step": timing["comm"][0] / args.steps, "allreduces_per_step": timing["comm"][1] / args.steps,
                  "note": "stream time of the all-reduces on rank 0 (HIP events around the RCCL calls on the library's stream): "
-                         "includes waiting for the slowest rank"} if multi else None,
+                         "includes waiting for the slowest rank"} if (multi or inproc) else None,
         "kernel_ms_per_step": per_step,
         "roofline": roofline,
         "roofline_secondary": secondary,
@@ -373,7 +447,7 @@ def main():
     if accept is not None:
         accept.pop("_poses", None)
         out["acceptance"] = accept
-    if world == 1 and not multi and not args.no_strong_ref and not args.no_cpu and args.features == 0 and W == 200:      # (--no-cpu: no extra legs at all)
+    if n_gpus == 1 and not multi and not args.no_strong_ref and not args.no_cpu and args.features == 0 and W == 200:      # (--no-cpu: no extra legs at all)
         # the problem the N > 1 runs shard (BASELINE configs[3]: 200 000 features in total) on ONE GPU: the N = 1 point of the
         # strong-scaling curve (`value` above is configs[2], a 4x smaller problem, and not comparable with the N > 1 values)
         try:
@@ -429,7 +503,7 @@ def main():
             ctx.set_features(sc.clusters, None, sc.coeffs)
         except Exception as e:
             out["strong_scaling_reference"] = {"error": repr(e)}
-    if world == 1 and not args.no_cpu:
+    if n_gpus == 1 and not args.no_cpu:
         try:
             out["cpu_baseline"] = cpu_baseline(sc, ctx, args.cpu_seconds)
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
