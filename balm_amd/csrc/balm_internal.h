@@ -149,7 +149,10 @@ struct balm_ctx {
   balm::Timer timer;
   // collective transport (balm_multi.hip): stream-ordered RCCL inside the library, either as one of the devices of a
   // balm_create_multi context or as one rank of a multi-process job (balm_comm_init_rank)
-  void *comm = nullptr;             // ncclComm_t
+  void *comm = nullptr;             // ncclComm_t; written only by the thread that owns the context's calls (never by a peer)
+  std::atomic<bool> comm_dead{false};   // a peer device thread aborted this communicator (multi_abort): no further collective
+  bool comm_aborted = false;        // ncclCommAbort was called on `comm` (guarded by comm_mu)
+  std::timed_mutex comm_mu;         // [check comm_dead + enqueue ncclAllReduce] vs [set comm_dead + ncclCommAbort]
   int rank = 0, nranks = 1;
   struct balm_multi *multi = nullptr;   // set on every device context of a balm_create_multi context
   double *d_pre = nullptr;          // [W + 2] pre-loop all-reduce: planes per pose, error flag
@@ -206,7 +209,7 @@ struct balm_multi {
   // (the scalar hand-over of the LM loop, the loopback barrier) with it instead of waiting for a peer that is gone.  An
   // RCCL communicator whose peer never enqueued its collective is aborted (ncclCommAbort) and the context is dead.
   std::atomic<int> abort_rc{0};
-  bool dead = false;
+  std::atomic<bool> dead{false};
   // LM decision scalars of device 0, per iteration parity
   std::atomic<uint64_t> lm_seq{0};
   uint64_t lm_epoch = 0;

@@ -95,7 +95,7 @@ int comm_init_rank(balm_ctx *ctx, int nranks, int rank, const void *id128) {
 void comm_destroy(balm_ctx *ctx) {
   if (!ctx->comm) return;
   const Rccl *r = rccl();
-  if (r) r->CommDestroy((ncclComm_t)ctx->comm);
+  if (r && !ctx->comm_aborted) r->CommDestroy((ncclComm_t)ctx->comm);      // (an aborted communicator is already freed)
   ctx->comm = nullptr;
 }
 
@@ -114,7 +114,18 @@ int comm_allreduce(balm_ctx *ctx, double *buf, long n) {
   static const bool skip = getenv("BALM_COMM_SKIP_ONE_RANK") != nullptr;      // experiment (tools/exp_dist_overhead.py): a one-rank sum is the identity
   if (skip && ctx->nranks == 1) return BALM_OK;
   const auto t0 = std::chrono::steady_clock::now();
-  const ncclResult_t e = r->AllReduce(buf, buf, (size_t)n, ncclDouble, ncclSum, (ncclComm_t)ctx->comm, ctx->stream);
+  ncclResult_t e;
+  {
+    // the enqueue and a peer's ncclCommAbort of this communicator (multi_abort) exclude each other: the handle is
+    // either used before it is aborted or not at all
+    std::lock_guard<std::timed_mutex> lk(ctx->comm_mu);
+    void *comm = ctx->comm;
+    if (!comm || ctx->comm_dead.load(std::memory_order_acquire)) {
+      ctx->err = "the communicator was aborted after a peer device failed";
+      return BALM_ERR_STATE;
+    }
+    e = r->AllReduce(buf, buf, (size_t)n, ncclDouble, ncclSum, (ncclComm_t)comm, ctx->stream);
+  }
   if (dbg) {
     ctx->comm_host_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
     if ((++ctx->comm_calls % 64) == 0)
@@ -147,8 +158,10 @@ struct Barrier {
 
 // A device thread returned `rc` != 0 from the current job.  Its peers may be waiting for it on the host (the LM loop's
 // scalar hand-over, the loopback barrier) or on the device (an all-reduce it never enqueued): the former are woken with the
-// status, the latter are taken down with their communicators (ncclCommAbort releases the peers' collective kernels); a
-// context that lost its communicators answers BALM_ERR_STATE from then on.
+// status, the latter are released by ncclCommAbort of their communicators -- the one RCCL call that is meant to come from
+// another thread while a collective hangs.  This thread never writes a peer's `comm` pointer: it marks the communicator dead
+// under the peer's comm_mu (so the peer either enqueued before the abort or refuses to enqueue after it), and multi_run
+// clears the pointers once every device thread of the job has returned.  The context answers BALM_ERR_STATE from then on.
 void multi_abort(balm_multi *m, int rc) {
   int expected = 0;
   if (!m->abort_rc.compare_exchange_strong(expected, rc, std::memory_order_acq_rel)) return;
@@ -156,9 +169,15 @@ void multi_abort(balm_multi *m, int rc) {
   if (!m->loopback && m->n > 1) {
     const Rccl *r = rccl();
     if (r && r->CommAbort) {
-      for (auto *c : m->sub)
-        if (c->comm) { r->CommAbort((ncclComm_t)c->comm); c->comm = nullptr; }
-      m->dead = true;
+      m->dead.store(true, std::memory_order_release);
+      for (auto *c : m->sub) {
+        c->comm_dead.store(true, std::memory_order_release);       // first: no new enqueue starts
+        std::unique_lock<std::timed_mutex> lk(c->comm_mu, std::chrono::seconds(2));   // an enqueue in flight returns first (bounded:
+        if (c->comm && !c->comm_aborted) {                                             //  a wedged one must not wedge the abort too)
+          c->comm_aborted = true;
+          r->CommAbort((ncclComm_t)c->comm);
+        }
+      }
     }
   }
 }
@@ -183,7 +202,7 @@ static void worker_main(balm_multi *m, int k) {
 // f(k) on the thread of device k (k = 0: the calling thread); returns the first non-zero result
 int multi_run(balm_multi *m, const std::function<int(int)> &f) {
   if (m->n == 1) return f(0);
-  if (m->dead) { m->sub[0]->err = "the context lost its communicators when a device failed (ncclCommAbort): destroy it"; return BALM_ERR_STATE; }
+  if (m->dead.load(std::memory_order_acquire)) { m->sub[0]->err = "the context lost its communicators when a device failed (ncclCommAbort): destroy it"; return BALM_ERR_STATE; }
   {
     std::lock_guard<std::mutex> lk(m->mu);
     m->abort_rc.store(0, std::memory_order_release);
@@ -199,6 +218,8 @@ int multi_run(balm_multi *m, const std::function<int(int)> &f) {
     m->cv_done.wait(lk, [&] { return m->pending == 0; });
     m->job = nullptr;
   }
+  if (m->dead.load(std::memory_order_acquire))       // every device thread is back: the aborted handles can go (ncclCommAbort freed them)
+    for (auto *c : m->sub) { std::lock_guard<std::timed_mutex> lk(c->comm_mu); c->comm = nullptr; }
   for (int rc : m->rc) if (rc) return rc;
   return BALM_OK;
 }

@@ -991,6 +991,33 @@ __global__ __launch_bounds__(1024) void k_ldl_finish_u(const double *__restrict_
     for (int j = tid; j < W; j += 1024) update_pose(upd_form, j, poses, dxl, poses_out);
 }
 
+// How the persistent kernels (k_ldl_fused, k_ldl_chain) are launched.  Neither uses a grid-wide barrier: they only need every
+// workgroup RESIDENT, which the grid size guarantees by construction (<= hipOccupancyMaxActiveBlocksPerMultiprocessor x CUs, on a
+// stream whose earlier kernels have drained), and every wait in them is bounded (-> abort flag -> BALM_ERR_NUMERIC, never a hang).
+// hipLaunchCooperativeKernel adds the runtime's own guarantee, at a price: the launch goes through the device's cooperative queue
+// with barrier packets on both sides, and issued from a thread other than the process's first it leaves ROCm 7.2 in a state that
+// segfaults at exit (tools/exp_crash.py).  BALM_COOP=0 / 1 forces the plain / cooperative launch; default: cooperative, except from the device threads of an in-process multi-device context.
+static bool coop_wanted(const balm_ctx *c) {
+  static const char *e = getenv("BALM_COOP");
+  if (e) return e[0] != '0';
+  return !(c->multi && c->multi->n > 1);
+}
+// Loopback shards (the one-GPU test vehicle of the multi-device context) run their replicated solves on n streams of ONE device at
+// the same time: each replica may only count on 1/n of the device's slots, or the plain launches would wait for each other's CUs.
+static int persistent_slots(const balm_ctx *c, int cap) {
+  if (cap > 0 && c->multi && c->multi->n > 1 && c->multi->loopback) return cap / c->multi->n;
+  return cap;
+}
+template <class Args>
+static hipError_t persistent_launch(const balm_ctx *c, void (*kernel)(Args), dim3 grid, dim3 block, Args &a, size_t lds, hipStream_t s) {
+  if (coop_wanted(c)) {
+    void *args[] = {(void *)&a};
+    return hipLaunchCooperativeKernel((const void *)kernel, grid, block, args, (unsigned)lds, s);
+  }
+  hipLaunchKernelGGL(kernel, grid, block, lds, s, a);
+  return hipGetLastError();
+}
+
 #include "kernels_chain.inc"
 
 // Co-resident workgroups of k_ldl_fused on the current device (0 = the cooperative launch is not available).
@@ -1017,10 +1044,15 @@ constexpr int CHAIN_MIN_P = 5, CHAIN_MAX_P = 40;      // (from 31 panels on the 
 // k_ldl_backsolve (kernels_chain.inc): the identity rows that yield L^-T D^+ are 70 % of the far updates at P = 63.  Not when the
 // caller needs that inverse (balm_pose_covariance: c->need_minv).  BALM_SOLVE=chainb forces it from CHAIN_MIN_P panels on.
 constexpr int CHAINB_MIN_P = 31, CHAINB_MAX_P = 100;      // n = 1488 .. 4800 (profiles/r03z_solve_paths_by_window.txt: n = 3600 1.44 vs 2.11 ms on the launch path, n = 4800 3.00 vs 4.10)
+static bool multi_persistent_off() {
+  static const char *e = getenv("BALM_MULTI_PERSISTENT");
+  return e && e[0] == '0';
+}
 static bool solve_wants_backsub(const balm_ctx *c) {
   const int P = c->nA / NB;
   const char *mode = getenv("BALM_SOLVE");
-  if (c->need_minv || c->chain_cap == 0 || (c->multi && c->multi->n > 1)) return false;
+  if (c->need_minv || c->chain_cap == 0 || (c->multi && c->multi->n > 1 && multi_persistent_off())) return false;
+  if (c->multi && c->multi->n > 1 && c->multi->loopback && P * c->multi->n > (c->chain_cap > 0 ? c->chain_cap : 256)) return false;   // k_ldl_backsolve's P workgroups per replica, all resident
   if (mode && !strcmp(mode, "chainb")) return P >= CHAIN_MIN_P && P <= 100;
   if (mode) return false;                              // launches / fused / chain: the other paths, as asked
   return P >= CHAINB_MIN_P && P <= CHAINB_MAX_P;
@@ -1035,11 +1067,10 @@ bool solve_is_persistent(const balm_ctx *c) {
   const int P = c->nA / NB;
   const char *mode = getenv("BALM_SOLVE");              // A/B: "launches" / "fused" / "chain" force one path
   const bool forced = mode && (!strcmp(mode, "fused") || !strcmp(mode, "chain"));
-  // Not from the device threads of an in-process multi-device context: a cooperative launch issued by a thread other than
-  // the process's first leaves this runtime (ROCm 7.2) in a state that segfaults at process exit (tools/exp_crash.py:
-  // exit code 139 after a correct run; launches path: 0).  Those replicas take the launch path with lookahead (+6 % per
-  // solve at n = 1200); one process per GPU (balm_comm_init_rank) is not affected.
-  if (c->multi && c->multi->n > 1) return false;
+  // The device threads of an in-process multi-device context launch it PLAINLY (persistent_launch: a cooperative launch from a
+  // thread other than the process's first leaves ROCm 7.2 in a state that segfaults at process exit, tools/exp_crash.py).
+  // BALM_MULTI_PERSISTENT=0: those replicas take the launch path instead (0.45 vs 0.28 ms per solve at n = 1200).
+  if (c->multi && c->multi->n > 1 && multi_persistent_off()) return false;
   if (mode && !strcmp(mode, "launches")) return false;
   if (solve_wants_backsub(c)) return true;
   if (forced) return P >= 2 && (c->fused_cap != 0 || c->chain_cap != 0);
@@ -1094,14 +1125,13 @@ static void launch_factor(balm_ctx *c) {
     const size_t lds = (size_t)(12 * FLR + 2 * NB * NB + NB) * sizeof(double);
     if (c->fused_cap < 0) c->fused_cap = fused_capacity(lds);
     const int RB = 2 * P + 1;
-    int NH = c->fused_cap - RB;
+    int NH = persistent_slots(c, c->fused_cap) - RB;
     const int most = (P - 2) * P;                        // tiles with far updates: more helpers than tiles idle
     if (NH > most) NH = most;
     if (P == 2) NH = 0;
     if (NH >= (P > 2 ? 1 : 0)) {
       FusedArgs fa{c->d_A, c->d_dvec, c->d_z, c->d_flags, c->d_flags + (size_t)RB * P, nA, P, RB, NH > 0 ? NH : 1, c->d_trace};
-      void *args[] = {(void *)&fa};
-      if (hipLaunchCooperativeKernel((const void *)k_ldl_fused, dim3(RB + (P > 2 ? NH : 0)), dim3(FT), args, (unsigned)lds, s) == hipSuccess)
+      if (persistent_launch(c, k_ldl_fused, dim3(RB + (P > 2 ? NH : 0)), dim3(FT), fa, lds, s) == hipSuccess)
         return;
       hipGetLastError();
       c->fused_cap = 0;                                  // not again on this context

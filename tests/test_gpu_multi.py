@@ -146,3 +146,34 @@ def test_a_failing_device_thread_takes_its_peers_out_instead_of_hanging(fault):
     out, lg = c.damping_iter(sc.poses_init, u0=0.1, max_iter=6)            # the next job starts clean
     assert np.array_equal(out, ref) and np.array_equal(lg, lref)
     c.close()
+
+
+@pytest.mark.parametrize("W,n", [(200, 4), (64, 2), (260, 2)])
+def test_multi_context_keeps_the_persistent_solve_and_exits_cleanly(W, n):
+    """The device threads of balm_create_multi launch k_ldl_chain plainly (a cooperative launch from a thread other than the process's
+    first segfaulted ROCm 7.2 at exit: tools/exp_crash.py): the replicas run the SAME factorisation kernel as a plain context (25 / 8
+    panels with identity rows; 33 panels with the back-substitution), reproduce its LM run, and the process exits with code 0."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, numpy as np\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "from balm_amd import capi, scene\n"
+        "sc = scene.generate(5, %d, 600, 6, mode=1)\n"
+        "a = capi.Context(sc.W); a.set_features(sc.clusters, None, sc.coeffs)\n"
+        "b = capi.Context(sc.W, 0, capi.FLAG_LOOPBACK_SHARDS, n_devices=%d); b.set_features(sc.clusters, None, sc.coeffs)\n"
+        "pa, la = a.damping_iter(sc.poses_init, u0=0.01, max_iter=6)\n"
+        "pb, lb = b.damping_iter(sc.poses_init, u0=0.01, max_iter=6)\n"
+        "assert len(la) == len(lb) and np.array_equal(la[:, 6], lb[:, 6]), (la, lb)\n"
+        "assert np.allclose(la[:, :2], lb[:, :2], rtol=1e-9, atol=0), (la, lb)\n"
+        "assert np.abs(pa - pb).max() < 1e-9\n"
+        "a.close(); b.close(); print('done', flush=True)\n" % (root, os.path.join(root, "tests"), W, n))
+    env = dict(os.environ, BALM_SOLVE_DEBUG="1")
+    p = subprocess.run([sys.executable, "-c", code], env=env, stdin=subprocess.DEVNULL, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       text=True, timeout=600)
+    assert p.returncode == 0, (p.returncode, p.stdout[-500:], p.stderr[-1500:])
+    assert "done" in p.stdout
+    lines = [ln for ln in p.stderr.splitlines() if "balm_hip: solve" in ln and "multi=%d" % n in ln]
+    assert lines and all("persistent=1" in ln for ln in lines), p.stderr[-1500:]
