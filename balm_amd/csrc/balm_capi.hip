@@ -438,7 +438,17 @@ balm_ctx *balm_create(int win_size, int device, int flags) {
   }
   ctx->ntiles = (int)(jobs.size() / 4);
   ctx->h_jobs = jobs;
-  if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) return fail();
+  {
+    // BALM_STREAM_PRIORITY=high: the context's stream at the device's greatest priority (experiment: does a process that also holds
+    // RCCL's streams get its kernels dispatched sooner?  tools/exp_dist_overhead.py)
+    const char *sp = getenv("BALM_STREAM_PRIORITY");
+    int lo = 0, hi = 0;
+    if (sp && !strcmp(sp, "high") && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess) {
+      if (hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, hi) != hipSuccess) return fail();
+    } else if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+      return fail();
+    }
+  }
   const int W = ctx->W, n = ctx->n, nA = ctx->nA;
   ctx->red_len = (size_t)ctx->ntiles * TILE_ELEMS + (size_t)DACC_MAX * W + 2;
   if (dalloc(ctx, &ctx->d_poses, (size_t)12 * W) || dalloc(ctx, &ctx->d_poses_tmp, (size_t)12 * W) ||

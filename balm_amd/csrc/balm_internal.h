@@ -120,7 +120,7 @@ struct balm_ctx {
   double comm_host_us = 0.0; long comm_calls = 0;      // BALM_COMM_DEBUG: host time inside the transport's calls
   bool need_minv = false;           // the caller wants M = L^-T D^+ in the identity rows of d_A (balm_pose_covariance): no back-substitution path
   bool solve_tiled = false;         // d_A holds [A ; rhs] tile by tile (k_build_A -> k_ldl_chain without identity rows -> k_ldl_backsolve)
-  bool solve_tiled_ident = false;   // BALM_TILED=ident: [A ; rhs ; identity] is stored tile by tile for this solve (k_ldl_chain with identity rows, k_ldl_apply_tiled)
+  int chain_refused_P[2] = {-1, -1};   // panels for which launch_factor_chain refused [without / with identity rows] (too few co-resident helpers, ...)
   bool solve_backsub = false;       // the last factorisation ran without identity rows: k_ldl_backsolve instead of k_ldl_apply
   double u_value = 0.0;             // damping of the next solve (set_damping)
   bool u_on_device = false;         // ... read by the solve's kernels from d_scal[SCAL_U] (graph capture / replay) instead of their arguments

@@ -30,16 +30,25 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 // ------------------------------------------------------------------------------------------------
 // permutation by decreasing |diag H| (ties by index); padded positions (>= n) go last.
 // 16 ranks per workgroup, the j-range split sixteen ways (the kernel is on the critical path of every solve and
-// has no other parallelism to offer: nA / 16 workgroups instead of nA / 64).
+// has no other parallelism to offer: nA / 16 workgroups instead of nA / 64).  The diagonal's loads are unrolled over a
+// compile-time bound (MAXI: nA <= 256 MAXI) so that all of them are in flight at once -- as a rolled loop every
+// workgroup walked nA / 256 dependent memory round trips: 23 us at n = 3000 (round 3), 10.5 -> 9 us at n = 1200.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_rank_diag(const double *__restrict__ H, int n, int nA,
-                                                   int *__restrict__ perm) {
+template <int MAXI>
+__global__ __launch_bounds__(256) void k_rank_diag(const double *__restrict__ H, int n, int nA, int *__restrict__ perm) {
   extern __shared__ __attribute__((aligned(16))) double dabs[];   // [nA] then int part[256]
   int *part = reinterpret_cast<int *>(dabs + nA);
+  double dv[MAXI];
+#pragma unroll
+  for (int it = 0; it < MAXI; it++) {
+    const int i = threadIdx.x + 256 * it;
+    dv[it] = i < n ? fabs(H[(size_t)i * n + i]) : -1.0;
+  }
   // a NaN diagonal ranks after every real entry and before the padding, so that perm stays a permutation
-  for (int i = threadIdx.x; i < nA; i += blockDim.x) {
-    const double v = i < n ? fabs(H[(size_t)i * n + i]) : -1.0;
-    dabs[i] = v == v ? v : -0.5;
+#pragma unroll
+  for (int it = 0; it < MAXI; it++) {
+    const int i = threadIdx.x + 256 * it;
+    if (i < nA) dabs[i] = dv[it] == dv[it] ? dv[it] : -0.5;
   }
   __syncthreads();
   const int il = threadIdx.x & 15, q = threadIdx.x >> 4;
@@ -64,88 +73,33 @@ __global__ __launch_bounds__(256) void k_rank_diag(const double *__restrict__ H,
   }
 }
 
-__global__ __launch_bounds__(256) void k_build_A(const double *__restrict__ H, const double *__restrict__ g, int n,
-                                                 int nA, const int *__restrict__ perm, const double *__restrict__ pu, double u_arg,
+// ------------------------------------------------------------------------------------------------
+// The damped, symmetrically permuted matrix with its right-hand side (and, column-major, the identity rows that become
+// L^-T D^+):  A[r][c] = H[perm[r]][perm[c]] (+ u H[..] on the diagonal: D = diag(H), bavoxel.hpp:1113), row block P = -g[perm[c]].
+// ONE workgroup builds ONE column c: row perm[c] of H is contiguous (H is symmetric), goes into LDS with coalesced loads -- all in
+// flight at once: the loop is unrolled over a compile-time bound, MAXI: nA <= 256 MAXI -- and the column is the LDS gather
+// hrow[perm[r]], written in 384-byte segments.  (Round 3's form gathered H[perm[c] * n + perm[r]] from memory, 8 bytes out of every
+// 64-byte sector: 114 us at n = 3000 = 145 MB at 1.3 TB/s; this one, measured in round 4: n = 3000 solve 0.992 -> 0.905 ms, n = 4800
+// 3.01 -> 2.68, n = 1200 0.277 -> 0.273, profiles/r04a_solve_switches.txt.)  It also zeroes the flags of the persistent kernels and
+// fills k_ldl_backsolve's exchange buffer with "not there yet" = all ones.
+// tiled: 0 = column-major [A ; rhs ; identity] (ldA = 2 nA + 48), what k_ldl_chain with identity rows, k_ldl_fused, the launch path,
+// k_ldl_apply and the covariance read; 1 = tile-major [A ; rhs] (kernels_chain.inc: ch_tile) for k_ldl_chain + k_ldl_backsolve, without
+// the tiles above the diagonal -- nothing on that path reads them (-54 us of the 114 at n = 3000 by itself).
+// ------------------------------------------------------------------------------------------------
+template <int MAXI>
+__global__ __launch_bounds__(256) void k_build_A(const double *__restrict__ H, const double *__restrict__ g, int n, int nA,
+                                                 const int *__restrict__ perm, const double *__restrict__ pu, double u_arg,
                                                  double *__restrict__ A, int *__restrict__ flags, int nflags, double *__restrict__ xs, int tiled) {
+  extern __shared__ __attribute__((aligned(16))) double hrow[];       // [n] row perm[c] of H
   const double u = pu ? *pu : u_arg;    // replayed hipGraphs read the damping from device memory (the launch sequence of an LM
                                         // iteration is then the same for every iteration); plain launches carry it as an argument
-  const int ldA = 2 * nA + NB;
-  const long total = (long)ldA * nA;
-  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < nflags; t += (long)gridDim.x * blockDim.x) flags[t] = 0;
-  // k_ldl_backsolve's exchange buffer: "not there yet" = all ones (kernels_chain.inc)
-  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < nA; t += (long)gridDim.x * blockDim.x) xs[t] = __longlong_as_double(-1ll);
-  if (tiled) {      // tile by tile (kernels_chain.inc: ch_tile): t runs over the tiled layout itself.  Bits: 1 tile-major [A ; rhs], 2 without the
-                    // tiles above the diagonal (BALM_BUILD_A=lower), 4 with the identity rows behind the right-hand side (BALM_TILED=ident)
-    const int P = nA / NB;
-    const int RBT = (tiled & 4) ? 2 * P + 1 : P + 1;
-    const long ttotal = (long)RBT * P * NB * NB;
-    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < ttotal; t += (long)gridDim.x * blockDim.x) {
-      const long tile = t / (NB * NB);
-      const int e = (int)(t - tile * (NB * NB));
-      const int cb = (int)(tile / RBT), rb = (int)(tile - (long)cb * RBT);
-      if ((tiled & 2) && rb < cb) continue;      // (nothing on this path reads a tile of A above the diagonal)
-      const int c = NB * cb + e / NB, rl = e % NB;
-      const int pc = perm[c];
-      double v;
-      if (rb < P) {
-        const int r = NB * rb + rl, pr = perm[r];
-        if (pr < n && pc < n) {
-          v = H[(size_t)pc * n + pr];
-          if (r == c) v += u * v;
-        } else {
-          v = (r == c) ? 1.0 : 0.0;
-        }
-      } else if (rb == P) {
-        v = (rl == 0 && pc < n) ? -g[pc] : 0.0;
-      } else {
-        v = (NB * (rb - P - 1) + rl == c) ? 1.0 : 0.0;     // identity rows -> L^-T D^+
-      }
-      A[t] = v;
-    }
-    return;
-  }
-  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
-    const int c = (int)(t / ldA), r = (int)(t - (long)c * ldA);
-    const int pc = perm[c];
-    double v;
-    if (r < nA) {
-      const int pr = perm[r];
-      if (pr < n && pc < n) {
-        v = H[(size_t)pc * n + pr];
-        if (r == c) v += u * v;      // D = diag(H)  (bavoxel.hpp:1113)
-      } else {
-        v = (r == c) ? 1.0 : 0.0;
-      }
-    } else if (r < nA + NB) {
-      v = (r == nA && pc < n) ? -g[pc] : 0.0;     // right-hand side row: P (-JacT)
-    } else {
-      v = (r - (nA + NB) == c) ? 1.0 : 0.0;       // identity rows -> L^-T D^+
-    }
-    A[t] = v;
-  }
-}
-
-// ---- round 3, written after its GPU minutes were gone: NOT yet run, opt-in by BALM_BUILD_A=rows[+lower] (tools/gpu_r04a.sh) --------
-// k_build_A above is a gather through the pivot permutation, H[perm[c] * n + perm[r]]: consecutive lanes read 8 bytes from 64-byte
-// sectors scattered over a row -- 114 us at n = 3000 (145 MB at 1.3 TB/s, profiles/r03z_solve_kernels_n3000.txt), 11 % of that
-// solve.  Here ONE workgroup builds ONE column c of the tall matrix: row perm[c] of H is contiguous, goes into LDS with coalesced
-// loads (all in flight at once: the loop is unrolled over a compile-time bound -- a rolled copy loop is one memory round trip per
-// iteration), and the column is the LDS gather hrow[perm[r]], written in 384-byte segments.  Same values as
-// k_build_A, bit for bit.  MAXI: nA <= 256 MAXI.  tiled: 0 = column-major with identity rows, 1 = tile-major [A ; rhs], 2 = the same
-// without the tiles above the diagonal (nothing reads them); as bits (k_build_A): 1 tile-major, 2 no upper tiles, 4 identity rows.
-template <int MAXI>
-__global__ __launch_bounds__(256) void k_build_A_rows(const double *__restrict__ H, const double *__restrict__ g, int n, int nA,
-                                                      const int *__restrict__ perm, const double *__restrict__ pu, double u_arg,
-                                                      double *__restrict__ A, int *__restrict__ flags, int nflags, double *__restrict__ xs, int tiled) {
-  extern __shared__ __attribute__((aligned(16))) double hrow[];       // [n] row perm[c] of H
-  const double u = pu ? *pu : u_arg;
   const int tid = threadIdx.x, c = blockIdx.x;
   for (long t = (long)c * 256 + tid; t < nflags; t += (long)gridDim.x * 256) flags[t] = 0;
   for (long t = (long)c * 256 + tid; t < nA; t += (long)gridDim.x * 256) xs[t] = __longlong_as_double(-1ll);
   const int P = nA / NB, cb = c / NB, cl = c - NB * cb;
   const int ldA = 2 * nA + NB;
   const int pc = perm[c];
-  const int r_begin = (tiled & 2) ? NB * cb : 0;
+  const int r_begin = tiled ? NB * cb : 0;
   double hv[MAXI];
   int prv[MAXI];
   const double *row = H + (size_t)(pc < n ? pc : 0) * n;
@@ -175,55 +129,14 @@ __global__ __launch_bounds__(256) void k_build_A_rows(const double *__restrict__
         v = (r == c) ? 1.0 : 0.0;
       }
       const int rb = r / NB, rl = r - NB * rb;
-      A[tiled ? ((size_t)cb * ((tiled & 4) ? 2 * P + 1 : P + 1) + rb) * (NB * NB) + (size_t)cl * NB + rl : (size_t)c * ldA + r] = v;
+      A[tiled ? ((size_t)cb * (P + 1) + rb) * (NB * NB) + (size_t)cl * NB + rl : (size_t)c * ldA + r] = v;
     }
   }
-  const int RBT = (tiled & 4) ? 2 * P + 1 : P + 1;
-  const int rows = (tiled && !(tiled & 4)) ? nA + NB : ldA;      // right-hand side rows and (column-major or bit 4) the identity rows: no loads
+  const int rows = tiled ? nA + NB : ldA;           // the right-hand side rows and (column-major) the identity rows: no loads
   for (int r = nA + tid; r < rows; r += 256) {
     const double v = r < nA + NB ? (r == nA ? gv : 0.0) : ((r - (nA + NB) == c) ? 1.0 : 0.0);
-    const int rb = P + (r - nA) / NB, rl = (r - nA) % NB;         // row block P = right-hand side, P + 1 + t = identity block t
-    A[tiled ? ((size_t)cb * RBT + rb) * (NB * NB) + (size_t)cl * NB + rl : (size_t)c * ldA + r] = v;
-  }
-}
-
-// k_rank_diag with the diagonal's loads in flight at once (as a rolled loop every one of the nA / 16 workgroups walks nA / 256 dependent
-// memory round trips through it: 23 us at n = 3000).  Same ranks.  Not yet run either.
-template <int MAXI>
-__global__ __launch_bounds__(256) void k_rank_diag_u(const double *__restrict__ H, int n, int nA, int *__restrict__ perm) {
-  extern __shared__ __attribute__((aligned(16))) double dabs[];   // [nA] then int part[256]
-  int *part = reinterpret_cast<int *>(dabs + nA);
-  double dv[MAXI];
-#pragma unroll
-  for (int it = 0; it < MAXI; it++) {
-    const int i = threadIdx.x + 256 * it;
-    dv[it] = i < n ? fabs(H[(size_t)i * n + i]) : -1.0;
-  }
-#pragma unroll
-  for (int it = 0; it < MAXI; it++) {
-    const int i = threadIdx.x + 256 * it;
-    if (i < nA) dabs[i] = dv[it] == dv[it] ? dv[it] : -0.5;
-  }
-  __syncthreads();
-  const int il = threadIdx.x & 15, q = threadIdx.x >> 4;
-  const int i = blockIdx.x * 16 + il;
-  int rank = 0;
-  if (i < nA) {
-    const double di = dabs[i];
-    const int chunk = (nA + 15) / 16;
-    const int j0 = q * chunk, j1 = min(nA, j0 + chunk);
-    for (int j = j0; j < j1; j++) {
-      const double dj = dabs[j];
-      rank += (dj > di) || (dj == di && j < i);
-    }
-  }
-  part[threadIdx.x] = rank;
-  __syncthreads();
-  if (q == 0 && i < nA) {
-    rank = 0;
-#pragma unroll
-    for (int k = 0; k < 16; k++) rank += part[16 * k + il];
-    perm[rank] = i;
+    const int rb = P + (r - nA) / NB, rl = (r - nA) % NB;         // row block P = right-hand side
+    A[tiled ? ((size_t)cb * (P + 1) + rb) * (NB * NB) + (size_t)cl * NB + rl : (size_t)c * ldA + r] = v;
   }
 }
 
@@ -795,33 +708,6 @@ __global__ __launch_bounds__(256) void k_ldl_apply(const double *__restrict__ A,
   if (q == 0 && r < nA) xpart[(size_t)blockIdx.y * nA + r] = (sq[rl] + sq[64 + rl]) + (sq[128 + rl] + sq[192 + rl]);
 }
 
-// k_ldl_apply for the tile-major matrix with identity rows (BALM_TILED=ident; not yet run): M(r, c) lives in identity block r / 48 of
-// column block c / 48 -- a group of 16 columns never straddles a column block.  Same sums in the same order.
-__global__ __launch_bounds__(256) void k_ldl_apply_tiled(const double *__restrict__ A, int nA, const double *__restrict__ dvec,
-                                                         const double *__restrict__ z, double *__restrict__ xpart) {
-  __shared__ double sq[256];
-  const int P = nA / NB, RBT = 2 * P + 1;
-  const int rl = threadIdx.x & 63, q = threadIdx.x >> 6;
-  const int r0 = blockIdx.x * 64, r = r0 + rl;
-  const int span = ((nA - r0) / 16 + APPLY_CHUNKS - 1) / APPLY_CHUNKS * 16;
-  const int cbeg = r0 + blockIdx.y * span, cend = min(nA, cbeg + span);
-  double acc0 = 0.0, acc1 = 0.0;
-  const int rr = min(r, nA - 1);
-  const double *Mr = A + (size_t)(P + 1 + rr / NB) * (NB * NB) + rr % NB;        // + column block * RBT tiles + column in block * 48
-  for (int cb = cbeg + 16 * q; cb < cend; cb += 64) {
-    const double *Mc = Mr + (size_t)(cb / NB) * RBT * (NB * NB) + (size_t)(cb % NB) * NB;
-#pragma unroll
-    for (int k = 0; k < 16; k += 2) {
-      const int c = cb + k;
-      acc0 = __builtin_fma(Mc[(size_t)k * NB], dvec[c] * z[c], acc0);
-      acc1 = __builtin_fma(Mc[(size_t)(k + 1) * NB], dvec[c + 1] * z[c + 1], acc1);
-    }
-  }
-  sq[threadIdx.x] = acc0 + acc1;
-  __syncthreads();
-  if (q == 0 && r < nA) xpart[(size_t)blockIdx.y * nA + r] = (sq[rl] + sq[64 + rl]) + (sq[128 + rl] + sq[192 + rl]);
-}
-
 // un-permute, q1 = 0.5 dx.(u D dx - g)    (bavoxel.hpp:1127)
 // ------------------------------------------------------------------------------------------------
 // pose update: left  R <- Exp(dth) R, p <- Exp(dth) p + dt   (bavoxel.hpp:1123-1125)
@@ -925,72 +811,6 @@ __global__ __launch_bounds__(1024) void k_ldl_finish(const double *__restrict__ 
   }
 }
 
-// ---- round 3, written after its GPU minutes were gone: NOT yet run, opt-in by BALM_FINISH=fast (tools/gpu_r04a.sh) ----------------------
-// k_ldl_finish is ONE workgroup on the critical path of every LM iteration, 16.5 us at n = 1200 (profiles/r03v_kernel_stats.csv) for what is
-// a handful of memory latencies: as written above, the row loop is rolled with a dependent chain inside (perm -> H diagonal, g), the sum
-// is a ten-step tree with ten barriers over sixteen wavefronts, and the pose update reads dx back from global memory.  Here: every load
-// of a stage in flight at once (compile-time bound MAXI: nA <= 1024 MAXI), the sum by wavefront shuffles + one exchange, dx also kept in
-// LDS for the pose update.  Same dx bit for bit; q1 (scal[2]) is the same terms added in a different order (~1e-16 relative).
-template <int MAXI>
-__global__ __launch_bounds__(1024) void k_ldl_finish_u(const double *__restrict__ x, int nA, int n,
-                                                       const int *__restrict__ perm, const double *__restrict__ H,
-                                                       const double *__restrict__ g, const double *__restrict__ pu, double u_arg,
-                                                       double *__restrict__ dx, double *__restrict__ scal, const int *__restrict__ abort_flag,
-                                                       int upd_form, int W, const double *__restrict__ poses, double *__restrict__ poses_out,
-                                                       int nchunks) {
-  extern __shared__ __attribute__((aligned(16))) double dxl[];      // [n] the step, then [16] the wavefronts' partial sums
-  double *wsum = dxl + n;
-  const double u = pu ? *pu : u_arg;
-  const double poison = *abort_flag ? __longlong_as_double(0x7ff8000000000000ll) : 0.0;
-  const int tid = threadIdx.x;
-  int pv[MAXI];
-  double xv[MAXI];
-#pragma unroll
-  for (int it = 0; it < MAXI; it++) {
-    const int r = tid + 1024 * it;
-    pv[it] = r < nA ? perm[r] : n;
-    double s = 0.0;
-    if (r < nA) {
-      if (nchunks == APPLY_CHUNKS) {
-#pragma unroll
-        for (int k = 0; k < APPLY_CHUNKS; k++) s += x[(size_t)k * nA + r];
-      } else {
-        s = x[r];
-      }
-    }
-    xv[it] = s + poison;
-  }
-  double hv[MAXI], gv[MAXI];
-#pragma unroll
-  for (int it = 0; it < MAXI; it++) {
-    const int p = pv[it];
-    hv[it] = p < n ? H[(size_t)p * n + p] : 0.0;
-    gv[it] = p < n ? g[p] : 0.0;
-  }
-  double q = 0.0;
-#pragma unroll
-  for (int it = 0; it < MAXI; it++) {
-    const int p = pv[it];
-    if (p < n) {
-      dx[p] = xv[it];
-      dxl[p] = xv[it];
-      q += xv[it] * (u * hv[it] * xv[it] - gv[it]);
-    }
-  }
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) q += __shfl_xor(q, off);
-  if ((tid & 63) == 0) wsum[tid >> 6] = q;
-  __syncthreads();                                   // (also: every dxl[] of this workgroup is written)
-  if (tid == 0) {
-    double t = 0.0;
-#pragma unroll
-    for (int k = 0; k < 16; k++) t += wsum[k];
-    scal[2] = 0.5 * t;
-  }
-  if (poses_out)
-    for (int j = tid; j < W; j += 1024) update_pose(upd_form, j, poses, dxl, poses_out);
-}
-
 // How the persistent kernels (k_ldl_fused, k_ldl_chain) are launched.  Neither uses a grid-wide barrier: they only need every
 // workgroup RESIDENT, which the grid size guarantees by construction (<= hipOccupancyMaxActiveBlocksPerMultiprocessor x CUs, on a
 // stream whose earlier kernels have drained), and every wait in them is bounded (-> abort flag -> BALM_ERR_NUMERIC, never a hang).
@@ -1051,7 +871,7 @@ static bool multi_persistent_off() {
 static bool solve_wants_backsub(const balm_ctx *c) {
   const int P = c->nA / NB;
   const char *mode = getenv("BALM_SOLVE");
-  if (c->need_minv || c->chain_cap == 0 || (c->multi && c->multi->n > 1 && multi_persistent_off())) return false;
+  if (c->need_minv || c->chain_cap == 0 || c->chain_refused_P[0] == P || (c->multi && c->multi->n > 1 && multi_persistent_off())) return false;
   if (c->multi && c->multi->n > 1 && c->multi->loopback && P * c->multi->n > (c->chain_cap > 0 ? c->chain_cap : 256)) return false;   // k_ldl_backsolve's P workgroups per replica, all resident
   if (mode && !strcmp(mode, "chainb")) return P >= CHAIN_MIN_P && P <= 100;
   if (mode) return false;                              // launches / fused / chain: the other paths, as asked
@@ -1074,34 +894,22 @@ bool solve_is_persistent(const balm_ctx *c) {
   if (mode && !strcmp(mode, "launches")) return false;
   if (solve_wants_backsub(c)) return true;
   if (forced) return P >= 2 && (c->fused_cap != 0 || c->chain_cap != 0);
-  return (P >= CHAIN_MIN_P && P <= CHAIN_MAX_P && c->chain_cap != 0) || (P >= 18 && P <= FUSED_MAX_P && c->fused_cap != 0);
+  return (P >= CHAIN_MIN_P && P <= CHAIN_MAX_P && c->chain_cap != 0 && c->chain_refused_P[1] != P) || (P >= 18 && P <= FUSED_MAX_P && c->fused_cap != 0);
 }
 
 static void launch_build_A(balm_ctx *c) {
   const int n = c->n, nA = c->nA, P = nA / NB;
   const double *pu = c->u_on_device ? c->d_scal + SCAL_U : nullptr;
-  long total = (long)(2 * nA + NB) * nA;
-  int grid = (int)((total + 255) / 256);
-  if (grid > 4096) grid = 4096;
-  // BALM_BUILD_A=lower | rows | rows+lower (round 3, written after the GPU budget ended: NOT yet run; first thing to measure in
-  // round 4, tools/gpu_r04a.sh).  lower: the tile-major build skips the tiles above the diagonal -- nothing reads them.  rows: a
-  // workgroup per column with the row of H staged in LDS instead of the 8-byte gather (k_build_A_rows), and k_rank_diag_u.
-  static const char *ba = getenv("BALM_BUILD_A");
-  static const bool lower_only = ba && strstr(ba, "lower"), by_rows = ba && strstr(ba, "rows");
-  const int tiled = c->solve_tiled ? (lower_only ? 3 : 1) : (c->solve_tiled_ident ? 5 : 0);       // bits: k_build_A
+  const int tiled = c->solve_tiled ? 1 : 0;
   const int nflags = 2 * (2 * P + 1) * P + P + 8;
-  if (by_rows && nA <= 256 * 20 && n >= 1) {
-    const size_t lds = (size_t)n * sizeof(double);
-#define BALM_BUILD_ROWS(M) hipLaunchKernelGGL(k_build_A_rows<M>, dim3(nA), dim3(256), lds, c->stream, c->d_H, c->d_g, n, nA, c->d_perm, pu, c->u_value, \
-                                              c->d_A, c->d_flags, nflags, c->d_x + nA, tiled)
-    if (nA <= 256 * 5) BALM_BUILD_ROWS(5);
-    else if (nA <= 256 * 10) BALM_BUILD_ROWS(10);
-    else BALM_BUILD_ROWS(20);
-#undef BALM_BUILD_ROWS
-    return;
-  }
-  hipLaunchKernelGGL(k_build_A, dim3(grid), dim3(256), 0, c->stream, c->d_H, c->d_g, n, nA, c->d_perm, pu, c->u_value, c->d_A, c->d_flags,
-                     nflags, c->d_x + nA, tiled);
+  const size_t lds = (size_t)n * sizeof(double);
+#define BALM_BUILD_A(M) hipLaunchKernelGGL(k_build_A<M>, dim3(nA), dim3(256), lds, c->stream, c->d_H, c->d_g, n, nA, c->d_perm, pu, c->u_value, \
+                                           c->d_A, c->d_flags, nflags, c->d_x + nA, tiled)
+  if (nA <= 256 * 5) BALM_BUILD_A(5);             // n <= 1280: the bench window (n = 1200), the shipped one (1062)
+  else if (nA <= 256 * 10) BALM_BUILD_A(10);
+  else if (nA <= 256 * 16) BALM_BUILD_A(16);
+  else BALM_BUILD_A(25);                          // nA <= 6400: every window balm_create takes (W <= 1024: nA = 6144)
+#undef BALM_BUILD_A
 }
 
 static void launch_factor(balm_ctx *c) {
@@ -1118,8 +926,7 @@ static void launch_factor(balm_ctx *c) {
     if (c->solve_tiled) { c->solve_tiled = false; launch_build_A(c); }      // ... and the other paths read the column-major matrix
   } else {
     const char *mode = getenv("BALM_SOLVE");
-    if (want_fused && solve_wants_chain(c, mode) && launch_factor_chain(c, true, c->solve_tiled_ident)) return;
-    if (c->solve_tiled_ident) { c->solve_tiled_ident = false; launch_build_A(c); }      // (refused: the other paths read the column-major matrix)
+    if (want_fused && solve_wants_chain(c, mode) && launch_factor_chain(c, true, false)) return;
   }
   if (want_fused) {
     const size_t lds = (size_t)(12 * FLR + 2 * NB * NB + NB) * sizeof(double);
@@ -1181,57 +988,31 @@ void launch_solve(balm_ctx *c, bool new_hessian, int upd_form, const double *upd
   const int n = c->n, nA = c->nA;
   const double *pu = c->u_on_device ? c->d_scal + SCAL_U : nullptr;
   if (new_hessian) {
-    static const char *ba = getenv("BALM_BUILD_A");
     const size_t lds = (size_t)nA * sizeof(double) + 256 * sizeof(int);
-    if (ba && strstr(ba, "rows") && nA <= 256 * 20) {       // (not yet run: see launch_build_A)
-      if (nA <= 256 * 5) hipLaunchKernelGGL(k_rank_diag_u<5>, dim3((nA + 15) / 16), dim3(256), lds, s, c->d_H, n, nA, c->d_perm);
-      else if (nA <= 256 * 10) hipLaunchKernelGGL(k_rank_diag_u<10>, dim3((nA + 15) / 16), dim3(256), lds, s, c->d_H, n, nA, c->d_perm);
-      else hipLaunchKernelGGL(k_rank_diag_u<20>, dim3((nA + 15) / 16), dim3(256), lds, s, c->d_H, n, nA, c->d_perm);
-    } else {
-      hipLaunchKernelGGL(k_rank_diag, dim3((nA + 15) / 16), dim3(256), lds, s, c->d_H, n, nA, c->d_perm);
-    }
+    const dim3 grid((nA + 15) / 16);
+    if (nA <= 256 * 5) hipLaunchKernelGGL(k_rank_diag<5>, grid, dim3(256), lds, s, c->d_H, n, nA, c->d_perm);
+    else if (nA <= 256 * 10) hipLaunchKernelGGL(k_rank_diag<10>, grid, dim3(256), lds, s, c->d_H, n, nA, c->d_perm);
+    else if (nA <= 256 * 16) hipLaunchKernelGGL(k_rank_diag<16>, grid, dim3(256), lds, s, c->d_H, n, nA, c->d_perm);
+    else hipLaunchKernelGGL(k_rank_diag<25>, grid, dim3(256), lds, s, c->d_H, n, nA, c->d_perm);
   }
   // [A ; rhs] tile by tile for k_ldl_chain + k_ldl_backsolve (no identity rows, nobody else reads the matrix); BALM_TILED=0: A/B
   {
     const char *te = getenv("BALM_TILED");
     c->solve_tiled = solve_wants_backsub(c) && !getenv("BALM_CHAINB_IDENT") && !(te && te[0] == '0');
-    // BALM_TILED=ident (round 3, written after the GPU minutes were gone: NOT yet run): the tile-major layout for k_ldl_chain WITH its
-    // identity rows too (5..30 panels, the bench's n = 1200).  The chain workgroup stages L[p+1, p-1] in 1.0 us out of the tile-major
-    // matrix (n = 3000's tail, profiles/r03z_chain_trace_n3000.txt) and in 2-3 us out of the column-major one (48 segments of 384
-    // bytes ~20 KB apart, profiles/r03d_chain_trace_n1200.txt) -- on the critical path of every panel.  Not for the covariance
-    // (kernels_cov.hip reads M column-major).
-    const char *mode = getenv("BALM_SOLVE");
-    c->solve_tiled_ident = te && !strcmp(te, "ident") && !c->solve_tiled && !c->need_minv && !solve_wants_backsub(c) &&
-                           solve_is_persistent(c) && solve_wants_chain(c, mode) && c->chain_cap != 0 && !(mode && !strcmp(mode, "fused"));
   }
   launch_build_A(c);
   launch_factor(c);
   if (c->solve_backsub) {           // x (permuted order) -> chunk 0 of d_x; chunk 1 is the workgroups' exchange buffer
     const int P = nA / NB;
-    static const bool bs_fused = getenv("BALM_BACKSOLVE") && !strcmp(getenv("BALM_BACKSOLVE"), "fused");      // (not yet run: kernels_chain.inc)
-    if (bs_fused)
-      hipLaunchKernelGGL(k_ldl_backsolve2, dim3(P), dim3(256), 0, s, c->d_A, nA, P, c->solve_tiled ? 1 : 0, c->d_minv, c->d_dvec, c->d_z, c->d_x + nA, c->d_x,
-                         c->d_flags + (size_t)2 * (2 * P + 1) * P + P);
-    else
-      hipLaunchKernelGGL(k_ldl_backsolve, dim3(P), dim3(256), 0, s, c->d_A, nA, P, c->solve_tiled ? 1 : 0, c->d_minv, c->d_dvec, c->d_z, c->d_x + nA, c->d_x,
-                         c->d_flags + (size_t)2 * (2 * P + 1) * P + P);
+    hipLaunchKernelGGL(k_ldl_backsolve, dim3(P), dim3(256), 0, s, c->d_A, nA, P, c->solve_tiled ? 1 : 0, c->d_minv, c->d_dvec, c->d_z, c->d_x + nA, c->d_x,
+                       c->d_flags + (size_t)2 * (2 * P + 1) * P + P);
   } else {
-    if (c->solve_tiled_ident) hipLaunchKernelGGL(k_ldl_apply_tiled, dim3((nA + 63) / 64, APPLY_CHUNKS), dim3(256), 0, s, c->d_A, nA, c->d_dvec, c->d_z, c->d_x);
-    else hipLaunchKernelGGL(k_ldl_apply, dim3((nA + 63) / 64, APPLY_CHUNKS), dim3(256), 0, s, c->d_A, nA, c->d_dvec, c->d_z, c->d_x);
+    hipLaunchKernelGGL(k_ldl_apply, dim3((nA + 63) / 64, APPLY_CHUNKS), dim3(256), 0, s, c->d_A, nA, c->d_dvec, c->d_z, c->d_x);
   }
   {
     const int P = nA / NB;
-    static const bool fin_fast = getenv("BALM_FINISH") && !strcmp(getenv("BALM_FINISH"), "fast");      // (not yet run: k_ldl_finish_u)
     int *abortf = c->d_flags + (size_t)2 * (2 * P + 1) * P + P;
     const int nch = c->solve_backsub ? 1 : APPLY_CHUNKS;
-    const size_t flds = ((size_t)n + 16) * sizeof(double);
-    if (fin_fast && nA <= 2048)
-      hipLaunchKernelGGL(k_ldl_finish_u<2>, dim3(1), dim3(1024), flds, s, c->d_x, nA, n, c->d_perm, c->d_H, c->d_g, pu, c->u_value, c->d_dx,
-                         c->d_scal, abortf, upd_form, c->W, upd_poses, upd_out, nch);
-    else if (fin_fast && nA <= 5120)
-      hipLaunchKernelGGL(k_ldl_finish_u<5>, dim3(1), dim3(1024), flds, s, c->d_x, nA, n, c->d_perm, c->d_H, c->d_g, pu, c->u_value, c->d_dx,
-                         c->d_scal, abortf, upd_form, c->W, upd_poses, upd_out, nch);
-    else
     hipLaunchKernelGGL(k_ldl_finish, dim3(1), dim3(1024), 0, s, c->d_x, nA, n, c->d_perm, c->d_H, c->d_g, pu, c->u_value, c->d_dx,
                        c->d_scal, abortf, upd_form, c->W, upd_poses, upd_out, nch);
   }
