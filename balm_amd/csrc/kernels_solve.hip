@@ -811,16 +811,22 @@ __global__ __launch_bounds__(1024) void k_ldl_finish(const double *__restrict__ 
   }
 }
 
-// How the persistent kernels (k_ldl_fused, k_ldl_chain) are launched.  Neither uses a grid-wide barrier: they only need every
+// How the persistent kernels (k_ldl_fused, k_ldl_chain) are launched: PLAINLY.  Neither uses a grid-wide barrier: they only need every
 // workgroup RESIDENT, which the grid size guarantees by construction (<= hipOccupancyMaxActiveBlocksPerMultiprocessor x CUs, on a
 // stream whose earlier kernels have drained), and every wait in them is bounded (-> abort flag -> BALM_ERR_NUMERIC, never a hang).
-// hipLaunchCooperativeKernel adds the runtime's own guarantee, at a price: the launch goes through the device's cooperative queue
-// with barrier packets on both sides, and issued from a thread other than the process's first it leaves ROCm 7.2 in a state that
-// segfaults at exit (tools/exp_crash.py).  BALM_COOP=0 / 1 forces the plain / cooperative launch; default: cooperative, except from the device threads of an in-process multi-device context.
+// hipLaunchCooperativeKernel adds the runtime's own guarantee at a price that round 4 measured (profiles/r04b_solve_coop.txt,
+// r04b_dist_overhead.txt): the launch goes through the device's cooperative queue with barrier packets on both sides --
+//   * 22-24 us per solve at every size (n = 240: 0.082 -> 0.060 ms, n = 1200: 0.277 -> 0.253, n = 3000: 0.893 -> 0.866);
+//   * in a process that also holds an RCCL communicator on the same stream (one rank per GPU) the cross-queue barriers multiply: EVERY
+//     kernel of the step runs late (k_rank_diag 51 instead of 9 us, assemble 0.19 instead of 0.06 ms, the SYRK +6 %): 0.7 ms per LM
+//     step, round 3's unexplained "communicator tax".  With plain launches it is gone (4.29 vs 4.26 ms/step at config 2);
+//   * issued from a thread other than the process's first it leaves ROCm 7.2 in a state that segfaults at exit (tools/exp_crash.py),
+//     which is why the device threads of balm_create_multi had no persistent solve in round 3.
+// BALM_COOP=1 brings the cooperative launch back (A/B).
 static bool coop_wanted(const balm_ctx *c) {
   static const char *e = getenv("BALM_COOP");
-  if (e) return e[0] != '0';
-  return !(c->multi && c->multi->n > 1);
+  if (e && e[0] == '1') return !(c->multi && c->multi->n > 1);      // (never from a device thread of a multi-device context)
+  return false;
 }
 // Loopback shards (the one-GPU test vehicle of the multi-device context) run their replicated solves on n streams of ONE device at
 // the same time: each replica may only count on 1/n of the device's slots, or the plain launches would wait for each other's CUs.
