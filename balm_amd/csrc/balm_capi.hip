@@ -456,7 +456,7 @@ balm_ctx *balm_create(int win_size, int device, int flags) {
       dalloc(ctx, &ctx->d_H, (size_t)n * n) || dalloc(ctx, &ctx->d_g, (size_t)n) ||
       dalloc(ctx, &ctx->d_A, (size_t)(2 * nA + NB) * nA) || dalloc(ctx, &ctx->d_Wp, (size_t)2 * NB * (2 * nA + NB)) ||
       dalloc(ctx, &ctx->d_dvec, (size_t)nA) || dalloc(ctx, &ctx->d_z, (size_t)nA) || dalloc(ctx, &ctx->d_x, (size_t)16 * nA) ||
-      dalloc(ctx, &ctx->d_perm, (size_t)nA) || dalloc(ctx, &ctx->d_flags, (size_t)2 * (2 * (nA / NB) + 1) * (nA / NB) + (nA / NB) + 8) || dalloc(ctx, &ctx->d_minv, (size_t)(nA / NB) * NB * NB) || dalloc(ctx, &ctx->d_dx, (size_t)n) ||
+      dalloc(ctx, &ctx->d_perm, (size_t)nA) || dalloc(ctx, &ctx->d_flags, (size_t)2 * (2 * (nA / NB) + 1) * (nA / NB) + (nA / NB) + 8) || dalloc(ctx, &ctx->d_minv, (size_t)2 * (nA / NB) * NB * NB) || dalloc(ctx, &ctx->d_dx, (size_t)n) ||
       dalloc(ctx, &ctx->d_scal, (size_t)16) || dalloc(ctx, &ctx->d_pre, (size_t)W + 2))
     return fail();
   if (hipHostMalloc((void **)&ctx->h_scal, (16 + 64 + 8) * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) return fail();
@@ -477,7 +477,7 @@ balm_ctx *balm_create(int win_size, int device, int flags) {
   }
   if (hipMemset(ctx->d_scal, 0, 16 * sizeof(double)) != hipSuccess) return fail();
   if (hipMemset(ctx->d_red, 0, ctx->red_len * sizeof(double)) != hipSuccess) return fail();
-  if (hipMemset(ctx->d_minv, 0, (size_t)(nA / NB) * NB * NB * sizeof(double)) != hipSuccess) return fail();
+  if (hipMemset(ctx->d_minv, 0, (size_t)2 * (nA / NB) * NB * NB * sizeof(double)) != hipSuccess) return fail();
   return ctx;
 }
 

@@ -109,7 +109,7 @@ struct balm_ctx {
   long long *d_trace = nullptr;     // BALM_SOLVE_TRACE=1: [2P+1][P][6] phase timestamps of the last k_ldl_fused (diagnostics)
   int fused_cap = -1;               // co-resident workgroups of k_ldl_fused on this device (-1 = not asked yet, 0 = unavailable)
   int chain_cap = -1;               // ... of k_ldl_chain
-  double *d_minv = nullptr;         // [P][48][48] Minv_p = L11^-T D11^-1 of every panel (k_ldl_chain)
+  double *d_minv = nullptr;         // [P][48][48] Minv_p = L11^-T D11^-1 of every panel (k_ldl_chain), then [P][48][48] its exchange copies of L[p+2, p]
   int *d_macro_tab = nullptr;       // [NH][64] the macro-tiles every helper of k_ldl_chain owns (chain_macro_table), built at the first such launch
   int macro_tab_P = 0, macro_tab_NH = 0;
   double *d_dx = nullptr;           // [n]

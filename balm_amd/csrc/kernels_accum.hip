@@ -108,9 +108,18 @@ __global__ __launch_bounds__(256) void k_world_moments(const double *__restrict_
                                                        const double *__restrict__ poses, int W, int f0, int f1,
                                                        double *__restrict__ Cout) {
   extern __shared__ __attribute__((aligned(16))) double sp[];   // [12][W]
-  for (int t = threadIdx.x; t < 12 * W; t += blockDim.x) {
-    int i = t / 12, c = t - 12 * i;
-    sp[c * W + i] = poses[t];
+  for (int t0 = 0; t0 < 12 * W; t0 += 10 * (int)blockDim.x) {     // ten loads per lane in flight at a time (k_feature_factors: why)
+    double pv[10];
+#pragma unroll
+    for (int j = 0; j < 10; j++) {
+      const int t = t0 + j * (int)blockDim.x + (int)threadIdx.x;
+      pv[j] = t < 12 * W ? poses[t] : 0.0;
+    }
+#pragma unroll
+    for (int j = 0; j < 10; j++) {
+      const int t = t0 + j * (int)blockDim.x + (int)threadIdx.x;
+      if (t < 12 * W) { const int i = t / 12, c = t - 12 * i; sp[c * W + i] = pv[j]; }
+    }
   }
   __syncthreads();
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
@@ -297,6 +306,12 @@ __device__ __forceinline__ void store6(double *dst, const double x[6]) {
   d2 *q = reinterpret_cast<d2 *>(dst);     // 6i doubles -> 48-byte offsets: 16-byte aligned
   d2 t0 = {x[0], x[1]}, t1 = {x[2], x[3]}, t2 = {x[4], x[5]};
   q[0] = t0; q[1] = t1; q[2] = t2;
+}
+// the same as a streaming store: Gt (1.44 GB at config 2) is read next by the SYRK, long after it has left every L2
+__device__ __forceinline__ void store6_nt(double *dst, const double x[6]) {
+  d2 *q = reinterpret_cast<d2 *>(dst);
+  d2 t0 = {x[0], x[1]}, t1 = {x[2], x[3]}, t2 = {x[4], x[5]};
+  __builtin_nontemporal_store(t0, q); __builtin_nontemporal_store(t1, q + 1); __builtin_nontemporal_store(t2, q + 2);
 }
 
 // One observation (feature a, pose i) of K2: the three Gt columns of the pose, and its gradient / block-diagonal terms added to
@@ -495,16 +510,27 @@ __global__ __launch_bounds__(256) void k_feature_factors(const double *__restric
                                                          const double *__restrict__ poses,
                                                          const double *__restrict__ feat, int W, int Wc, int npad, int f0,
                                                          int f1, double *__restrict__ Gt,
-                                                         double *__restrict__ dpart, const int *__restrict__ slot) {
+                                                         double *__restrict__ dpart, const int *__restrict__ slot, int nt) {
   constexpr int DACC = FORM == 0 ? DACC_LEFT : DACC_RIGHT;
   extern __shared__ __attribute__((aligned(16))) double sm[];
   // blockIdx.y = chunk of Wc poses (one chunk = the whole window up to MAX_W_LDS poses)
   const int p0 = blockIdx.y * Wc, wc = min(Wc, W - p0);
   double *sp = sm;                 // [12][Wc] poses of the chunk
   double *sacc = sm + 12 * Wc;     // [DACC][Wc]
-  for (int t = threadIdx.x; t < 12 * wc; t += blockDim.x) {
-    int il = t / 12, c = t - 12 * il;
-    sp[c * Wc + il] = poses[12 * p0 + t];
+  // the pose table, ten loads per lane in flight at a time (rolled, this copy was one memory round trip per iteration -- ~10 dependent
+  // trips at W = 200 before a workgroup's first feature: tools/find_rolled_copies.py)
+  for (int t0 = 0; t0 < 12 * wc; t0 += 10 * (int)blockDim.x) {
+    double pv[10];
+#pragma unroll
+    for (int j = 0; j < 10; j++) {
+      const int t = t0 + j * (int)blockDim.x + (int)threadIdx.x;
+      pv[j] = t < 12 * wc ? poses[12 * p0 + t] : 0.0;
+    }
+#pragma unroll
+    for (int j = 0; j < 10; j++) {
+      const int t = t0 + j * (int)blockDim.x + (int)threadIdx.x;
+      if (t < 12 * wc) { const int il = t / 12, c = t - 12 * il; sp[c * Wc + il] = pv[j]; }
+    }
   }
   for (int t = threadIdx.x; t < DACC * Wc; t += blockDim.x) sacc[t] = 0.0;
   __syncthreads();
@@ -546,9 +572,15 @@ __global__ __launch_bounds__(256) void k_feature_factors(const double *__restric
       const double N = il == (int)threadIdx.x ? nxt[9] : ca[(size_t)9 * W + i];
       if (il == (int)threadIdx.x && a + (int)gridDim.x < f1) fetch(a + gridDim.x, i_first);
       obs_factors<FORM>(fr, P, v, N, sp, sacc, Wc, il, col0, col1, col2);
-      store6(g0 + 6 * i, col0);
-      store6(g0 + (size_t)npad + 6 * i, col1);
-      store6(g0 + (size_t)2 * npad + 6 * i, col2);
+      if (nt) {
+        store6_nt(g0 + 6 * i, col0);
+        store6_nt(g0 + (size_t)npad + 6 * i, col1);
+        store6_nt(g0 + (size_t)2 * npad + 6 * i, col2);
+      } else {
+        store6(g0 + 6 * i, col0);
+        store6(g0 + (size_t)npad + 6 * i, col1);
+        store6(g0 + (size_t)2 * npad + 6 * i, col2);
+      }
     }
   }
   __syncthreads();
@@ -749,10 +781,11 @@ void launch_factors(hipStream_t s, int form, const double *cl, const double *pos
   const int Wc = factors_chunk(W), chunks = (W + Wc - 1) / Wc;
   size_t lds = (size_t)(12 + dacc) * Wc * sizeof(double);
   int bs = W <= 64 ? 64 : (W <= 128 ? 128 : 256);
+  static const int nt = getenv("BALM_GT_NT") ? atoi(getenv("BALM_GT_NT")) : 0;      // A/B (round 4): streaming stores for Gt
   if (form == 0)
-    hipLaunchKernelGGL(k_feature_factors<0>, dim3(nblk, chunks), dim3(bs), lds, s, cl, poses, feat, W, Wc, npad, f0, f1, Gt, dpart, slot);
+    hipLaunchKernelGGL(k_feature_factors<0>, dim3(nblk, chunks), dim3(bs), lds, s, cl, poses, feat, W, Wc, npad, f0, f1, Gt, dpart, slot, nt);
   else
-    hipLaunchKernelGGL(k_feature_factors<1>, dim3(nblk, chunks), dim3(bs), lds, s, cl, poses, feat, W, Wc, npad, f0, f1, Gt, dpart, slot);
+    hipLaunchKernelGGL(k_feature_factors<1>, dim3(nblk, chunks), dim3(bs), lds, s, cl, poses, feat, W, Wc, npad, f0, f1, Gt, dpart, slot, nt);
 }
 
 // ------------------------------------------------------------------------------------------------

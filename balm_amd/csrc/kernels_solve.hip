@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256) void k_rank_diag(const double *__restrict__ H,
 // hrow[perm[r]], written in 384-byte segments.  (Round 3's form gathered H[perm[c] * n + perm[r]] from memory, 8 bytes out of every
 // 64-byte sector: 114 us at n = 3000 = 145 MB at 1.3 TB/s; this one, measured in round 4: n = 3000 solve 0.992 -> 0.905 ms, n = 4800
 // 3.01 -> 2.68, n = 1200 0.277 -> 0.273, profiles/r04a_solve_switches.txt.)  It also zeroes the flags of the persistent kernels and
-// fills k_ldl_backsolve's exchange buffer with "not there yet" = all ones.
+// fills the exchange buffers whose payload is its own flag (k_ldl_backsolve's x, k_ldl_chain's xtile) with "not there yet" = all ones.
 // tiled: 0 = column-major [A ; rhs ; identity] (ldA = 2 nA + 48), what k_ldl_chain with identity rows, k_ldl_fused, the launch path,
 // k_ldl_apply and the covariance read; 1 = tile-major [A ; rhs] (kernels_chain.inc: ch_tile) for k_ldl_chain + k_ldl_backsolve, without
 // the tiles above the diagonal -- nothing on that path reads them (-54 us of the 114 at n = 3000 by itself).
@@ -89,13 +89,20 @@ __global__ __launch_bounds__(256) void k_rank_diag(const double *__restrict__ H,
 template <int MAXI>
 __global__ __launch_bounds__(256) void k_build_A(const double *__restrict__ H, const double *__restrict__ g, int n, int nA,
                                                  const int *__restrict__ perm, const double *__restrict__ pu, double u_arg,
-                                                 double *__restrict__ A, int *__restrict__ flags, int nflags, double *__restrict__ xs, int tiled) {
+                                                 double *__restrict__ A, int *__restrict__ flags, int nflags, double *__restrict__ xs,
+                                                 double *__restrict__ xtile, int tiled) {
   extern __shared__ __attribute__((aligned(16))) double hrow[];       // [n] row perm[c] of H
   const double u = pu ? *pu : u_arg;    // replayed hipGraphs read the damping from device memory (the launch sequence of an LM
                                         // iteration is then the same for every iteration); plain launches carry it as an argument
   const int tid = threadIdx.x, c = blockIdx.x;
   for (long t = (long)c * 256 + tid; t < nflags; t += (long)gridDim.x * 256) flags[t] = 0;
   for (long t = (long)c * 256 + tid; t < nA; t += (long)gridDim.x * 256) xs[t] = __longlong_as_double(-1ll);
+  if (tid < NB) {      // k_ldl_chain's exchange tiles [P][48][48] = nA x 48 doubles each: xtile all ones; Minv_p (in front of it) all ones in
+                       // the upper 16 x 16 sub-tiles -- what the riders will write and the row workgroups poll -- and zero below
+    xtile[(size_t)c * NB + tid] = __longlong_as_double(-1ll);
+    const int k = c % NB;                                                        // element (k, tid) of panel c / 48
+    (xtile - (size_t)nA * NB)[(size_t)c * NB + tid] = (k / 16 <= tid / 16) ? __longlong_as_double(-1ll) : 0.0;
+  }
   const int P = nA / NB, cb = c / NB, cl = c - NB * cb;
   const int ldA = 2 * nA + NB;
   const int pc = perm[c];
@@ -910,7 +917,7 @@ static void launch_build_A(balm_ctx *c) {
   const int nflags = 2 * (2 * P + 1) * P + P + 8;
   const size_t lds = (size_t)n * sizeof(double);
 #define BALM_BUILD_A(M) hipLaunchKernelGGL(k_build_A<M>, dim3(nA), dim3(256), lds, c->stream, c->d_H, c->d_g, n, nA, c->d_perm, pu, c->u_value, \
-                                           c->d_A, c->d_flags, nflags, c->d_x + nA, tiled)
+                                           c->d_A, c->d_flags, nflags, c->d_x + nA, c->d_minv + (size_t)P * NB * NB, tiled)
   if (nA <= 256 * 5) BALM_BUILD_A(5);             // n <= 1280: the bench window (n = 1200), the shipped one (1062)
   else if (nA <= 256 * 10) BALM_BUILD_A(10);
   else if (nA <= 256 * 16) BALM_BUILD_A(16);

@@ -2,6 +2,7 @@
 // Confirms the roofline peak that bench.py prices hessian_syrk against (MI355X_MICROARCH.md gives
 // 157.3 TF fp32 vector/matrix; FP64 = half that = 78.6 TF is the working assumption).
 #include <hip/hip_runtime.h>
+#include <cmath>
 #include <cstdio>
 #include <vector>
 typedef double d4 __attribute__((ext_vector_type(4)));
@@ -79,6 +80,38 @@ __global__ void k_copy(const double4 *__restrict__ in, double4 *__restrict__ out
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = in[i];
 }
 
+// HBM yardsticks (round 4: VERDICT r3 item 6 -- the double4 grid-stride copy above reaches 4.94 TB/s, the guide's float4 copy 6.29):
+// 16-byte accesses, U independent accesses per lane in flight, streaming (nontemporal) variants, and the read-only / write-only rates
+// (K2 is 36 % reads, 64 % writes).
+typedef float f4 __attribute__((ext_vector_type(4)));
+template <int U, bool NT>
+__global__ __launch_bounds__(256) void k_copy16(const f4 *__restrict__ in, f4 *__restrict__ out, size_t n) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride * U) {
+    f4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) if (i + u * stride < n) v[u] = NT ? __builtin_nontemporal_load(in + i + u * stride) : in[i + u * stride];
+#pragma unroll
+    for (int u = 0; u < U; u++) if (i + u * stride < n) { if (NT) __builtin_nontemporal_store(v[u], out + i + u * stride); else out[i + u * stride] = v[u]; }
+  }
+}
+template <int U>
+__global__ __launch_bounds__(256) void k_read16(const f4 *__restrict__ in, float *__restrict__ out, size_t n) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  f4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride * U) {
+#pragma unroll
+    for (int u = 0; u < U; u++) if (i + u * stride < n) acc += in[i + u * stride];
+  }
+  if (acc.x + acc.y + acc.z + acc.w == 12345.678f) out[0] = acc.x;
+}
+template <bool NT>
+__global__ __launch_bounds__(256) void k_fill16(f4 *__restrict__ out, size_t n) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  const f4 v = {1.f, 2.f, 3.f, 4.f};
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) { if (NT) __builtin_nontemporal_store(v, out + i); else out[i] = v; }
+}
+
 template <class F>
 float time_ms(F f, int reps = 5) {
   hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
@@ -132,6 +165,40 @@ int main() {
     double4 *a, *b; hipMalloc(&a, n * 32); hipMalloc(&b, n * 32); hipMemset(a, 1, n * 32);
     float ms = time_ms([&] { hipLaunchKernelGGL(k_copy, dim3(CU * 8), dim3(256), 0, 0, a, b, n); });
     printf("copy 2 GiB: %.3f ms  %.2f TB/s (read+write)\n", ms, 2.0 * n * 32 / ms / 1e9);
+    // 16-byte variants over the same 2 GiB: grid = blocks per CU x CUs, U accesses per lane in flight
+    const size_t n16 = n * 2;
+    const f4 *a16 = (const f4 *)a; f4 *b16 = (f4 *)b;
+    double best = 0.0;
+    auto report = [&](const char *what, float t, double bytes) {
+      const double tbs = bytes / t / 1e9;
+      printf("  %-58s %.3f ms  %.2f TB/s\n", what, t, tbs);
+      return tbs;
+    };
+    for (int bpc : {8, 16, 32}) {
+      char nm[96];
+      float t;
+      t = time_ms([&] { hipLaunchKernelGGL((k_copy16<1, false>), dim3(CU * bpc), dim3(256), 0, 0, a16, b16, n16); });
+      snprintf(nm, sizeof nm, "copy float4, %d blocks/CU, 1 in flight", bpc); best = fmax(best, report(nm, t, 2.0 * n * 32));
+      t = time_ms([&] { hipLaunchKernelGGL((k_copy16<4, false>), dim3(CU * bpc), dim3(256), 0, 0, a16, b16, n16); });
+      snprintf(nm, sizeof nm, "copy float4, %d blocks/CU, 4 in flight", bpc); best = fmax(best, report(nm, t, 2.0 * n * 32));
+      t = time_ms([&] { hipLaunchKernelGGL((k_copy16<4, true>), dim3(CU * bpc), dim3(256), 0, 0, a16, b16, n16); });
+      snprintf(nm, sizeof nm, "copy float4, %d blocks/CU, 4 in flight, nontemporal", bpc); best = fmax(best, report(nm, t, 2.0 * n * 32));
+      t = time_ms([&] { hipLaunchKernelGGL((k_copy16<8, true>), dim3(CU * bpc), dim3(256), 0, 0, a16, b16, n16); });
+      snprintf(nm, sizeof nm, "copy float4, %d blocks/CU, 8 in flight, nontemporal", bpc); best = fmax(best, report(nm, t, 2.0 * n * 32));
+    }
+    {
+      float t = time_ms([&] { hipLaunchKernelGGL((k_copy16<1, false>), dim3((unsigned)(n16 / 256)), dim3(256), 0, 0, a16, b16, n16); });
+      best = fmax(best, report("copy float4, one element per thread (8M blocks)", t, 2.0 * n * 32));
+    }
+    printf("best copy rate: %.2f TB/s (read+write)\n", best);
+    {
+      float t = time_ms([&] { hipLaunchKernelGGL((k_read16<8>), dim3(CU * 16), dim3(256), 0, 0, a16, (float *)out, n16); });
+      report("read-only float4, 16 blocks/CU, 8 in flight", t, 1.0 * n * 32);
+      t = time_ms([&] { hipLaunchKernelGGL((k_fill16<false>), dim3(CU * 16), dim3(256), 0, 0, b16, n16); });
+      report("write-only float4, 16 blocks/CU", t, 1.0 * n * 32);
+      t = time_ms([&] { hipLaunchKernelGGL((k_fill16<true>), dim3(CU * 16), dim3(256), 0, 0, b16, n16); });
+      report("write-only float4, 16 blocks/CU, nontemporal", t, 1.0 * n * 32);
+    }
     hipFree(a); hipFree(b);
   }
   hipFree(out);
