@@ -100,6 +100,7 @@ def cpu_baseline(sc, ctx, target_seconds=20.0):
                            (bavoxel.hpp:1027) -- the form BASELINE's real-world driver runs
       "reference_virtual"  oracle/_ref: the reference's benchmark_virtual.cpp, BALM2::left_evaluate_acc2 on ONE thread
                            (benchmark_virtual.cpp:413) -- the form BASELINE configs[0..3] name
+      "reference_march_v3" "reference" rebuilt with -O3 -march=x86-64-v3 (the optional extra column of SURVEY 8d)
       "port"               oracle/balm_oracle.hpp, the dependency-free restatement, 4 threads
       "port_all_cores"     the same on every host core
     The reference's sources are compiled against oracle/compat's STAND-IN Eigen (plain loops, no expression
@@ -151,6 +152,19 @@ def cpu_baseline(sc, ctx, target_seconds=20.0):
                                            "(bavoxel.hpp compiled against oracle/compat's stand-in Eigen)")
     except Exception as e:
         cands["reference_error"] = repr(e)
+    try:        # SURVEY 8d's optional extra column: the same sources with the host's vector ISA on (the reference's CMakeLists.txt only says -O3)
+        from oracle import ref
+        if ref.v3_available():
+            te, tr = ref.time_sample_v3(sc.clusters, sc.coeffs, sc.poses_init, min(64, F))
+            fr = min(sample_size((te + tr) / min(64, F), 0.5 * share), 6000)
+            te, tr = ref.time_sample_v3(sc.clusters, sc.coeffs, sc.poses_init, fr)
+            ts = ref.time_solve_v3(H, g, 0.1)
+            cands["reference_march_v3"] = dict(value=1.0 / ((te + tr) * (F / fr) + ts), f_sample=fr, threads=4, seconds_eval_sample=te,
+                                               seconds_resid_sample=tr, seconds_solve=ts,
+                                               what="the reference's BALM2::divide_thread_left + evaluate_only_residual, built with -O3 "
+                                                    "-march=x86-64-v3 (AVX2 + FMA; not the reference's own flags)")
+    except Exception as e:
+        cands["reference_march_v3_error"] = repr(e)
     try:
         from oracle import ref, ref_virtual
         if ref_virtual.available():
@@ -170,7 +184,7 @@ def cpu_baseline(sc, ctx, target_seconds=20.0):
                                                    "single thread as :413 (compiled against oracle/compat's stand-in Eigen)")
     except Exception as e:
         cands["reference_virtual_error"] = repr(e)
-    eligible = [k for k in ("port", "reference", "reference_virtual") if k in cands]
+    eligible = [k for k in ("port", "reference", "reference_march_v3", "reference_virtual") if k in cands]
     kind_key = max(eligible, key=lambda k: cands[k]["value"])
     best = cands[kind_key]
     return {

@@ -105,6 +105,37 @@ def time_sample(clusters, coeffs, poses, f_sample):
     return float(out[0]), float(out[1])
 
 
+SO_V3 = os.path.join(_HERE, "_ref", "libbalm_ref_v3.so")      # the same sources built with -march=x86-64-v3 (ref_build.sh)
+_LIB_V3 = None
+
+
+def v3_available():
+    """the AVX2/FMA build exists and this host can run it"""
+    if not os.path.exists(SO_V3):
+        return False
+    try:
+        flags = open("/proc/cpuinfo").read().split("flags", 1)[1].split("\n", 1)[0].split()
+    except Exception:
+        return False
+    return all(f in flags for f in ("avx2", "fma", "bmi2", "movbe", "f16c"))
+
+
+def time_sample_v3(clusters, coeffs, poses, f_sample):
+    global _LIB_V3
+    if _LIB_V3 is None:
+        _LIB_V3 = C.CDLL(SO_V3, mode=os.RTLD_LOCAL)
+        _LIB_V3.ref_time_solve.restype = C.c_double
+    clusters, coeffs, poses = _c(clusters), _c(coeffs), _c(poses)
+    out = np.zeros(2)
+    _LIB_V3.ref_time_sample(clusters.shape[1], f_sample, _p(clusters), _p(coeffs), _p(poses), _p(out))
+    return float(out[0]), float(out[1])
+
+
+def time_solve_v3(H, g, u):
+    Hc = _c(np.asarray(H).T); g = _c(g)
+    return _LIB_V3.ref_time_solve(g.shape[0], _p(Hc), _p(g), C.c_double(u))
+
+
 def time_solve(H, g, u):
     Hc = _c(np.asarray(H).T); g = _c(g)
     return lib().ref_time_solve(g.shape[0], _p(Hc), _p(g), C.c_double(u))

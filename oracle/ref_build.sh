@@ -17,6 +17,16 @@ if ! { [ "$OUT" -nt "$HERE/ref_driver.cpp" ] && [ "$OUT" -nt "$HERE/compat/Eigen
       -o "$OUT" "$HERE/ref_driver.cpp"
   echo "ref_build: built $OUT"
 fi
+# the same translation unit with the host's vector ISA switched on (SURVEY 8d's optional extra column of the CPU baseline: the reference's
+# CMakeLists.txt:8-9 only says -O3).  -march=x86-64-v3 (AVX2 + FMA + BMI2), not -march=native: the library is built in one container and
+# timed on another host, and v3 is what every x86 server of the last decade runs; bench.py checks /proc/cpuinfo before loading it.
+OUT="$HERE/_ref/libbalm_ref_v3.so"
+if ! { [ "$OUT" -nt "$HERE/ref_driver.cpp" ] && [ "$OUT" -nt "$HERE/compat/Eigen/Core" ] && [ -z "$BALM_FORCE_BUILD" ]; }; then
+  g++ -std=c++14 -O3 -march=x86-64-v3 -fPIC -pthread -shared -w -Wl,-Bsymbolic \
+      -I"$HERE/compat" -I"$REF/include" -I"$REF/src/benchmark" \
+      -o "$OUT" "$HERE/ref_driver.cpp"
+  echo "ref_build: built $OUT"
+fi
 # the consistency / covariance sources (src/simulation) re-declare the same class names: separate object,
 # symbols bound locally
 OUT="$HERE/_ref/libbalm_ref_sim.so"
