@@ -13,6 +13,7 @@ LIB_PATH = os.environ.get("BALM_HIP_LIB") or os.path.join(_HERE, "lib", "libbalm
 
 FORM_LEFT, FORM_RIGHT = 0, 1
 OK, ERR_ARG, ERR_HIP, ERR_STATE, ERR_TOO_FEW_PLANES, ERR_NUMERIC = range(6)
+ABI_VERSION = 4            # include/balm_hip.h: BALM_ABI_VERSION
 FLAG_TIMING = 1
 FLAG_LOOPBACK_SHARDS = 2
 T_MOMENTS, T_FACTORS, T_SYRK, T_ASSEMBLE, T_SOLVE, T_UPDATE, T_BUILD, T_VOXEL, T_COV, T_COMM, T_COUNT = range(11)
@@ -23,7 +24,7 @@ EXPORTS = ["balm_create", "balm_create_multi", "balm_destroy", "balm_set_feature
            "balm_solve_damped", "balm_damping_iter", "balm_build_clusters", "balm_voxel_defaults", "balm_associate", "balm_get_features", "balm_get_association", "balm_pose_covariance",
            "balm_window_open", "balm_window_add_scan", "balm_window_recut", "balm_window_get_points", "balm_window_features", "balm_window_marginalize", "balm_window_info", "balm_window_close",
            "balm_set_allreduce", "balm_comm_unique_id", "balm_comm_init_rank", "balm_comm_info",
-           "balm_get_timing", "balm_get_solve_trace", "balm_chain_macro_plan", "balm_reset_timing", "balm_work_model", "balm_last_error", "balm_version"]
+           "balm_get_timing", "balm_get_solve_trace", "balm_chain_macro_plan", "balm_reset_timing", "balm_work_model", "balm_last_error", "balm_version", "balm_abi_version"]
 
 
 class IterLog(C.Structure):
@@ -105,6 +106,9 @@ def lib():
         L.balm_last_error.restype = C.c_char_p
         L.balm_last_error.argtypes = [C.c_void_p]
         L.balm_version.restype = C.c_char_p
+        if L.balm_abi_version() != ABI_VERSION:
+            raise ImportError("libbalm_hip.so has ABI revision %d, this binding was written for %d: rebuild (python -m balm_amd.build)"
+                              % (L.balm_abi_version(), ABI_VERSION))
         _LIB = L
     return _LIB
 

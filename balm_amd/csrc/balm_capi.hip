@@ -375,7 +375,8 @@ int feature_bookkeeping(balm_ctx *ctx, int F, const unsigned char *obs, const do
 
 extern "C" {
 
-const char *balm_version(void) { return "balm_hip 0.2.0 (gfx950)"; }
+const char *balm_version(void) { return "balm_hip 0.4.0 (gfx950)"; }
+int balm_abi_version(void) { return BALM_ABI_VERSION; }
 
 const char *balm_last_error(balm_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 
@@ -786,7 +787,7 @@ static int one_associate(balm_ctx *ctx, const balm_voxel_opts *opts, const float
   HIP_TRY(hipSetDevice(ctx->device));
   *F_out = 0;
   ctx->F = 0;
-  ctx->assoc_clusters.clear(); ctx->assoc_coeffs.clear(); ctx->assoc_layer.clear(); ctx->assoc_fix.clear();
+  ctx->assoc_clusters.clear(); ctx->assoc_coeffs.clear(); ctx->assoc_layer.clear(); ctx->assoc_fix.clear(); ctx->assoc_cl_on_device = false;
   ctx->assoc_point_feat.clear();
   float *d_xyz = nullptr; int *d_f = nullptr;
   double *d_out = nullptr, *d_coe = nullptr, *d_fix = nullptr, *d_pos = nullptr; int *d_lay = nullptr, *d_pf = nullptr;
@@ -899,7 +900,7 @@ static int one_window_features(balm_ctx *ctx, int *F_out) {
   HIP_TRY(hipSetDevice(ctx->device));
   *F_out = 0;
   ctx->F = 0;
-  ctx->assoc_clusters.clear(); ctx->assoc_coeffs.clear(); ctx->assoc_layer.clear(); ctx->assoc_fix.clear(); ctx->assoc_point_feat.clear();
+  ctx->assoc_clusters.clear(); ctx->assoc_coeffs.clear(); ctx->assoc_layer.clear(); ctx->assoc_fix.clear(); ctx->assoc_point_feat.clear(); ctx->assoc_cl_on_device = false;    // (with the vectors: a failed or empty result must not leave "the table is on the device" behind)
   int F = 0, *d_lay = nullptr;
   double *d_out = nullptr, *d_coe = nullptr, *d_fix = nullptr;
   int rc;

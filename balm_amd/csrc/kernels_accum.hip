@@ -318,18 +318,14 @@ __device__ __forceinline__ void store6_nt(double *dst, const double x[6]) {
 // the lane's accumulators in LDS (sacc[k * Wc + il]).  Shared by k_feature_factors and the fused k_moments_factors.
 struct FeatRec { double NN, iNN, vbar[3], u0[3], u1[3], u2[3], c0, c1, c2, coe; };
 
+// (the pose as twelve values R[9] column-major, p[3]: from the LDS table, or -- k_feature_factors with one pose per lane -- from registers)
 template <int FORM>
-__device__ __forceinline__ void obs_factors(const FeatRec &fr, const double P[6], const double v[3], const double N,
-                                            const double *__restrict__ sp, double *__restrict__ sacc, const int Wc, const int il,
-                                            double col0[6], double col1[6], double col2[6]) {
+__device__ __forceinline__ void obs_factors_rp(const FeatRec &fr, const double P[6], const double v[3], const double N,
+                                               const double R[9], const double p[3], double *__restrict__ sacc, const int Wc, const int il,
+                                               double col0[6], double col1[6], double col2[6]) {
   const double NN = fr.NN, iNN = fr.iNN, c0 = fr.c0, c1 = fr.c1, c2 = fr.c2, coe = fr.coe;
   const double *vbar = fr.vbar, *u0 = fr.u0, *u1 = fr.u1, *u2 = fr.u2;
   if ((int)N > 0) {
-    double R[9], p[3];
-#pragma unroll
-    for (int c = 0; c < 9; c++) R[c] = sp[c * Wc + il];
-#pragma unroll
-    for (int c = 0; c < 3; c++) p[c] = sp[(9 + c) * Wc + il];
 
     if (FORM == 0) {
       // ---- LEFT form, bavoxel.hpp:365-402 -------------------------------------------------
@@ -506,6 +502,18 @@ __device__ __forceinline__ void obs_factors(const FeatRec &fr, const double P[6]
 }
 
 template <int FORM>
+__device__ __forceinline__ void obs_factors(const FeatRec &fr, const double P[6], const double v[3], const double N,
+                                            const double *__restrict__ sp, double *__restrict__ sacc, const int Wc, const int il,
+                                            double col0[6], double col1[6], double col2[6]) {
+  double R[9], p[3];
+#pragma unroll
+  for (int c = 0; c < 9; c++) R[c] = sp[c * Wc + il];
+#pragma unroll
+  for (int c = 0; c < 3; c++) p[c] = sp[(9 + c) * Wc + il];
+  obs_factors_rp<FORM>(fr, P, v, N, R, p, sacc, Wc, il, col0, col1, col2);
+}
+
+template <int FORM, bool PREG>
 __global__ __launch_bounds__(256) void k_feature_factors(const double *__restrict__ cl,
                                                          const double *__restrict__ poses,
                                                          const double *__restrict__ feat, int W, int Wc, int npad, int f0,
@@ -515,21 +523,33 @@ __global__ __launch_bounds__(256) void k_feature_factors(const double *__restric
   extern __shared__ __attribute__((aligned(16))) double sm[];
   // blockIdx.y = chunk of Wc poses (one chunk = the whole window up to MAX_W_LDS poses)
   const int p0 = blockIdx.y * Wc, wc = min(Wc, W - p0);
-  double *sp = sm;                 // [12][Wc] poses of the chunk
-  double *sacc = sm + 12 * Wc;     // [DACC][Wc]
-  // the pose table, ten loads per lane in flight at a time (rolled, this copy was one memory round trip per iteration -- ~10 dependent
-  // trips at W = 200 before a workgroup's first feature: tools/find_rolled_copies.py)
-  for (int t0 = 0; t0 < 12 * wc; t0 += 10 * (int)blockDim.x) {
-    double pv[10];
+  // PREG (round 4; one chunk, W <= blockDim: a lane owns ONE pose for the workgroup's whole life): the pose sits in twelve registers
+  // instead of a [12][Wc] table in LDS -- 43 instead of 62 KB per workgroup at W = 200, i.e. THREE workgroups per CU instead of two
+  // behind a kernel whose loads and stores are all latency (profiles/r04d_factors_ab.txt).
+  double *sp = sm;                                  // [12][Wc] poses of the chunk (not with PREG)
+  double *sacc = PREG ? sm : sm + 12 * Wc;          // [DACC][Wc]
+  double Rreg[9], preg[3];
+  if (PREG) {
+    const double *q = poses + 12 * (p0 + (threadIdx.x < (unsigned)wc ? (int)threadIdx.x : 0));
 #pragma unroll
-    for (int j = 0; j < 10; j++) {
-      const int t = t0 + j * (int)blockDim.x + (int)threadIdx.x;
-      pv[j] = t < 12 * wc ? poses[12 * p0 + t] : 0.0;
-    }
+    for (int c = 0; c < 9; c++) Rreg[c] = q[c];
 #pragma unroll
-    for (int j = 0; j < 10; j++) {
-      const int t = t0 + j * (int)blockDim.x + (int)threadIdx.x;
-      if (t < 12 * wc) { const int il = t / 12, c = t - 12 * il; sp[c * Wc + il] = pv[j]; }
+    for (int c = 0; c < 3; c++) preg[c] = q[9 + c];
+  } else {
+    // the pose table, ten loads per lane in flight at a time (rolled, this copy was one memory round trip per iteration -- ~10
+    // dependent trips at W = 200 before a workgroup's first feature: tools/find_rolled_copies.py)
+    for (int t0 = 0; t0 < 12 * wc; t0 += 10 * (int)blockDim.x) {
+      double pv[10];
+#pragma unroll
+      for (int j = 0; j < 10; j++) {
+        const int t = t0 + j * (int)blockDim.x + (int)threadIdx.x;
+        pv[j] = t < 12 * wc ? poses[12 * p0 + t] : 0.0;
+      }
+#pragma unroll
+      for (int j = 0; j < 10; j++) {
+        const int t = t0 + j * (int)blockDim.x + (int)threadIdx.x;
+        if (t < 12 * wc) { const int il = t / 12, c = t - 12 * il; sp[c * Wc + il] = pv[j]; }
+      }
     }
   }
   for (int t = threadIdx.x; t < DACC * Wc; t += blockDim.x) sacc[t] = 0.0;
@@ -571,7 +591,8 @@ __global__ __launch_bounds__(256) void k_feature_factors(const double *__restric
       }
       const double N = il == (int)threadIdx.x ? nxt[9] : ca[(size_t)9 * W + i];
       if (il == (int)threadIdx.x && a + (int)gridDim.x < f1) fetch(a + gridDim.x, i_first);
-      obs_factors<FORM>(fr, P, v, N, sp, sacc, Wc, il, col0, col1, col2);
+      if (PREG) obs_factors_rp<FORM>(fr, P, v, N, Rreg, preg, sacc, Wc, il, col0, col1, col2);
+      else obs_factors<FORM>(fr, P, v, N, sp, sacc, Wc, il, col0, col1, col2);
       if (nt) {
         store6_nt(g0 + 6 * i, col0);
         store6_nt(g0 + (size_t)npad + 6 * i, col1);
@@ -738,9 +759,19 @@ __global__ __launch_bounds__(320, 3) void k_moments_factors(const double *__rest
 // poses per workgroup of the factor kernel: the whole window while its accumulators fit in LDS, else chunks
 int factors_chunk(int W) { return W <= MAX_W_LDS ? W : 256; }
 
+// one pose per lane for the workgroup's whole life: the pose lives in registers, not in LDS (k_feature_factors<.., PREG>)
+static bool factors_pose_in_regs(int W) {
+  static const char *e = getenv("BALM_FACTORS_PREG");      // A/B (round 4): 0 = the LDS pose table at every window
+  return W <= 256 && !(e && e[0] == '0');
+}
+
+static size_t factors_lds(int W, int form) {
+  const int dacc = form == 0 ? DACC_LEFT : DACC_RIGHT;
+  return (size_t)((factors_pose_in_regs(W) ? 0 : 12) + dacc) * factors_chunk(W) * sizeof(double);
+}
+
 int factors_grid(int W, int nfeat, int form) {
-  int dacc = form == 0 ? DACC_LEFT : DACC_RIGHT;
-  size_t lds = (size_t)(12 + dacc) * factors_chunk(W) * sizeof(double);
+  size_t lds = factors_lds(W, form);
   int per_cu = (int)(160 * 1024 / lds);
   if (per_cu < 1) per_cu = 1;
   if (per_cu > 4) per_cu = 4;
@@ -755,8 +786,10 @@ int factors_grid(int W, int nfeat, int form) {
 // The attribute belongs to the CURRENT device: balm_create calls this once per context, after hipSetDevice.
 hipError_t prepare_device_accum() {
   hipError_t e = hipFuncSetAttribute((const void *)k_world_moments, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_feature_factors<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_feature_factors<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_feature_factors<0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_feature_factors<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_feature_factors<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_feature_factors<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_moments_factors<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_moments_factors<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   return e;
@@ -777,15 +810,15 @@ int launch_moments_factors(hipStream_t s, int form, const double *cl, const doub
 
 void launch_factors(hipStream_t s, int form, const double *cl, const double *poses, const double *feat, int W,
                     int npad, int f0, int f1, double *Gt, double *dpart, int nblk, const int *slot) {
-  int dacc = form == 0 ? DACC_LEFT : DACC_RIGHT;
   const int Wc = factors_chunk(W), chunks = (W + Wc - 1) / Wc;
-  size_t lds = (size_t)(12 + dacc) * Wc * sizeof(double);
+  const size_t lds = factors_lds(W, form);
   int bs = W <= 64 ? 64 : (W <= 128 ? 128 : 256);
   static const int nt = getenv("BALM_GT_NT") ? atoi(getenv("BALM_GT_NT")) : 0;      // A/B (round 4): streaming stores for Gt
-  if (form == 0)
-    hipLaunchKernelGGL(k_feature_factors<0>, dim3(nblk, chunks), dim3(bs), lds, s, cl, poses, feat, W, Wc, npad, f0, f1, Gt, dpart, slot, nt);
-  else
-    hipLaunchKernelGGL(k_feature_factors<1>, dim3(nblk, chunks), dim3(bs), lds, s, cl, poses, feat, W, Wc, npad, f0, f1, Gt, dpart, slot, nt);
+  const bool preg = factors_pose_in_regs(W);
+#define BALM_FACTORS(F, R) hipLaunchKernelGGL((k_feature_factors<F, R>), dim3(nblk, chunks), dim3(bs), lds, s, cl, poses, feat, W, Wc, npad, f0, f1, Gt, dpart, slot, nt)
+  if (form == 0) { if (preg) BALM_FACTORS(0, true); else BALM_FACTORS(0, false); }
+  else { if (preg) BALM_FACTORS(1, true); else BALM_FACTORS(1, false); }
+#undef BALM_FACTORS
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -281,6 +281,13 @@ int balm_work_model(balm_ctx *ctx, double *out4);
 const char *balm_last_error(balm_ctx *ctx);
 const char *balm_version(void);
 
+/* ABI revision of this header.  It changes whenever a struct above grows, an enum gains a member that sizes a caller's array
+ * (BALM_T_COUNT) or an entry point changes its meaning: 3 = round 3 (balm_voxel_opts gained fix_point_limit / defer_recut,
+ * BALM_T_COUNT went from 9 to 10), 4 = this header.  A caller built against another revision must not call anything else:
+ *     if (balm_abi_version() != BALM_ABI_VERSION) { refuse }                                                              */
+#define BALM_ABI_VERSION 4
+int balm_abi_version(void);
+
 #ifdef __cplusplus
 }
 #endif
