@@ -11,6 +11,9 @@
 //   K3  hessian_syrk    25 MFMA sub-tiles (an 80x80 tile, or 25 upper sub-tiles of the diagonal blocks) per
 //                       wavefront on v_mfma_f64_16x16x4_f64, split-K
 //   K4  reduce / assemble
+#include <algorithm>
+#include <vector>
+
 #include "balm_internal.h"
 
 namespace balm {
@@ -307,25 +310,23 @@ __device__ __forceinline__ void store6(double *dst, const double x[6]) {
   d2 t0 = {x[0], x[1]}, t1 = {x[2], x[3]}, t2 = {x[4], x[5]};
   q[0] = t0; q[1] = t1; q[2] = t2;
 }
-// the same as a streaming store: Gt (1.44 GB at config 2) is read next by the SYRK, long after it has left every L2
-__device__ __forceinline__ void store6_nt(double *dst, const double x[6]) {
-  d2 *q = reinterpret_cast<d2 *>(dst);
-  d2 t0 = {x[0], x[1]}, t1 = {x[2], x[3]}, t2 = {x[4], x[5]};
-  __builtin_nontemporal_store(t0, q); __builtin_nontemporal_store(t1, q + 1); __builtin_nontemporal_store(t2, q + 2);
-}
 
 // One observation (feature a, pose i) of K2: the three Gt columns of the pose, and its gradient / block-diagonal terms added to
 // the lane's accumulators in LDS (sacc[k * Wc + il]).  Shared by k_feature_factors and the fused k_moments_factors.
 struct FeatRec { double NN, iNN, vbar[3], u0[3], u1[3], u2[3], c0, c1, c2, coe; };
 
-// (the pose as twelve values R[9] column-major, p[3]: from the LDS table, or -- k_feature_factors with one pose per lane -- from registers)
 template <int FORM>
-__device__ __forceinline__ void obs_factors_rp(const FeatRec &fr, const double P[6], const double v[3], const double N,
-                                               const double R[9], const double p[3], double *__restrict__ sacc, const int Wc, const int il,
-                                               double col0[6], double col1[6], double col2[6]) {
+__device__ __forceinline__ void obs_factors(const FeatRec &fr, const double P[6], const double v[3], const double N,
+                                            const double *__restrict__ sp, double *__restrict__ sacc, const int Wc, const int il,
+                                            double col0[6], double col1[6], double col2[6]) {
   const double NN = fr.NN, iNN = fr.iNN, c0 = fr.c0, c1 = fr.c1, c2 = fr.c2, coe = fr.coe;
   const double *vbar = fr.vbar, *u0 = fr.u0, *u1 = fr.u1, *u2 = fr.u2;
   if ((int)N > 0) {
+    double R[9], p[3];
+#pragma unroll
+    for (int c = 0; c < 9; c++) R[c] = sp[c * Wc + il];
+#pragma unroll
+    for (int c = 0; c < 3; c++) p[c] = sp[(9 + c) * Wc + il];
 
     if (FORM == 0) {
       // ---- LEFT form, bavoxel.hpp:365-402 -------------------------------------------------
@@ -502,54 +503,33 @@ __device__ __forceinline__ void obs_factors_rp(const FeatRec &fr, const double P
 }
 
 template <int FORM>
-__device__ __forceinline__ void obs_factors(const FeatRec &fr, const double P[6], const double v[3], const double N,
-                                            const double *__restrict__ sp, double *__restrict__ sacc, const int Wc, const int il,
-                                            double col0[6], double col1[6], double col2[6]) {
-  double R[9], p[3];
-#pragma unroll
-  for (int c = 0; c < 9; c++) R[c] = sp[c * Wc + il];
-#pragma unroll
-  for (int c = 0; c < 3; c++) p[c] = sp[(9 + c) * Wc + il];
-  obs_factors_rp<FORM>(fr, P, v, N, R, p, sacc, Wc, il, col0, col1, col2);
-}
-
-template <int FORM, bool PREG>
 __global__ __launch_bounds__(256) void k_feature_factors(const double *__restrict__ cl,
                                                          const double *__restrict__ poses,
                                                          const double *__restrict__ feat, int W, int Wc, int npad, int f0,
                                                          int f1, double *__restrict__ Gt,
-                                                         double *__restrict__ dpart, const int *__restrict__ slot, int nt) {
+                                                         double *__restrict__ dpart, const int *__restrict__ slot,
+                                                         const int *__restrict__ order) {
+  // order != NULL: [f0, f1) is a range of POSITIONS in `order`, a permutation of the features (the slabs of the evaluation that
+  // overlaps this kernel with the SYRK: evaluate_device); the Gt column of a feature stays 3 a (or its block-sparse slot)
   constexpr int DACC = FORM == 0 ? DACC_LEFT : DACC_RIGHT;
   extern __shared__ __attribute__((aligned(16))) double sm[];
   // blockIdx.y = chunk of Wc poses (one chunk = the whole window up to MAX_W_LDS poses)
   const int p0 = blockIdx.y * Wc, wc = min(Wc, W - p0);
-  // PREG (round 4; one chunk, W <= blockDim: a lane owns ONE pose for the workgroup's whole life): the pose sits in twelve registers
-  // instead of a [12][Wc] table in LDS -- 43 instead of 62 KB per workgroup at W = 200, i.e. THREE workgroups per CU instead of two
-  // behind a kernel whose loads and stores are all latency (profiles/r04d_factors_ab.txt).
-  double *sp = sm;                                  // [12][Wc] poses of the chunk (not with PREG)
-  double *sacc = PREG ? sm : sm + 12 * Wc;          // [DACC][Wc]
-  double Rreg[9], preg[3];
-  if (PREG) {
-    const double *q = poses + 12 * (p0 + (threadIdx.x < (unsigned)wc ? (int)threadIdx.x : 0));
+  double *sp = sm;                 // [12][Wc] poses of the chunk
+  double *sacc = sm + 12 * Wc;     // [DACC][Wc]
+  // the pose table, ten loads per lane in flight at a time (rolled, this copy was one memory round trip per iteration -- ~10 dependent
+  // trips at W = 200 before a workgroup's first feature: tools/find_rolled_copies.py)
+  for (int t0 = 0; t0 < 12 * wc; t0 += 10 * (int)blockDim.x) {
+    double pv[10];
 #pragma unroll
-    for (int c = 0; c < 9; c++) Rreg[c] = q[c];
+    for (int j = 0; j < 10; j++) {
+      const int t = t0 + j * (int)blockDim.x + (int)threadIdx.x;
+      pv[j] = t < 12 * wc ? poses[12 * p0 + t] : 0.0;
+    }
 #pragma unroll
-    for (int c = 0; c < 3; c++) preg[c] = q[9 + c];
-  } else {
-    // the pose table, ten loads per lane in flight at a time (rolled, this copy was one memory round trip per iteration -- ~10
-    // dependent trips at W = 200 before a workgroup's first feature: tools/find_rolled_copies.py)
-    for (int t0 = 0; t0 < 12 * wc; t0 += 10 * (int)blockDim.x) {
-      double pv[10];
-#pragma unroll
-      for (int j = 0; j < 10; j++) {
-        const int t = t0 + j * (int)blockDim.x + (int)threadIdx.x;
-        pv[j] = t < 12 * wc ? poses[12 * p0 + t] : 0.0;
-      }
-#pragma unroll
-      for (int j = 0; j < 10; j++) {
-        const int t = t0 + j * (int)blockDim.x + (int)threadIdx.x;
-        if (t < 12 * wc) { const int il = t / 12, c = t - 12 * il; sp[c * Wc + il] = pv[j]; }
-      }
+    for (int j = 0; j < 10; j++) {
+      const int t = t0 + j * (int)blockDim.x + (int)threadIdx.x;
+      if (t < 12 * wc) { const int il = t / 12, c = t - 12 * il; sp[c * Wc + il] = pv[j]; }
     }
   }
   for (int t = threadIdx.x; t < DACC * Wc; t += blockDim.x) sacc[t] = 0.0;
@@ -565,14 +545,15 @@ __global__ __launch_bounds__(256) void k_feature_factors(const double *__restric
     for (int c = 0; c < 10; c++) nxt[c] = ca[(size_t)c * W];
   };
   const int i_first = p0 + (threadIdx.x < (unsigned)wc ? (int)threadIdx.x : 0);
-  if (f0 + (int)blockIdx.x < f1) fetch(f0 + blockIdx.x, i_first);
+  if (f0 + (int)blockIdx.x < f1) fetch(order ? order[f0 + blockIdx.x] : f0 + (int)blockIdx.x, i_first);
 
-  for (int a = f0 + blockIdx.x; a < f1; a += gridDim.x) {
+  for (int ia = f0 + blockIdx.x; ia < f1; ia += gridDim.x) {
+    const int a = order ? order[ia] : ia;
     const double *f = feat + (size_t)a * FEAT_STRIDE;
     const FeatRec fr = {f[FT_NN], 1.0 / f[FT_NN], {f[FT_VBAR], f[FT_VBAR + 1], f[FT_VBAR + 2]}, {f[FT_U0], f[FT_U0 + 1], f[FT_U0 + 2]},
                         {f[FT_U1], f[FT_U1 + 1], f[FT_U1 + 2]}, {f[FT_U2], f[FT_U2 + 1], f[FT_U2 + 2]}, f[FT_C0], f[FT_C1], f[FT_C2], f[FT_COE]};
     const double *ca = cl + (size_t)a * 10 * W;
-    double *g0 = Gt + (size_t)(3 * (slot ? slot[a] : a - f0)) * npad;      // slot: the block-sparse plan's column order
+    double *g0 = Gt + (size_t)(3 * (slot ? slot[a] : (order ? a : a - f0))) * npad;      // slot: the block-sparse plan's column order
 
     for (int il = threadIdx.x; il < wc; il += blockDim.x) {
       const int i = p0 + il;
@@ -590,18 +571,13 @@ __global__ __launch_bounds__(256) void k_feature_factors(const double *__restric
         for (int c = 0; c < 3; c++) v[c] = ca[(size_t)(6 + c) * W + i];
       }
       const double N = il == (int)threadIdx.x ? nxt[9] : ca[(size_t)9 * W + i];
-      if (il == (int)threadIdx.x && a + (int)gridDim.x < f1) fetch(a + gridDim.x, i_first);
-      if (PREG) obs_factors_rp<FORM>(fr, P, v, N, Rreg, preg, sacc, Wc, il, col0, col1, col2);
-      else obs_factors<FORM>(fr, P, v, N, sp, sacc, Wc, il, col0, col1, col2);
-      if (nt) {
-        store6_nt(g0 + 6 * i, col0);
-        store6_nt(g0 + (size_t)npad + 6 * i, col1);
-        store6_nt(g0 + (size_t)2 * npad + 6 * i, col2);
-      } else {
-        store6(g0 + 6 * i, col0);
-        store6(g0 + (size_t)npad + 6 * i, col1);
-        store6(g0 + (size_t)2 * npad + 6 * i, col2);
-      }
+      if (il == (int)threadIdx.x && ia + (int)gridDim.x < f1) fetch(order ? order[ia + gridDim.x] : ia + (int)gridDim.x, i_first);
+      obs_factors<FORM>(fr, P, v, N, sp, sacc, Wc, il, col0, col1, col2);
+      // (Measured and rejected, round 4, profiles/r04d_factors_ab.txt: streaming (nontemporal) stores -- 0.555 vs 0.553 ms; the lane's
+      // pose in twelve registers instead of the LDS table, i.e. 43 KB per workgroup and THREE workgroups per CU -- 0.565 vs 0.554.)
+      store6(g0 + 6 * i, col0);
+      store6(g0 + (size_t)npad + 6 * i, col1);
+      store6(g0 + (size_t)2 * npad + 6 * i, col2);
     }
   }
   __syncthreads();
@@ -759,15 +735,9 @@ __global__ __launch_bounds__(320, 3) void k_moments_factors(const double *__rest
 // poses per workgroup of the factor kernel: the whole window while its accumulators fit in LDS, else chunks
 int factors_chunk(int W) { return W <= MAX_W_LDS ? W : 256; }
 
-// one pose per lane for the workgroup's whole life: the pose lives in registers, not in LDS (k_feature_factors<.., PREG>)
-static bool factors_pose_in_regs(int W) {
-  static const char *e = getenv("BALM_FACTORS_PREG");      // A/B (round 4): 0 = the LDS pose table at every window
-  return W <= 256 && !(e && e[0] == '0');
-}
-
 static size_t factors_lds(int W, int form) {
   const int dacc = form == 0 ? DACC_LEFT : DACC_RIGHT;
-  return (size_t)((factors_pose_in_regs(W) ? 0 : 12) + dacc) * factors_chunk(W) * sizeof(double);
+  return (size_t)(12 + dacc) * factors_chunk(W) * sizeof(double);
 }
 
 int factors_grid(int W, int nfeat, int form) {
@@ -786,10 +756,8 @@ int factors_grid(int W, int nfeat, int form) {
 // The attribute belongs to the CURRENT device: balm_create calls this once per context, after hipSetDevice.
 hipError_t prepare_device_accum() {
   hipError_t e = hipFuncSetAttribute((const void *)k_world_moments, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_feature_factors<0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_feature_factors<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_feature_factors<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_feature_factors<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_feature_factors<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_feature_factors<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_moments_factors<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_moments_factors<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   return e;
@@ -808,17 +776,19 @@ int launch_moments_factors(hipStream_t s, int form, const double *cl, const doub
   return nblk;
 }
 
+// order / one_per_cu: the slabs that run BESIDE the SYRK (evaluate_device): positions [f0, f1) of a feature permutation, and a dynamic
+// LDS request above half a CU's so that at most ONE workgroup lands on a CU -- two of its wavefronts on one SIMD would leave no
+// room for the SYRK's wavefront there (328 of the 512 registers per lane) for the slab's whole life.
 void launch_factors(hipStream_t s, int form, const double *cl, const double *poses, const double *feat, int W,
-                    int npad, int f0, int f1, double *Gt, double *dpart, int nblk, const int *slot) {
+                    int npad, int f0, int f1, double *Gt, double *dpart, int nblk, const int *slot, const int *order, bool one_per_cu) {
   const int Wc = factors_chunk(W), chunks = (W + Wc - 1) / Wc;
-  const size_t lds = factors_lds(W, form);
+  size_t lds = factors_lds(W, form);
+  if (one_per_cu && lds < 81 * 1024) lds = 81 * 1024;
   int bs = W <= 64 ? 64 : (W <= 128 ? 128 : 256);
-  static const int nt = getenv("BALM_GT_NT") ? atoi(getenv("BALM_GT_NT")) : 0;      // A/B (round 4): streaming stores for Gt
-  const bool preg = factors_pose_in_regs(W);
-#define BALM_FACTORS(F, R) hipLaunchKernelGGL((k_feature_factors<F, R>), dim3(nblk, chunks), dim3(bs), lds, s, cl, poses, feat, W, Wc, npad, f0, f1, Gt, dpart, slot, nt)
-  if (form == 0) { if (preg) BALM_FACTORS(0, true); else BALM_FACTORS(0, false); }
-  else { if (preg) BALM_FACTORS(1, true); else BALM_FACTORS(1, false); }
-#undef BALM_FACTORS
+  if (form == 0)
+    hipLaunchKernelGGL(k_feature_factors<0>, dim3(nblk, chunks), dim3(bs), lds, s, cl, poses, feat, W, Wc, npad, f0, f1, Gt, dpart, slot, order);
+  else
+    hipLaunchKernelGGL(k_feature_factors<1>, dim3(nblk, chunks), dim3(bs), lds, s, cl, poses, feat, W, Wc, npad, f0, f1, Gt, dpart, slot, order);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -927,12 +897,14 @@ __device__ __forceinline__ long xcd_remap(long bid, long nblocks) {
 
 __global__ __launch_bounds__(64) void k_hessian_syrk(const double *__restrict__ Gt, int npad, int njobs,
                                                      const int *__restrict__ jobs, int nsteps, long nblocks,
-                                                     double *__restrict__ part) {
+                                                     double *__restrict__ part, long bid0) {
   // Dense plan: one wavefront per (job, k-slice).  The remap gives an XCD ALL jobs of one k-slice after the other:
   // an XCD holds 128 of these one-wave workgroups (4 per CU), i.e. the jobs of a slice run side by side and sweep
   // k in lockstep (they are all MFMA-paced, 25 MFMAs per k-step each), so each 128-byte line of Gt is pulled into
   // that XCD's L2 once and serves the ~15 jobs that need it.
-  const long bid = xcd_remap(blockIdx.x, nblocks);
+  // bid0: the launch covers the workgroups [bid0, bid0 + gridDim.x) of the plan (a multiple of 8: the XCD of a workgroup is the same
+  // as in one launch of all of them) -- the rounds of the evaluation that runs the factor kernel's slabs beside them
+  const long bid = xcd_remap((long)blockIdx.x + bid0, nblocks);
   const int tile = (int)(bid % njobs);
   const int sg = (int)(bid / njobs);
   BALM_SYRK_ZERO_ACC();
@@ -1000,9 +972,39 @@ void launch_syrk_sparse(hipStream_t s, const double *Gt, int npad, const int *jo
 }
 
 void launch_syrk(hipStream_t s, const double *Gt, int npad, int ntiles, const int *tileIJ, const SyrkPlan &p,
-                 double *part) {
-  hipLaunchKernelGGL(k_hessian_syrk, dim3((unsigned)p.nblocks), dim3(64), 0, s, Gt, npad, ntiles, tileIJ,
-                     p.nsteps, p.nblocks, part);
+                 double *part, long bid0, long count) {
+  if (count < 0) count = p.nblocks - bid0;
+  hipLaunchKernelGGL(k_hessian_syrk, dim3((unsigned)count), dim3(64), 0, s, Gt, npad, ntiles, tileIJ,
+                     p.nsteps, p.nblocks, part, bid0);
+}
+
+// The hardware runs a launch of one-wave workgroups in ROUNDS of 1024 (128 slots per XCD, all workgroups of a round alike and MFMA-paced:
+// they start and end together).  Which features must the factor kernel have finished before round rho may start?  Round rho holds the
+// hardware blocks [1024 rho, 1024 (rho + 1)), i.e. on XCD x the logical workgroups xcd_remap(8 j + x), 128 rho <= j < 128 (rho + 1): a
+// run of ~1.1 k-slices per XCD -- EIGHT stretches of Gt columns spread over the whole K range, plus the prefetch ring's overrun of
+// SYRK_NBUF - 1 k-steps behind each.  order = the features in the order in which the rounds first need them; slab[rho] = how many of
+// them rounds 0..rho need (slab[rounds - 1] = F).  Pure host code.
+int syrk_round_order(int ntiles, const SyrkPlan &p, int F, std::vector<int> &order, std::vector<int> &slab) {
+  const long nb = p.nblocks, q = nb >> 3, r = nb & 7;
+  const int rounds = (int)((nb + 1023) / 1024);
+  order.clear(); slab.assign((size_t)rounds, 0);
+  std::vector<char> seen((size_t)F, 0);
+  for (int rho = 0; rho < rounds; rho++) {
+    for (long x = 0; x < 8; x++) {
+      const long cnt = q + (x < r ? 1 : 0), j0 = 128l * rho, j1 = std::min(128l * (rho + 1), cnt);
+      if (j0 >= j1) continue;
+      const long L = x * q + std::min(x, r);
+      const long sg0 = (L + j0) / ntiles, sg1 = (L + j1 - 1) / ntiles;
+      const long c0 = sg0 * p.nsteps * 4, c1 = (sg1 + 1) * p.nsteps * 4 + (SYRK_NBUF - 1) * 4;
+      const long a0 = c0 / 3, a1 = std::min((long)F, (c1 + 2) / 3);
+      for (long a = a0; a < a1; a++)
+        if (!seen[(size_t)a]) { seen[(size_t)a] = 1; order.push_back((int)a); }
+    }
+    slab[(size_t)rho] = (int)order.size();
+  }
+  for (int a = 0; a < F; a++) if (!seen[(size_t)a]) order.push_back(a);      // (none: the slices cover every column)
+  slab[(size_t)rounds - 1] = F;
+  return rounds;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -33,7 +33,8 @@ import numpy as np  # noqa: E402
 
 FP64_PEAK_TFLOPS = 78.6     # MI355X FP64 matrix = vector peak (MI355X_MICROARCH.md: 157.3 TF fp32 / 2)
 HBM_PEAK_TBS = 8.0          # MI355X_MICROARCH.md: HBM3E ~8 TB/s
-COPY_RATE_TBS = 4.99        # what a plain copy kernel moves on the box (read + write): tools/ubench_f64.hip, profiles/r03f_ubench_f64.txt
+COPY_RATE_TBS = 6.21        # what the best plain copy kernel moves on the box (read + write; float4, one element per thread): tools/ubench_f64.hip,
+                            # profiles/r04c_ubench_f64.txt (the guide: 6.29).  Round 3 quoted 4.99 = its double4 grid-stride copy.  Write-only: 4.09 TB/s.
 F_SINGLE = 50000            # BASELINE configs[2]
 F_SHARDED_TOTAL = 200000    # BASELINE configs[3]
 GOLDEN_SHARDED = os.path.join(ROOT, "tests", "golden", "lm_big_w200_f200000.npz")       # the reference's own run of configs[3]
@@ -389,8 +390,17 @@ def main(argv=None):
         ms, cnt = timing[key]
         return ms / max(cnt, 1) * 1e-3 if cnt else None
 
-    syrk_s = avg_s("syrk")
+    syrk_s = avg_s("syrk")          # per Hessian evaluation (HIP events around the kernel's launch -- or, overlapped, its launches -- on the library's stream)
     achieved = wm["syrk_flops_algorithmic"] / syrk_s / 1e12 if syrk_s else None
+    # Overlapped evaluation: k_hessian_syrk runs as one launch PER ROUND of 1024 one-wave workgroups (the same plan, the same
+    # workgroups), with feature_factors' later slabs on a second stream beside them -- per-launch figures are the evaluation's divided by the rounds
+    overlapped = timing.get("factors_overlapped", (0.0, 0))[1] > 0
+    rounds = 1
+    if overlapped:
+        try:
+            rounds = capi.overlap_plan(W, Fg)[2]["rounds"]
+        except Exception:
+            rounds = 1
     # HBM bytes per launch: NOT measured in this run (PMC counters need rocprofv3 around the process) -- read from the
     # committed summary of separate `rocprofv3 --pmc` passes of this same command; `traffic_source` names that run
     traffic, traffic_source = None, None
@@ -405,9 +415,12 @@ def main(argv=None):
         "kernel": "k_hessian_syrk", "bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS,
         "unit": "TFLOP/s", "frac": (achieved / FP64_PEAK_TFLOPS) if achieved else None, "traffic": traffic,
         "traffic_source": traffic_source,
-        "dtype": "f64", "avg_launch_ms": syrk_s * 1e3 if syrk_s else None, "launches": timing["syrk"][1],
-        "algorithmic_flops_per_launch": wm["syrk_flops_algorithmic"],
-        "issued_flops_per_launch": wm["syrk_flops_issued"],
+        "dtype": "f64", "avg_launch_ms": syrk_s * 1e3 / rounds if syrk_s else None, "launches": timing["syrk"][1] * rounds,
+        "algorithmic_flops_per_launch": wm["syrk_flops_algorithmic"] / rounds,
+        "issued_flops_per_launch": wm["syrk_flops_issued"] / rounds,
+        "launches_per_evaluation": rounds, "ms_per_evaluation": syrk_s * 1e3 if syrk_s else None,
+        "overlapped_with": ("k_feature_factors' slabs 1..%d on a second stream (their stream time: kernel_ms_per_step.factors_overlapped, "
+                            "INSIDE the syrk time, not added to it)" % (rounds - 1)) if overlapped else None,
     }
     # the other kernel classes of the step against THEIR rooflines (algorithmic bytes/flops of SURVEY 8d; S = observations)
     S = wm["S"]
@@ -418,10 +431,16 @@ def main(argv=None):
                                 "frac": 80.0 * S / t / 1e12 / HBM_PEAK_TBS, "frac_of_copy_rate": 80.0 * S / t / 1e12 / COPY_RATE_TBS,
                                 "avg_launch_ms": t * 1e3}
     t = avg_s("factors")
-    if t:      # K2: 80 B read + 144 B written per observation
-        secondary["factors"] = {"bound": "hbm", "achieved": 224.0 * S / t / 1e12, "peak": HBM_PEAK_TBS, "unit": "TB/s",
-                                "frac": 224.0 * S / t / 1e12 / HBM_PEAK_TBS, "frac_of_copy_rate": 224.0 * S / t / 1e12 / COPY_RATE_TBS,
-                                "avg_launch_ms": t * 1e3}
+    if t:      # K2: 80 B read + 144 B written per observation (overlapped evaluation: slab 0 only -- the share of the observations it covers)
+        share = 1.0
+        if overlapped:
+            try:
+                share = float(capi.overlap_plan(W, Fg)[1][0]) / Fg
+            except Exception:
+                share = 1.0
+        secondary["factors"] = {"bound": "hbm", "achieved": 224.0 * S * share / t / 1e12, "peak": HBM_PEAK_TBS, "unit": "TB/s",
+                                "frac": 224.0 * S * share / t / 1e12 / HBM_PEAK_TBS, "frac_of_copy_rate": 224.0 * S * share / t / 1e12 / COPY_RATE_TBS,
+                                "avg_launch_ms": t * 1e3, "share_of_observations": share}
     t = avg_s("solve")
     if t:      # blocked LDL^T: n^3/3 + 2 n^2 flops; a latency chain, priced against the FP64 peak for the record
         fl = n ** 3 / 3.0 + 2.0 * n * n
