@@ -16,15 +16,15 @@ OK, ERR_ARG, ERR_HIP, ERR_STATE, ERR_TOO_FEW_PLANES, ERR_NUMERIC = range(6)
 ABI_VERSION = 4            # include/balm_hip.h: BALM_ABI_VERSION
 FLAG_TIMING = 1
 FLAG_LOOPBACK_SHARDS = 2
-T_MOMENTS, T_FACTORS, T_SYRK, T_ASSEMBLE, T_SOLVE, T_UPDATE, T_BUILD, T_VOXEL, T_COV, T_COMM, T_FACTORS_OVERLAPPED, T_COUNT = range(12)
-TIMING_NAMES = ["moments", "factors", "syrk", "assemble", "solve", "update", "build", "voxel", "cov", "comm", "factors_overlapped"]
+T_MOMENTS, T_FACTORS, T_SYRK, T_ASSEMBLE, T_SOLVE, T_UPDATE, T_BUILD, T_VOXEL, T_COV, T_COMM, T_COUNT = range(11)
+TIMING_NAMES = ["moments", "factors", "syrk", "assemble", "solve", "update", "build", "voxel", "cov", "comm"]
 
 # every symbol include/balm_hip.h declares
 EXPORTS = ["balm_create", "balm_create_multi", "balm_destroy", "balm_set_features", "balm_evaluate", "balm_only_residual",
            "balm_solve_damped", "balm_damping_iter", "balm_build_clusters", "balm_voxel_defaults", "balm_associate", "balm_get_features", "balm_get_association", "balm_pose_covariance",
            "balm_window_open", "balm_window_add_scan", "balm_window_recut", "balm_window_get_points", "balm_window_features", "balm_window_marginalize", "balm_window_info", "balm_window_close",
            "balm_set_allreduce", "balm_comm_unique_id", "balm_comm_init_rank", "balm_comm_info",
-           "balm_get_timing", "balm_get_solve_trace", "balm_chain_macro_plan", "balm_overlap_plan", "balm_reset_timing", "balm_work_model", "balm_last_error", "balm_version", "balm_abi_version"]
+           "balm_get_timing", "balm_get_solve_trace", "balm_chain_macro_plan", "balm_reset_timing", "balm_work_model", "balm_last_error", "balm_version", "balm_abi_version"]
 
 
 class IterLog(C.Structure):
@@ -101,7 +101,6 @@ def lib():
         L.balm_get_timing.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.balm_get_solve_trace.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_void_p]
         L.balm_chain_macro_plan.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_long]
-        L.balm_overlap_plan.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.balm_reset_timing.argtypes = [C.c_void_p]
         L.balm_work_model.argtypes = [C.c_void_p, C.c_void_p]
         L.balm_last_error.restype = C.c_char_p
@@ -122,15 +121,6 @@ def chain_macro_plan(panels, helpers):
         raise BalmError(rc, "balm_chain_macro_plan(%d, %d)" % (panels, helpers))
     tab = tab.reshape(helpers, 64)
     return [[(int(e) & 0xffff, int(e) >> 16) for e in row if e >= 0] for row in tab]
-
-
-def overlap_plan(win_size, F):
-    """host-only: (order[F], slab[8], dict(ntiles, SG, nsteps, nblocks, rounds)) of the evaluation that overlaps K2's slabs with K3's rounds"""
-    order = np.empty(F, np.int32); slab = np.empty(8, np.int32); plan = np.empty(5, np.int32)
-    rc = lib().balm_overlap_plan(int(win_size), int(F), order.ctypes.data_as(C.c_void_p), slab.ctypes.data_as(C.c_void_p), plan.ctypes.data_as(C.c_void_p))
-    if rc != OK:
-        raise BalmError(rc, "balm_overlap_plan(%d, %d)" % (win_size, F))
-    return order, slab, dict(zip(("ntiles", "SG", "nsteps", "nblocks", "rounds"), (int(v) for v in plan)))
 
 
 def _p(a):

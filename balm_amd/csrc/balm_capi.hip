@@ -28,15 +28,15 @@ namespace {
 
 // ---- timing ------------------------------------------------------------------------------------
 struct Span {
-  balm_ctx *c; int slot; hipStream_t st; hipEvent_t a = nullptr, b = nullptr;
-  Span(balm_ctx *ctx, int s, hipStream_t stream = nullptr) : c(ctx), slot(s), st(stream ? stream : ctx->stream) {
+  balm_ctx *c; int slot; hipEvent_t a = nullptr, b = nullptr;
+  Span(balm_ctx *ctx, int s) : c(ctx), slot(s) {
     if (!c->timer.on) return;
     a = take(); b = take();
-    hipEventRecord(a, st);
+    hipEventRecord(a, c->stream);
   }
   ~Span() {
     if (!c->timer.on) return;
-    hipEventRecord(b, st);
+    hipEventRecord(b, c->stream);
     c->timer.pending.push_back({a, b, slot});
   }
   hipEvent_t take() {
@@ -213,56 +213,6 @@ bool fuse_trial(const balm_ctx *ctx) {
   return ctx->W <= 256 && ctx->F > 0 && e && e[0] == '1';
 }
 
-// The Hessian evaluation with the factor kernel's slabs BESIDE the SYRK's rounds (round 4).  K2 is HBM-bound
-// (0.5 ms at config 2) and K3 MFMA-bound (3.1 ms, one wavefront per SIMD holding 328 of the 512 registers per lane); run one
-// after the other, each leaves the other's resource idle.  The SYRK cannot simply be cut into feature slabs -- its 3 990 one-wave
-// workgroups run as four ROUNDS of the 1 024 wave slots, and a slab's launch would end in a partial round -- but it can be cut AT
-// its rounds: round rho is the hardware blocks [1024 rho, 1024 (rho + 1)) of the same plan (k_hessian_syrk's bid0), and all
-// workgroups of a round start and end together anyway.  Round rho needs ~1.1 k-slices per XCD, eight stretches of Gt spread over
-// the whole K range (syrk_round_order): the factor kernel takes the features in THAT order (`order`), slab 0 (what round 0 needs)
-// on the main stream at full occupancy, slab rho >= 1 on a second stream, one workgroup per CU, while round rho - 1 runs; the
-// rounds wait for their slab's event.  Same k-slices, same partial tiles, same reduction order as the single launch: H is bit for
-// bit what it was; the per-pose gradient / block-diagonal partial sums are grouped by the slabs' workgroups (a fixed order too).
-// Only for the dense plan over the whole feature range, at least two rounds, one pose chunk; BALM_OVERLAP=0 switches it off (A/B).
-static int overlap_rounds(balm_ctx *ctx, int form, int nf, const SyrkPlan &plan, bool full_dense) {
-  static const char *e = getenv("BALM_OVERLAP");
-  static const bool graphs = getenv("BALM_GRAPH") != nullptr;       // (a second stream inside a captured iteration: not worth the forks)
-  if ((e && e[0] == '0') || graphs || !full_dense || nf != ctx->F) return 0;
-  if (factors_chunk(ctx->W) < ctx->W) return 0;
-  const int rounds = (int)((plan.nblocks + 1023) / 1024);
-  if (rounds < 2 || rounds > 8) return 0;
-  if (!ctx->stream2) {
-    if (hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess) { hipGetLastError(); ctx->stream2 = nullptr; return 0; }
-    bool ok = hipEventCreateWithFlags(&ctx->ev_slab0, hipEventDisableTiming) == hipSuccess;
-    for (auto &ev : ctx->ev_slab) ok = ok && hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess;
-    if (!ok) { hipGetLastError(); return 0; }
-  }
-  const long key[5] = {nf, plan.SG, plan.nsteps, ctx->ntiles, plan.nblocks};
-  if (memcmp(key, ctx->ovl_key, sizeof key) != 0 || !ctx->d_forder) {
-    std::vector<int> order;
-    syrk_round_order(ctx->ntiles, plan, nf, order, ctx->ovl_slab);
-    if (hipStreamSynchronize(ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream2) != hipSuccess) return 0;      // (the old table may be in use)
-    if (ctx->d_forder) { hipFree(ctx->d_forder); ctx->d_forder = nullptr; }
-    if (hipMalloc((void **)&ctx->d_forder, (size_t)nf * sizeof(int)) != hipSuccess ||
-        hipMemcpy(ctx->d_forder, order.data(), (size_t)nf * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) {
-      hipGetLastError(); ctx->ovl_key[0] = -1; return 0;
-    }
-    memcpy(ctx->ovl_key, key, sizeof key);
-  }
-  return ctx->ovl_slab[0] > 0 && ctx->ovl_slab[0] < nf ? rounds : 0;
-}
-// workgroups of slab rho (rho = 0: the main stream, full occupancy; rho >= 1: beside the SYRK, one per CU)
-static int overlap_slab_grid(const balm_ctx *ctx, int form, int rho) {
-  const int cnt = ctx->ovl_slab[(size_t)rho] - (rho ? ctx->ovl_slab[(size_t)rho - 1] : 0);
-  if (cnt <= 0) return 0;
-  return rho == 0 ? factors_grid(ctx->W, cnt, form) : std::min(cnt, 256);
-}
-static int overlap_total_grid(const balm_ctx *ctx, int form, int rounds) {
-  int t = 0;
-  for (int rho = 0; rho < rounds; rho++) t += overlap_slab_grid(ctx, form, rho);
-  return t;
-}
-
 // scratch of one Hessian evaluation over nf features (grown, never shrunk): every allocation an evaluation can need
 // happens here, so that a rank of a sharded run can fail BEFORE the collectives start (see one_damping_iter)
 int prepare_evaluate(balm_ctx *ctx, int form, int nf) {
@@ -280,12 +230,7 @@ int prepare_evaluate(balm_ctx *ctx, int form, int nf) {
     if (ctx->d_Gt != before) ctx->gt_dirty_cols = ~(size_t)0;        // fresh memory: nothing is known to be zero
   }
   if ((rc = ensure(ctx, &ctx->d_part, &ctx->cap_part, parts * TILE_ELEMS))) return rc;
-  {
-    size_t rows = (size_t)factors_grid(ctx->W, nf, form);
-    if (const int rounds = overlap_rounds(ctx, form, nf, plan, !(ctx->sparse && nf == ctx->F) && nf == ctx->F))
-      rows = std::max(rows, (size_t)overlap_total_grid(ctx, form, rounds));
-    if ((rc = ensure(ctx, &ctx->d_dpart, &ctx->cap_dpart, rows * DACC_MAX * ctx->W))) return rc;
-  }
+  if ((rc = ensure(ctx, &ctx->d_dpart, &ctx->cap_dpart, (size_t)factors_grid(ctx->W, nf, form) * DACC_MAX * ctx->W))) return rc;
   if (nf == ctx->F && fuse_trial(ctx)) {       // the trial poses' factors (same sizes; reallocation invalidates what they held)
     if (ctx->cap_Gt2 < gcols * ctx->npad || ctx->cap_dpart2 < (size_t)factors_grid(ctx->W, nf, form) * DACC_MAX * ctx->W) ctx->gt_trial_valid = false;
     if ((rc = ensure(ctx, &ctx->d_Gt2, &ctx->cap_Gt2, gcols * ctx->npad))) return rc;
@@ -309,7 +254,7 @@ int evaluate_device(balm_ctx *ctx, int form, const double *d_poses, int f0, int 
   }
   SyrkPlan plan = plan_syrk(ctx->ntiles, 3L * nf);
   if ((rc = prepare_evaluate(ctx, form, nf))) return rc;
-  int nblk = factors_grid(W, nf, form);
+  const int nblk = factors_grid(W, nf, form);
   hipStream_t s = ctx->stream;
   if (!(ctx->feat_cur_valid && f0 == 0 && f1 == ctx->F)) {
     Span sp(ctx, BALM_T_MOMENTS);
@@ -318,7 +263,6 @@ int evaluate_device(balm_ctx *ctx, int form, const double *d_poses, int f0, int 
     ctx->feat_cur_valid = (f0 == 0 && f1 == ctx->F);
   }
   const int nr = ctx->nr_cur;
-  int ovl_rounds = 0;                                               // > 0: this evaluation runs K2's slabs beside K3's rounds (overlap_rounds)
   const bool sparse = ctx->sparse && f0 == 0 && f1 == ctx->F;       // sub-ranges keep the dense plan and column order
   const size_t kpad = sparse ? (size_t)ctx->sp_nchunks * ctx->sp_nsteps * 4 : (size_t)plan.Kpad;
   if (!(ctx->gt_cur_valid && ctx->feat_cur_valid && f0 == 0 && f1 == ctx->F)) {
@@ -334,33 +278,9 @@ int evaluate_device(balm_ctx *ctx, int form, const double *d_poses, int f0, int 
       HIP_TRY(hipMemsetAsync(ctx->d_Gt + k0 * ctx->npad, 0, (std::max(ctx->gt_dirty_cols, k1) - k0) * ctx->npad * sizeof(double), s));
     }
     ctx->gt_dirty_cols = k0;
-    ovl_rounds = overlap_rounds(ctx, form, nf, plan, !sparse && f0 == 0 && f1 == ctx->F);
-    if (ovl_rounds) {
-      // slab 0 here, at full occupancy; the later slabs are enqueued on stream2 below, behind this one's event, beside the SYRK's rounds
-      const int g0 = overlap_slab_grid(ctx, form, 0);
-      launch_factors(s, form, ctx->d_cl, d_poses, ctx->d_feat, W, ctx->npad, 0, ctx->ovl_slab[0], ctx->d_Gt, ctx->d_dpart, g0, nullptr, ctx->d_forder, false);
-      nblk = overlap_total_grid(ctx, form, ovl_rounds);
-    } else {
-      launch_factors(s, form, ctx->d_cl, d_poses, ctx->d_feat, W, ctx->npad, f0, f1, ctx->d_Gt, ctx->d_dpart, nblk,
-                     sparse ? ctx->d_slot : nullptr);
-    }
+    launch_factors(s, form, ctx->d_cl, d_poses, ctx->d_feat, W, ctx->npad, f0, f1, ctx->d_Gt, ctx->d_dpart, nblk,
+                   sparse ? ctx->d_slot : nullptr);
     ctx->gt_cur_valid = false;                // (set by the LM loop only, when an accepted trial's factors become current)
-  }
-  if (ovl_rounds) {
-    HIP_TRY(hipEventRecord(ctx->ev_slab0, s));
-    HIP_TRY(hipStreamWaitEvent(ctx->stream2, ctx->ev_slab0, 0));
-    size_t row = (size_t)overlap_slab_grid(ctx, form, 0);
-    const int dacc_rows = (form == 0 ? DACC_LEFT : DACC_RIGHT) * W;
-    for (int rho = 1; rho < ovl_rounds; rho++) {
-      const int g = overlap_slab_grid(ctx, form, rho);
-      if (g > 0) {
-        Span sp2(ctx, BALM_T_FACTORS_OVERLAPPED, ctx->stream2);
-        launch_factors(ctx->stream2, form, ctx->d_cl, d_poses, ctx->d_feat, W, ctx->npad, ctx->ovl_slab[(size_t)rho - 1], ctx->ovl_slab[(size_t)rho],
-                       ctx->d_Gt, ctx->d_dpart + row * dacc_rows, g, nullptr, ctx->d_forder, true);
-        row += (size_t)g;
-      }
-      HIP_TRY(hipEventRecord(ctx->ev_slab[rho], ctx->stream2));
-    }
   }
   // the moments / factor kernels ask for up to 150 KB of dynamic LDS (above the 64 KiB default: granted per device by
   // prepare_device_accum); a refused launch must surface here, not as stale results at the next synchronisation
@@ -368,12 +288,7 @@ int evaluate_device(balm_ctx *ctx, int form, const double *d_poses, int f0, int 
   {
     Span sp(ctx, BALM_T_SYRK);
     if (sparse) launch_syrk_sparse(s, ctx->d_Gt, ctx->npad, ctx->d_jobs, ctx->d_items, ctx->d_chunk_ids, ctx->sp_nsteps, ctx->sp_nitems, ctx->d_part);
-    else if (ovl_rounds) {
-      for (int rho = 0; rho < ovl_rounds; rho++) {
-        if (rho) HIP_TRY(hipStreamWaitEvent(s, ctx->ev_slab[rho], 0));
-        launch_syrk(s, ctx->d_Gt, ctx->npad, ctx->ntiles, ctx->d_jobs, plan, ctx->d_part, 1024l * rho, std::min(1024l, plan.nblocks - 1024l * rho));
-      }
-    } else launch_syrk(s, ctx->d_Gt, ctx->npad, ctx->ntiles, ctx->d_jobs, plan, ctx->d_part);
+    else launch_syrk(s, ctx->d_Gt, ctx->npad, ctx->ntiles, ctx->d_jobs, plan, ctx->d_part);
   }
   {
     Span sp(ctx, BALM_T_ASSEMBLE);
@@ -581,10 +496,6 @@ static void one_destroy(balm_ctx *ctx) {
   if (ctx->h_scal) hipHostFree(ctx->h_scal);
   for (auto &sp : ctx->timer.pending) { hipEventDestroy(sp.a); hipEventDestroy(sp.b); }
   for (auto e : ctx->timer.pool) hipEventDestroy(e);
-  if (ctx->stream2) { hipStreamSynchronize(ctx->stream2); hipStreamDestroy(ctx->stream2); }
-  if (ctx->ev_slab0) hipEventDestroy(ctx->ev_slab0);
-  for (auto e : ctx->ev_slab) if (e) hipEventDestroy(e);
-  if (ctx->d_forder) hipFree(ctx->d_forder);
   if (ctx->stream) hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -1596,21 +1507,6 @@ int balm_chain_macro_plan(int panels, int helpers, int *table, long capacity) {
   std::vector<int> tab;
   if (!balm::chain_macro_plan(panels, helpers, tab)) return BALM_ERR_ARG;
   memcpy(table, tab.data(), tab.size() * sizeof(int));
-  return BALM_OK;
-}
-
-// host-only: the plan of the overlapped evaluation for a window of win_size poses and F features (every pose sees every feature)
-int balm_overlap_plan(int win_size, int F, int *order, int *slab8, int *plan5) {
-  if (win_size < 1 || win_size > MAX_W || F < 1 || !order || !slab8 || !plan5) return BALM_ERR_ARG;
-  const int n = 6 * win_size, T = ((n + TILE - 1) / TILE * TILE) / TILE, ngroups = T / 5;
-  const int ntiles = T * (T - 1) / 2 + 3 * ngroups + (T - TM * ngroups);       // off-diagonal tiles + mixed jobs + left-over diagonal blocks (balm_create)
-  const SyrkPlan plan = plan_syrk(ntiles, 3L * F);
-  std::vector<int> ord, slab;
-  const int rounds = syrk_round_order(ntiles, plan, F, ord, slab);
-  if ((int)ord.size() != F) return BALM_ERR_STATE;
-  memcpy(order, ord.data(), (size_t)F * sizeof(int));
-  for (int k = 0; k < 8; k++) slab8[k] = k < rounds ? slab[(size_t)k] : F;
-  plan5[0] = ntiles; plan5[1] = plan.SG; plan5[2] = plan.nsteps; plan5[3] = (int)plan.nblocks; plan5[4] = rounds;
   return BALM_OK;
 }
 

@@ -82,12 +82,6 @@ struct balm_ctx {
   size_t cap_part = 0;
   double *d_dpart = nullptr;        // [nblk_factors][DACC][W]
   size_t cap_dpart = 0;
-  // the Hessian evaluation that runs the factor kernel's later slabs BESIDE the SYRK's rounds (evaluate_device, round 4)
-  hipStream_t stream2 = nullptr;    // the slabs' stream
-  hipEvent_t ev_slab0 = nullptr, ev_slab[8] = {nullptr};   // slab 0 done (main stream) / slab rho done (stream2)
-  int *d_forder = nullptr;          // [F] the features in the order in which the SYRK's rounds first need them (syrk_round_order)
-  std::vector<int> ovl_slab;        // positions in d_forder up to which round rho needs the factors
-  long ovl_key[5] = {-1, -1, -1, -1, -1};   // (F, SG, nsteps, ntiles, nblocks) the table was built for
   double *d_rpart = nullptr;        // residual partials at the current poses
   double *d_red = nullptr;          // [ntiles*6400 | DACC_MAX*W | r | pad]   all-reduce payload
   size_t red_len = 0;
@@ -128,6 +122,7 @@ struct balm_ctx {
   bool solve_tiled = false;         // d_A holds [A ; rhs] tile by tile (k_build_A -> k_ldl_chain without identity rows -> k_ldl_backsolve)
   int chain_refused_P[2] = {-1, -1};   // panels for which launch_factor_chain refused [without / with identity rows] (too few co-resident helpers, ...)
   bool solve_backsub = false;       // the last factorisation ran without identity rows: k_ldl_backsolve instead of k_ldl_apply
+  bool small_ready = false, small_refused = false;   // k_solve_small (windows of <= 24 poses): its LDS attribute is set on this device / the device refused it
   double u_value = 0.0;             // damping of the next solve (set_damping)
   bool u_on_device = false;         // ... read by the solve's kernels from d_scal[SCAL_U] (graph capture / replay) instead of their arguments
   int u_ring = 0;
@@ -176,15 +171,13 @@ int launch_feature_eigen(hipStream_t s, const double *C, const double *fix, cons
 int factors_grid(int W, int nfeat, int form);
 int factors_chunk(int W);     // poses per workgroup of the factor kernel (the whole window up to MAX_W_LDS)
 void launch_factors(hipStream_t s, int form, const double *cl, const double *poses, const double *feat, int W,
-                    int npad, int f0, int f1, double *Gt, double *dpart, int nblk, const int *slot = nullptr, const int *order = nullptr,
-                    bool one_per_cu = false);
+                    int npad, int f0, int f1, double *Gt, double *dpart, int nblk, const int *slot = nullptr);
 int launch_moments_factors(hipStream_t s, int form, const double *cl, const double *poses, const double *fix, const double *coe, int W,
                            int npad, int F, double *Gt, double *dpart, int nblk, const int *slot, double *feat, double *rpart);
 struct SyrkPlan { int SG; int nsteps; int Kpad; long nblocks; };   // k-slices, MFMA k-steps per wave, padded K, workgroups
 SyrkPlan plan_syrk(int ntiles, long K);
 void launch_syrk(hipStream_t s, const double *Gt, int npad, int ntiles, const int *tileIJ, const SyrkPlan &p,
-                 double *part, long bid0 = 0, long count = -1);
-int syrk_round_order(int ntiles, const SyrkPlan &p, int F, std::vector<int> &order, std::vector<int> &slab);
+                 double *part);
 void launch_syrk_sparse(hipStream_t s, const double *Gt, int npad, const int *jobs, const int *items, const int *chunk_ids,
                         int nsteps, long nitems, double *part);
 void launch_reduce(hipStream_t s, const double *part, int SG, long tile_elems_total, const double *dpart, int nblk,

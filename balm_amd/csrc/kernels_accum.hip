@@ -11,9 +11,6 @@
 //   K3  hessian_syrk    25 MFMA sub-tiles (an 80x80 tile, or 25 upper sub-tiles of the diagonal blocks) per
 //                       wavefront on v_mfma_f64_16x16x4_f64, split-K
 //   K4  reduce / assemble
-#include <algorithm>
-#include <vector>
-
 #include "balm_internal.h"
 
 namespace balm {
@@ -507,10 +504,7 @@ __global__ __launch_bounds__(256) void k_feature_factors(const double *__restric
                                                          const double *__restrict__ poses,
                                                          const double *__restrict__ feat, int W, int Wc, int npad, int f0,
                                                          int f1, double *__restrict__ Gt,
-                                                         double *__restrict__ dpart, const int *__restrict__ slot,
-                                                         const int *__restrict__ order) {
-  // order != NULL: [f0, f1) is a range of POSITIONS in `order`, a permutation of the features (the slabs of the evaluation that
-  // overlaps this kernel with the SYRK: evaluate_device); the Gt column of a feature stays 3 a (or its block-sparse slot)
+                                                         double *__restrict__ dpart, const int *__restrict__ slot) {
   constexpr int DACC = FORM == 0 ? DACC_LEFT : DACC_RIGHT;
   extern __shared__ __attribute__((aligned(16))) double sm[];
   // blockIdx.y = chunk of Wc poses (one chunk = the whole window up to MAX_W_LDS poses)
@@ -545,15 +539,14 @@ __global__ __launch_bounds__(256) void k_feature_factors(const double *__restric
     for (int c = 0; c < 10; c++) nxt[c] = ca[(size_t)c * W];
   };
   const int i_first = p0 + (threadIdx.x < (unsigned)wc ? (int)threadIdx.x : 0);
-  if (f0 + (int)blockIdx.x < f1) fetch(order ? order[f0 + blockIdx.x] : f0 + (int)blockIdx.x, i_first);
+  if (f0 + (int)blockIdx.x < f1) fetch(f0 + blockIdx.x, i_first);
 
-  for (int ia = f0 + blockIdx.x; ia < f1; ia += gridDim.x) {
-    const int a = order ? order[ia] : ia;
+  for (int a = f0 + blockIdx.x; a < f1; a += gridDim.x) {
     const double *f = feat + (size_t)a * FEAT_STRIDE;
     const FeatRec fr = {f[FT_NN], 1.0 / f[FT_NN], {f[FT_VBAR], f[FT_VBAR + 1], f[FT_VBAR + 2]}, {f[FT_U0], f[FT_U0 + 1], f[FT_U0 + 2]},
                         {f[FT_U1], f[FT_U1 + 1], f[FT_U1 + 2]}, {f[FT_U2], f[FT_U2 + 1], f[FT_U2 + 2]}, f[FT_C0], f[FT_C1], f[FT_C2], f[FT_COE]};
     const double *ca = cl + (size_t)a * 10 * W;
-    double *g0 = Gt + (size_t)(3 * (slot ? slot[a] : (order ? a : a - f0))) * npad;      // slot: the block-sparse plan's column order
+    double *g0 = Gt + (size_t)(3 * (slot ? slot[a] : a - f0)) * npad;      // slot: the block-sparse plan's column order
 
     for (int il = threadIdx.x; il < wc; il += blockDim.x) {
       const int i = p0 + il;
@@ -571,7 +564,7 @@ __global__ __launch_bounds__(256) void k_feature_factors(const double *__restric
         for (int c = 0; c < 3; c++) v[c] = ca[(size_t)(6 + c) * W + i];
       }
       const double N = il == (int)threadIdx.x ? nxt[9] : ca[(size_t)9 * W + i];
-      if (il == (int)threadIdx.x && ia + (int)gridDim.x < f1) fetch(order ? order[ia + gridDim.x] : ia + (int)gridDim.x, i_first);
+      if (il == (int)threadIdx.x && a + (int)gridDim.x < f1) fetch(a + gridDim.x, i_first);
       obs_factors<FORM>(fr, P, v, N, sp, sacc, Wc, il, col0, col1, col2);
       // (Measured and rejected, round 4, profiles/r04d_factors_ab.txt: streaming (nontemporal) stores -- 0.555 vs 0.553 ms; the lane's
       // pose in twelve registers instead of the LDS table, i.e. 43 KB per workgroup and THREE workgroups per CU -- 0.565 vs 0.554.)
@@ -776,19 +769,15 @@ int launch_moments_factors(hipStream_t s, int form, const double *cl, const doub
   return nblk;
 }
 
-// order / one_per_cu: the slabs that run BESIDE the SYRK (evaluate_device): positions [f0, f1) of a feature permutation, and a dynamic
-// LDS request above half a CU's so that at most ONE workgroup lands on a CU -- two of its wavefronts on one SIMD would leave no
-// room for the SYRK's wavefront there (328 of the 512 registers per lane) for the slab's whole life.
 void launch_factors(hipStream_t s, int form, const double *cl, const double *poses, const double *feat, int W,
-                    int npad, int f0, int f1, double *Gt, double *dpart, int nblk, const int *slot, const int *order, bool one_per_cu) {
+                    int npad, int f0, int f1, double *Gt, double *dpart, int nblk, const int *slot) {
   const int Wc = factors_chunk(W), chunks = (W + Wc - 1) / Wc;
-  size_t lds = factors_lds(W, form);
-  if (one_per_cu && lds < 81 * 1024) lds = 81 * 1024;
+  const size_t lds = factors_lds(W, form);
   int bs = W <= 64 ? 64 : (W <= 128 ? 128 : 256);
   if (form == 0)
-    hipLaunchKernelGGL(k_feature_factors<0>, dim3(nblk, chunks), dim3(bs), lds, s, cl, poses, feat, W, Wc, npad, f0, f1, Gt, dpart, slot, order);
+    hipLaunchKernelGGL(k_feature_factors<0>, dim3(nblk, chunks), dim3(bs), lds, s, cl, poses, feat, W, Wc, npad, f0, f1, Gt, dpart, slot);
   else
-    hipLaunchKernelGGL(k_feature_factors<1>, dim3(nblk, chunks), dim3(bs), lds, s, cl, poses, feat, W, Wc, npad, f0, f1, Gt, dpart, slot, order);
+    hipLaunchKernelGGL(k_feature_factors<1>, dim3(nblk, chunks), dim3(bs), lds, s, cl, poses, feat, W, Wc, npad, f0, f1, Gt, dpart, slot);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -897,14 +886,12 @@ __device__ __forceinline__ long xcd_remap(long bid, long nblocks) {
 
 __global__ __launch_bounds__(64) void k_hessian_syrk(const double *__restrict__ Gt, int npad, int njobs,
                                                      const int *__restrict__ jobs, int nsteps, long nblocks,
-                                                     double *__restrict__ part, long bid0) {
+                                                     double *__restrict__ part) {
   // Dense plan: one wavefront per (job, k-slice).  The remap gives an XCD ALL jobs of one k-slice after the other:
   // an XCD holds 128 of these one-wave workgroups (4 per CU), i.e. the jobs of a slice run side by side and sweep
   // k in lockstep (they are all MFMA-paced, 25 MFMAs per k-step each), so each 128-byte line of Gt is pulled into
   // that XCD's L2 once and serves the ~15 jobs that need it.
-  // bid0: the launch covers the workgroups [bid0, bid0 + gridDim.x) of the plan (a multiple of 8: the XCD of a workgroup is the same
-  // as in one launch of all of them) -- the rounds of the evaluation that runs the factor kernel's slabs beside them
-  const long bid = xcd_remap((long)blockIdx.x + bid0, nblocks);
+  const long bid = xcd_remap(blockIdx.x, nblocks);
   const int tile = (int)(bid % njobs);
   const int sg = (int)(bid / njobs);
   BALM_SYRK_ZERO_ACC();
@@ -972,39 +959,12 @@ void launch_syrk_sparse(hipStream_t s, const double *Gt, int npad, const int *jo
 }
 
 void launch_syrk(hipStream_t s, const double *Gt, int npad, int ntiles, const int *tileIJ, const SyrkPlan &p,
-                 double *part, long bid0, long count) {
-  if (count < 0) count = p.nblocks - bid0;
-  hipLaunchKernelGGL(k_hessian_syrk, dim3((unsigned)count), dim3(64), 0, s, Gt, npad, ntiles, tileIJ,
-                     p.nsteps, p.nblocks, part, bid0);
-}
-
-// The hardware runs a launch of one-wave workgroups in ROUNDS of 1024 (128 slots per XCD, all workgroups of a round alike and MFMA-paced:
-// they start and end together).  Which features must the factor kernel have finished before round rho may start?  Round rho holds the
-// hardware blocks [1024 rho, 1024 (rho + 1)), i.e. on XCD x the logical workgroups xcd_remap(8 j + x), 128 rho <= j < 128 (rho + 1): a
-// run of ~1.1 k-slices per XCD -- EIGHT stretches of Gt columns spread over the whole K range, plus the prefetch ring's overrun of
-// SYRK_NBUF - 1 k-steps behind each.  order = the features in the order in which the rounds first need them; slab[rho] = how many of
-// them rounds 0..rho need (slab[rounds - 1] = F).  Pure host code.
-int syrk_round_order(int ntiles, const SyrkPlan &p, int F, std::vector<int> &order, std::vector<int> &slab) {
-  const long nb = p.nblocks, q = nb >> 3, r = nb & 7;
-  const int rounds = (int)((nb + 1023) / 1024);
-  order.clear(); slab.assign((size_t)rounds, 0);
-  std::vector<char> seen((size_t)F, 0);
-  for (int rho = 0; rho < rounds; rho++) {
-    for (long x = 0; x < 8; x++) {
-      const long cnt = q + (x < r ? 1 : 0), j0 = 128l * rho, j1 = std::min(128l * (rho + 1), cnt);
-      if (j0 >= j1) continue;
-      const long L = x * q + std::min(x, r);
-      const long sg0 = (L + j0) / ntiles, sg1 = (L + j1 - 1) / ntiles;
-      const long c0 = sg0 * p.nsteps * 4, c1 = (sg1 + 1) * p.nsteps * 4 + (SYRK_NBUF - 1) * 4;
-      const long a0 = c0 / 3, a1 = std::min((long)F, (c1 + 2) / 3);
-      for (long a = a0; a < a1; a++)
-        if (!seen[(size_t)a]) { seen[(size_t)a] = 1; order.push_back((int)a); }
-    }
-    slab[(size_t)rho] = (int)order.size();
-  }
-  for (int a = 0; a < F; a++) if (!seen[(size_t)a]) order.push_back(a);      // (none: the slices cover every column)
-  slab[(size_t)rounds - 1] = F;
-  return rounds;
+                 double *part) {
+  // (Measured and rejected, round 4, profiles/r04f_overlap_ab.txt: the launch cut at its rounds of 1024 workgroups with the factor
+  // kernel's later slabs on a second stream beside them -- factors + syrk 3.70 instead of 3.64 ms per step at config 2: the SYRK keeps
+  // the FP64 datapath busy 97 % of the time, and the factor kernel's f64 VALU work shares that datapath: it is added, not hidden.)
+  hipLaunchKernelGGL(k_hessian_syrk, dim3((unsigned)p.nblocks), dim3(64), 0, s, Gt, npad, ntiles, tileIJ,
+                     p.nsteps, p.nblocks, part);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -996,9 +996,15 @@ static void launch_factor(balm_ctx *c) {
   }
 }
 
+#include "kernels_small.inc"
+
 void launch_solve(balm_ctx *c, bool new_hessian, int upd_form, const double *upd_poses, double *upd_out) {      // damping u: c->u_value as a kernel argument, or (c->u_on_device: graph
   hipStream_t s = c->stream;                            // capture / replay) c->d_scal[SCAL_U], put there on the stream by push_damping
   const int n = c->n, nA = c->nA;
+  if (solve_wants_small(c)) {                           // windows of up to 24 poses: the whole solve is one launch of one workgroup
+    c->solve_backsub = false; c->solve_tiled = false;
+    if (launch_solve_small(c, upd_form, upd_poses, upd_out)) return;
+  }
   const double *pu = c->u_on_device ? c->d_scal + SCAL_U : nullptr;
   if (new_hessian) {
     const size_t lds = (size_t)nA * sizeof(double) + 256 * sizeof(int);

@@ -390,17 +390,8 @@ def main(argv=None):
         ms, cnt = timing[key]
         return ms / max(cnt, 1) * 1e-3 if cnt else None
 
-    syrk_s = avg_s("syrk")          # per Hessian evaluation (HIP events around the kernel's launch -- or, overlapped, its launches -- on the library's stream)
+    syrk_s = avg_s("syrk")          # HIP events around the kernel's launch on the library's stream
     achieved = wm["syrk_flops_algorithmic"] / syrk_s / 1e12 if syrk_s else None
-    # Overlapped evaluation: k_hessian_syrk runs as one launch PER ROUND of 1024 one-wave workgroups (the same plan, the same
-    # workgroups), with feature_factors' later slabs on a second stream beside them -- per-launch figures are the evaluation's divided by the rounds
-    overlapped = timing.get("factors_overlapped", (0.0, 0))[1] > 0
-    rounds = 1
-    if overlapped:
-        try:
-            rounds = capi.overlap_plan(W, Fg)[2]["rounds"]
-        except Exception:
-            rounds = 1
     # HBM bytes per launch: NOT measured in this run (PMC counters need rocprofv3 around the process) -- read from the
     # committed summary of separate `rocprofv3 --pmc` passes of this same command; `traffic_source` names that run
     traffic, traffic_source = None, None
@@ -415,12 +406,9 @@ def main(argv=None):
         "kernel": "k_hessian_syrk", "bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS,
         "unit": "TFLOP/s", "frac": (achieved / FP64_PEAK_TFLOPS) if achieved else None, "traffic": traffic,
         "traffic_source": traffic_source,
-        "dtype": "f64", "avg_launch_ms": syrk_s * 1e3 / rounds if syrk_s else None, "launches": timing["syrk"][1] * rounds,
-        "algorithmic_flops_per_launch": wm["syrk_flops_algorithmic"] / rounds,
-        "issued_flops_per_launch": wm["syrk_flops_issued"] / rounds,
-        "launches_per_evaluation": rounds, "ms_per_evaluation": syrk_s * 1e3 if syrk_s else None,
-        "overlapped_with": ("k_feature_factors' slabs 1..%d on a second stream (their stream time: kernel_ms_per_step.factors_overlapped, "
-                            "INSIDE the syrk time, not added to it)" % (rounds - 1)) if overlapped else None,
+        "dtype": "f64", "avg_launch_ms": syrk_s * 1e3 if syrk_s else None, "launches": timing["syrk"][1],
+        "algorithmic_flops_per_launch": wm["syrk_flops_algorithmic"],
+        "issued_flops_per_launch": wm["syrk_flops_issued"],
     }
     # the other kernel classes of the step against THEIR rooflines (algorithmic bytes/flops of SURVEY 8d; S = observations)
     S = wm["S"]
@@ -431,16 +419,10 @@ def main(argv=None):
                                 "frac": 80.0 * S / t / 1e12 / HBM_PEAK_TBS, "frac_of_copy_rate": 80.0 * S / t / 1e12 / COPY_RATE_TBS,
                                 "avg_launch_ms": t * 1e3}
     t = avg_s("factors")
-    if t:      # K2: 80 B read + 144 B written per observation (overlapped evaluation: slab 0 only -- the share of the observations it covers)
-        share = 1.0
-        if overlapped:
-            try:
-                share = float(capi.overlap_plan(W, Fg)[1][0]) / Fg
-            except Exception:
-                share = 1.0
-        secondary["factors"] = {"bound": "hbm", "achieved": 224.0 * S * share / t / 1e12, "peak": HBM_PEAK_TBS, "unit": "TB/s",
-                                "frac": 224.0 * S * share / t / 1e12 / HBM_PEAK_TBS, "frac_of_copy_rate": 224.0 * S * share / t / 1e12 / COPY_RATE_TBS,
-                                "avg_launch_ms": t * 1e3, "share_of_observations": share}
+    if t:      # K2: 80 B read + 144 B written per observation
+        secondary["factors"] = {"bound": "hbm", "achieved": 224.0 * S / t / 1e12, "peak": HBM_PEAK_TBS, "unit": "TB/s",
+                                "frac": 224.0 * S / t / 1e12 / HBM_PEAK_TBS, "frac_of_copy_rate": 224.0 * S / t / 1e12 / COPY_RATE_TBS,
+                                "avg_launch_ms": t * 1e3}
     t = avg_s("solve")
     if t:      # blocked LDL^T: n^3/3 + 2 n^2 flops; a latency chain, priced against the FP64 peak for the record
         fl = n ** 3 / 3.0 + 2.0 * n * n
@@ -502,15 +484,15 @@ def main(argv=None):
             # the curve the measured N > 1 values are to be judged against: features shard, the assemble / solve /
             # pose update replicate, two RCCL calls per step (the 5.9 MB payload of an evaluation: ~0.07 ms of link time at
             # 7/8 x 2 x payload over 153 GB/s per link; the trial residual: 8 bytes).  comm = what those calls cost a step with a
-            # ONE-rank communicator on one GPU (profiles/r03v_bench_dist_path_one_gpu.json against r03v_bench.json: 4.93 vs
-            # 4.24 ms/step -- 50-110 us of idle stream around every call, and the clocks sag in the gaps), plus the wire time;
-            # an estimate until a multi-GPU node has measured it
+            # ONE-rank communicator on one GPU (profiles/r04b_dist_overhead.txt: 4.286 vs 4.257 ms/step = 0.03 ms, the calls' own
+            # stream time; round 3's 0.7 ms was the cooperative launch's cross-queue barriers, root-caused and removed there), plus
+            # the wire time; an estimate until a multi-GPU node has measured it
             fixed_ms = per_step.get("solve", 0) + per_step.get("assemble", 0) + per_step.get("update", 0)
             t4 = d4 / k4 * 1e3
-            comm_ms = 0.7 + 0.07
+            comm_ms = 0.03 + 0.07
             out["strong_scaling_reference"]["predicted"] = {
                 "model": "T(N) = (T(1) - fixed) / N + fixed + comm; fixed = replicated solve + assemble + pose update of this run; "
-                         "comm = one-rank RCCL call overhead measured on one GPU (0.7 ms/step) + link time of the 5.9 MB all-reduce (0.07 ms)",
+                         "comm = one-rank RCCL call overhead measured on one GPU (0.03 ms/step, profiles/r04b_dist_overhead.txt) + link time of the 5.9 MB all-reduce (0.07 ms)",
                 "fixed_ms": fixed_ms, "comm_ms_assumed": comm_ms,
                 "ms_per_step": {str(N): (t4 - fixed_ms) / N + fixed_ms + comm_ms for N in (2, 4, 8)},
                 "speedup_vs_one_gpu": {str(N): t4 / ((t4 - fixed_ms) / N + fixed_ms + comm_ms) for N in (2, 4, 8)}}

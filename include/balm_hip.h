@@ -255,9 +255,7 @@ enum {
   BALM_T_VOXEL = 7,     /* adaptive-voxel association (balm_associate, device part only)      */
   BALM_T_COV = 8,       /* balm_pose_covariance: covariance factors, its two SYRKs, H^-1 R H^-T */
   BALM_T_COMM = 9,      /* the all-reduces of the sharded path (stream time: includes waiting for the slowest rank) */
-  BALM_T_FACTORS_OVERLAPPED = 10, /* the slabs of feature_factors that run on a second stream BESIDE hessian_syrk (their stream time is
-                                     inside the SYRK's span, not in addition to it)                                */
-  BALM_T_COUNT = 11
+  BALM_T_COUNT = 10
 };
 int balm_get_timing(balm_ctx *ctx, double *ms, long *count);
 
@@ -274,12 +272,6 @@ int balm_reset_timing(balm_ctx *ctx);
  * helper with more than 64 macro-tiles, or a short buffer.  (Here so that the CPU tests cover the scheduling logic.) */
 int balm_chain_macro_plan(int panels, int helpers, int *table, long capacity);
 
-/* Host-only diagnostic (no device needed): the plan of the Hessian evaluation that runs feature_factors' slabs beside hessian_syrk's rounds, for a
- * window of win_size poses that all see all F features -- order[F]: the features in the order in which the SYRK's rounds first need their Gt
- * columns; slab8[rho]: how many of them rounds 0..rho need (F from the last round on); plan5 = {jobs per k-slice, k-slices, k-steps per slice,
- * workgroups, rounds of 1024 workgroups}.  (Here so that the CPU tests cover the ordering logic.) */
-int balm_overlap_plan(int win_size, int F, int *order, int *slab8, int *plan5);
-
 /* Work model of the last balm_set_features: out[0] = S = sum_a n_a, out[1] = sum_a n_a(n_a+1)/2,
  * out[2] = algorithmic FLOPs of one hessian_syrk launch = 216 * out[1] (three 6x6 rank-1 updates per observed
  * unordered pose pair incl. the diagonal; 108*F*W*(W+1) when every pose sees every feature), out[3] = FLOPs the
@@ -291,7 +283,7 @@ const char *balm_version(void);
 
 /* ABI revision of this header.  It changes whenever a struct above grows, an enum gains a member that sizes a caller's array
  * (BALM_T_COUNT) or an entry point changes its meaning: 3 = round 3 (balm_voxel_opts gained fix_point_limit / defer_recut,
- * BALM_T_COUNT went from 9 to 10), 4 = this header (BALM_T_COUNT 11, balm_abi_version itself).  A caller built against another revision must not call anything else:
+ * BALM_T_COUNT went from 9 to 10), 4 = this header (balm_abi_version itself).  A caller built against another revision must not call anything else:
  *     if (balm_abi_version() != BALM_ABI_VERSION) { refuse }                                                              */
 #define BALM_ABI_VERSION 4
 int balm_abi_version(void);

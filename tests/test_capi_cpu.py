@@ -109,28 +109,3 @@ def test_macro_tile_ownership_plan_is_a_balanced_partition(P, NH):
     assert max(loads) <= sum(loads) / NH + heaviest          # longest-processing-time-first's bound
     if P == 63:
         assert max(loads) <= 1.12 * sum(loads) / NH
-
-
-@pytest.mark.parametrize("W,F", [(200, 50000), (200, 25000), (200, 6250), (120, 40000), (64, 5000), (256, 30011)])
-def test_overlap_plan_covers_what_every_syrk_round_reads(W, F):
-    """The evaluation that runs feature_factors' slabs beside hessian_syrk's rounds (balm_capi.hip: overlap_rounds) must have produced, before round
-    rho starts, every Gt column a workgroup of rounds 0..rho reads -- its k-slice and the prefetch ring's overrun behind it.  Recomputed here from
-    the plan alone (hardware block -> XCD -> logical workgroup -> k-slice), independently of syrk_round_order's own bookkeeping."""
-    from balm_amd import capi
-    order, slab, plan = capi.overlap_plan(W, F)
-    assert sorted(order.tolist()) == list(range(F)), "order is a permutation of the features"
-    nt, ns, nb, R = (plan[k] for k in ("ntiles", "nsteps", "nblocks", "rounds"))
-    assert R == (nb + 1023) // 1024 and slab[R - 1] == F and all(slab[k] <= slab[k + 1] for k in range(7))
-    pos = np.empty(F, np.int64)
-    pos[order] = np.arange(F)
-    q, r = nb >> 3, nb & 7
-    seen = set()
-    for hb in range(nb):
-        x = hb & 7
-        bid = x * q + min(x, r) + (hb >> 3)          # kernels_accum.hip: xcd_remap
-        seen.add(bid)
-        sg, rho = bid // nt, hb // 1024
-        a0, a1 = (sg * ns * 4) // 3, min(F, ((sg + 1) * ns * 4 + 12 + 2) // 3)
-        if a1 > a0:
-            assert pos[a0:a1].max() < slab[rho], (hb, rho, a0, a1)
-    assert len(seen) == nb, "the remap is a bijection of the plan's workgroups"

@@ -259,3 +259,83 @@ def test_chain_kernel_lm_run_and_real_hessian():
         os.environ.pop("BALM_SOLVE", None)
     assert len(la) == len(lb) and np.allclose(la[:, :3], lb[:, :3], rtol=1e-9, atol=0) and np.abs(pa - pb).max() < 1e-10
     c.close()
+
+
+# ---- k_solve_small (round 4): the whole damped solve of a window of <= 32 poses as one launch of one workgroup ----------------
+@pytest.mark.parametrize("W", [1, 2, 5, 8, 9, 15, 16, 17, 20, 23, 24, 25, 31, 32])
+@pytest.mark.parametrize("kind", ["spd", "indefinite"])
+def test_small_window_kernel_matches_lapack(W, kind):
+    """k_solve_small (rank + build + LDL^T + substitution + q1 in one launch, the matrix in LDS; bavoxel.hpp:1113-1127) against LAPACK and
+    against the launch path, every panel count 1..3 and windows that do / do not fill their last panel, solve after solve; windows of
+    25..32 poses (four panels) are beyond it and stay on the launch path"""
+    H, g = _test_matrix(W, kind, 31 * W + (kind == "spd"))
+    u = 0.1
+    D = np.diag(np.diag(H))
+    ref = np.linalg.solve(H + u * D, -g)
+    c = capi.Context(W)
+    try:
+        os.environ["BALM_SOLVE"] = "small"
+        for _ in range(3):
+            dx, q1 = c.solve_damped(H, g, u)
+            assert np.all(np.isfinite(dx))
+            assert rel_err(dx, ref) < 1e-9
+        assert abs(q1 - 0.5 * dx @ (u * D @ dx - g)) <= 1e-12 * abs(q1)
+        os.environ["BALM_SOLVE"] = "launches"
+        dx0, q0 = c.solve_damped(H, g, u)
+        assert rel_err(dx, dx0) < 1e-10 and abs(q1 - q0) <= 1e-10 * abs(q0)
+        os.environ.pop("BALM_SOLVE")
+        dxd, qd = c.solve_damped(H, g, u)                    # the default IS the small kernel at these sizes: bit for bit
+        assert np.array_equal(dxd, dx) and qd == q1
+    finally:
+        os.environ.pop("BALM_SOLVE", None)
+    c.close()
+
+
+@pytest.mark.parametrize("W", [12, 20, 30])
+def test_small_window_kernel_blind_poses(W):
+    """zero 6x6 blocks (poses that observe nothing): zero pivots, D^+ leaves exact zeros there (Eigen's rule), as on every other path"""
+    rng = np.random.default_rng(W)
+    n = 6 * W
+    blind = rng.choice(W, size=3, replace=False)
+    live = np.ones(n, bool)
+    for b in blind:
+        live[6 * b:6 * b + 6] = False
+    m = int(live.sum())
+    B = rng.standard_normal((m, 96))
+    Hl = B @ B.T / 96 + np.diag(rng.uniform(0.5, 50.0, m))
+    H = np.zeros((n, n)); H[np.ix_(live, live)] = Hl
+    g = np.zeros(n); g[live] = rng.standard_normal(m)
+    u = 0.1
+    ref = np.zeros(n)
+    ref[live] = np.linalg.solve(Hl + u * np.diag(np.diag(Hl)), -g[live])
+    c = capi.Context(W)
+    try:
+        for mode in ("small", "launches"):
+            os.environ["BALM_SOLVE"] = mode
+            dx, q1 = c.solve_damped(H, g, u)
+            assert np.all(dx[~live] == 0.0), mode
+            assert rel_err(dx[live], ref[live]) < 1e-9, (mode, rel_err(dx[live], ref[live]))
+    finally:
+        os.environ.pop("BALM_SOLVE", None)
+    c.close()
+
+
+@pytest.mark.parametrize("W,F,form", [(20, 20, 0), (20, 150, 1), (32, 300, 0), (9, 40, 0)])
+def test_small_window_kernel_lm_run(W, F, form):
+    """an LM run with the one-launch solve (trial poses written by the kernel itself) against the launch path: same accept / reject
+    sequence, same poses; plain launches and the replayed hipGraph"""
+    sc, _ = make_scene(40 + W, W, F, 8, drop=0.2)
+    c = capi.Context(sc.W)
+    c.set_features(sc.clusters, None, sc.coeffs)
+    try:
+        os.environ["BALM_SOLVE"] = "launches"
+        pa, la = c.damping_iter(sc.poses_init, form=form, u0=0.01, max_iter=10)
+        os.environ.pop("BALM_SOLVE")
+        pb, lb = c.damping_iter(sc.poses_init, form=form, u0=0.01, max_iter=10)
+        os.environ["BALM_GRAPH"] = "1"
+        pc, lc = c.damping_iter(sc.poses_init, form=form, u0=0.01, max_iter=10)
+    finally:
+        os.environ.pop("BALM_SOLVE", None); os.environ.pop("BALM_GRAPH", None)
+    assert len(la) == len(lb) and np.allclose(la[:, :3], lb[:, :3], rtol=1e-9, atol=0) and np.abs(pa - pb).max() < 1e-10
+    assert len(lc) == len(lb) and np.allclose(lc[:, :3], lb[:, :3], rtol=1e-12, atol=0) and np.abs(pc - pb).max() < 1e-12
+    c.close()
