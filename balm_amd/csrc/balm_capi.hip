@@ -186,15 +186,18 @@ void drop_lm_graphs(balm_ctx *ctx) {
 // ranks).  The per-feature eigen records it produces are kept (d_feat_tmp): if the step is accepted
 // they are exactly what the next Hessian evaluation needs at the same poses (the reference recomputes
 // them, bavoxel.hpp:331-351 after :443-457).
-int residual_device(balm_ctx *ctx, const double *d_poses, int f0, int f1, int slot, bool defer_sum = false) {
+// send_mail (contexts without a collective transport, the LM loop, at most 256 features): the eigen kernel's one workgroup puts its sum
+// into d_scal[slot] and sends the iteration's scalars and the stamp to the host mirror itself (-> wait_scalars) -- no launch behind it.
+int residual_device(balm_ctx *ctx, const double *d_poses, int f0, int f1, int slot, bool defer_sum = false, bool send_mail = false) {
   if (f1 <= f0) {          // a shard the requested feature range does not reach: contributes zero
     HIP_TRY(hipMemsetAsync(ctx->d_scal + slot, 0, sizeof(double), ctx->stream));
     ctx->nr_tmp = 0;
   } else {
     Span sp(ctx, BALM_T_MOMENTS);
     launch_world_moments(ctx->stream, ctx->d_cl, d_poses, ctx->W, f0, f1, ctx->d_C);
+    const EigenMail mail{ctx->d_scal, ctx->d_hscal, send_mail ? (double)++ctx->mail_seq : 0.0, slot};
     ctx->nr_tmp = launch_feature_eigen(ctx->stream, ctx->d_C, ctx->has_fix ? ctx->d_fix : nullptr, ctx->d_coe, f0, f1, ctx->d_feat_tmp,
-                                       ctx->d_rpart_tmp);
+                                       ctx->d_rpart_tmp, send_mail ? &mail : nullptr);
     if (!defer_sum) launch_sum_scalar(ctx->stream, ctx->d_rpart_tmp, ctx->nr_tmp, ctx->d_scal + slot);
   }
   HIP_TRY(hipGetLastError());          // k_world_moments: dynamic LDS above the 64 KiB default
@@ -1109,7 +1112,9 @@ static int lm_enqueue(balm_ctx *ctx, int form, bool evaluated, bool mail) {
     if ((rc = trial_device(ctx, form, ctx->d_poses_tmp, 1))) return rc;
   } else {
     sum_in_mail = mail && !has_transport(ctx) && ctx->F > 0;
-    if ((rc = residual_device(ctx, ctx->d_poses_tmp, 0, ctx->F, 1, sum_in_mail))) return rc;
+    const bool eigen_mails = sum_in_mail && ctx->F <= 256;      // one workgroup of k_feature_eigen: it sends the mail itself
+    if ((rc = residual_device(ctx, ctx->d_poses_tmp, 0, ctx->F, 1, sum_in_mail, eigen_mails))) return rc;
+    if (eigen_mails) return BALM_OK;
   }
   if (mail) launch_scalars_mail(ctx->stream, ctx->d_scal, ctx->d_hscal, (double)++ctx->mail_seq, sum_in_mail ? ctx->d_rpart_tmp : nullptr,
                                 ctx->nr_tmp, 1);      // -> wait_scalars

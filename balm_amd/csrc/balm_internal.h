@@ -166,8 +166,9 @@ hipError_t prepare_device_accum();     // per-device kernel attributes (dynamic 
 hipError_t prepare_device_cov();
 void launch_transpose_clusters(hipStream_t s, const double *aos, double *soa, int F, int W);
 void launch_world_moments(hipStream_t s, const double *cl, const double *poses, int W, int f0, int f1, double *C);
+struct EigenMail { double *scal; double *host; double stamp; int slot; };      // a ONE-workgroup k_feature_eigen sends the LM iteration's scalars itself (host == NULL: no)
 int launch_feature_eigen(hipStream_t s, const double *C, const double *fix, const double *coe, int f0, int f1,
-                         double *feat, double *rpart);   // returns #partials
+                         double *feat, double *rpart, const EigenMail *mail = nullptr);   // returns #partials
 int factors_grid(int W, int nfeat, int form);
 int factors_chunk(int W);     // poses per workgroup of the factor kernel (the whole window up to MAX_W_LDS)
 void launch_factors(hipStream_t s, int form, const double *cl, const double *poses, const double *feat, int W,

@@ -218,9 +218,13 @@ __device__ __forceinline__ void eig3_jacobi(double a00, double a01, double a02, 
   for (int k = 0; k < 3; k++) { U[k][0] = c0[k]; U[k][1] = c1[k]; U[k][2] = c2[k]; }
 }
 
+// mail.host != NULL (the LM loop's trial residual, no collective transport, at most 256 features = ONE workgroup): the workgroup puts its
+// sum -- the whole residual -- into scal[mail.slot] and sends the iteration's 16 scalars and the stamp to the pinned host mirror itself: one
+// launch (k_scalars_mail, ~6 us) less per LM iteration of a small window.  (With more workgroups the last one would have to be found by
+// tickets: measured, 0.02 ms per launch at 196 workgroups for the device-scope release each of them needs -- see the note at the end of this file.)
 __global__ __launch_bounds__(256) void k_feature_eigen(const double *__restrict__ C, const double *__restrict__ fix,
                                                        const double *__restrict__ coe, int f0, int f1,
-                                                       double *__restrict__ feat, double *__restrict__ rpart) {
+                                                       double *__restrict__ feat, double *__restrict__ rpart, EigenMail mail) {
   __shared__ double sred[256];
   const int a = f0 + blockIdx.x * blockDim.x + threadIdx.x;
   double res = 0.0;
@@ -261,14 +265,23 @@ __global__ __launch_bounds__(256) void k_feature_eigen(const double *__restrict_
     __syncthreads();
   }
   if (threadIdx.x == 0) rpart[blockIdx.x] = sred[0];
+  if (!mail.host) return;                                         // (only ever set on a ONE-workgroup launch: sred[0] is the whole sum)
+  if (threadIdx.x == 0) mail.scal[mail.slot] = sred[0];
+  __syncthreads();
+  volatile double *host = mail.host;
+  if (threadIdx.x < 16) host[threadIdx.x] = ((int)threadIdx.x == mail.slot) ? sred[0] : mail.scal[threadIdx.x];
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) { host[SCAL_STAMP] = mail.stamp; __threadfence_system(); }
 }
 
 int launch_feature_eigen(hipStream_t s, const double *C, const double *fix, const double *coe, int f0, int f1,
-                         double *feat, double *rpart) {
+                         double *feat, double *rpart, const EigenMail *mail) {
   int nf = f1 - f0;
   if (nf <= 0) return 0;
   int grid = (nf + 255) / 256;
-  hipLaunchKernelGGL(k_feature_eigen, dim3(grid), dim3(256), 0, s, C, fix, coe, f0, f1, feat, rpart);
+  const EigenMail none{nullptr, nullptr, 0.0, 0};
+  hipLaunchKernelGGL(k_feature_eigen, dim3(grid), dim3(256), 0, s, C, fix, coe, f0, f1, feat, rpart, (mail && grid == 1) ? *mail : none);
   return grid;
 }
 
@@ -970,7 +983,8 @@ void launch_syrk(hipStream_t s, const double *Gt, int npad, int ntiles, const in
 // ------------------------------------------------------------------------------------------------
 // K4a: deterministic reductions into the all-reduce payload  red = [tiles | dacc | r]
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void reduce_tiles(const double *__restrict__ part, int SG, long tile_total, double *__restrict__ red,
+template <class Sink>
+__device__ __forceinline__ void reduce_tiles(const double *__restrict__ part, int SG, long tile_total, Sink sink,
                                              int bid, int nb) {
   for (long t = (long)bid * blockDim.x + threadIdx.x; t < tile_total; t += (long)nb * blockDim.x) {
     // fixed summation order (deterministic), four independent chains to keep loads in flight
@@ -984,13 +998,14 @@ __device__ __forceinline__ void reduce_tiles(const double *__restrict__ part, in
       s3 += pp[(size_t)(g + 3) * tile_total];
     }
     for (; g < SG; g++) s0 += pp[(size_t)g * tile_total];
-    red[t] = (s0 + s1) + (s2 + s3);
+    sink(t, (s0 + s1) + (s2 + s3));
   }
 }
 
 // block-sparse plan: the partial tiles of job j are slots ptr[j] .. ptr[j+1]-1 (chunk order: deterministic)
+template <class Sink>
 __device__ __forceinline__ void reduce_tiles_csr(const double *__restrict__ part, const int *__restrict__ ptr, long tile_total,
-                                                 double *__restrict__ red, int bid, int nb) {
+                                                 Sink sink, int bid, int nb) {
   for (long t = (long)bid * blockDim.x + threadIdx.x; t < tile_total; t += (long)nb * blockDim.x) {
     const int job = (int)(t / TILE_ELEMS);
     const long e = t - (long)job * TILE_ELEMS;
@@ -1004,7 +1019,7 @@ __device__ __forceinline__ void reduce_tiles_csr(const double *__restrict__ part
       a3 += part[(size_t)(g + 3) * TILE_ELEMS + e];
     }
     for (; g < s1; g++) a0 += part[(size_t)g * TILE_ELEMS + e];
-    red[t] = (a0 + a1) + (a2 + a3);
+    sink(t, (a0 + a1) + (a2 + a3));
   }
 }
 
@@ -1055,8 +1070,9 @@ __global__ __launch_bounds__(256) void k_reduce_all(const double *__restrict__ p
                                                     int tile_blocks, const double *__restrict__ dpart, int nblk, int dacc_len, int dacc_cap,
                                                     const double *__restrict__ rpart, int nr, double *__restrict__ red, long dacc_off, long r_off) {
   if ((int)blockIdx.x < tile_blocks) {
-    if (csr_ptr) reduce_tiles_csr(part, csr_ptr, tile_total, red, blockIdx.x, tile_blocks);
-    else reduce_tiles(part, SG, tile_total, red, blockIdx.x, tile_blocks);
+    auto to_payload = [&](long t, double v) { red[t] = v; };
+    if (csr_ptr) reduce_tiles_csr(part, csr_ptr, tile_total, to_payload, blockIdx.x, tile_blocks);
+    else reduce_tiles(part, SG, tile_total, to_payload, blockIdx.x, tile_blocks);
   } else {
     reduce_dacc(dpart, nblk, dacc_len, dacc_cap, rpart, nr, red + dacc_off, red + r_off, (int)blockIdx.x - tile_blocks);
   }
@@ -1148,5 +1164,10 @@ void launch_assemble(hipStream_t s, int form, const double *red, long dacc_off, 
   else
     hipLaunchKernelGGL(k_assemble<1>, dim3(grid), dim3(256), 0, s, red, dacc_off, tileIJ, ntiles, W, H, g, r_in, r_out);
 }
+
+// (Measured and rejected, round 4, profiles/r04h_ticket_fusions.txt: K4 as ONE launch on contexts without a transport -- the tile workgroups
+// write H themselves, the workgroup that draws the last ticket adds the block diagonal and writes g -- bit-identical and 0.294 instead of
+// 0.055 ms at config 2, 0.185 instead of 0.026 on the shipped window: a ticket is a device-scope release per workgroup, i.e. a write-back
+// of that XCD's L2, thousands of times per launch.  The same pattern in k_feature_eigen cost 0.02 ms at 196 workgroups.)
 
 }  // namespace balm

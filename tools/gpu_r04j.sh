@@ -1,0 +1,7 @@
+#!/bin/bash
+# Tenth GPU call of round 4: k_solve_small with the build's index arithmetic done once per thread -- tests, timeline, timings.
+REPO=$(pwd); OUT=$REPO/gpurun_out/r04j; mkdir -p $OUT
+timeout 600 python -m pytest tests/test_gpu_solve.py -q -m gpu -x -k "small" > $OUT/pytest_small.txt 2>&1 < /dev/null; echo "pytest small rc=$?"; tail -3 $OUT/pytest_small.txt
+timeout 300 python tools/small_trace.py 8 16 20 24 > $OUT/small_trace.txt 2>&1 < /dev/null; cat $OUT/small_trace.txt | cut -c1-400
+timeout 300 python tools/bench_solve.py 4 8 12 16 20 24 > $OUT/solve_small.txt 2>&1 < /dev/null; cut -c1-30,100-250 $OUT/solve_small.txt
+timeout 300 python tools/bench_small.py > $OUT/small.txt 2>&1 < /dev/null; tail -5 $OUT/small.txt
