@@ -517,7 +517,12 @@ __global__ __launch_bounds__(256) void k_feature_factors(const double *__restric
                                                          const double *__restrict__ poses,
                                                          const double *__restrict__ feat, int W, int Wc, int npad, int f0,
                                                          int f1, double *__restrict__ Gt,
-                                                         double *__restrict__ dpart, const int *__restrict__ slot) {
+                                                         double *__restrict__ dpart, const int *__restrict__ slot, int staged) {
+  // staged (round 4, the default wherever the LDS has room): a lane's six values of a Gt column are 48 contiguous bytes, a wavefront's 64 poses
+  // 3 KB -- written lane by lane as three 16-byte stores, every store instruction touches a THIRD of each 48-byte segment of 24 cache lines,
+  // three times over.  Through a 3 KB staging block per wavefront in LDS the same bytes leave as three stores of 1 KB each, consecutive lanes
+  // consecutive 16 bytes: 0.554 -> 0.444 ms at config 2 (2.24 GB at 5.05 TB/s, 0.80 of the copy rate; profiles/r04l_factors_staged.txt).
+  // Bit for bit the same Gt.  (Contiguous feature ranges per workgroup instead of every gridDim-th feature: +0.02 ms, rejected.)
   constexpr int DACC = FORM == 0 ? DACC_LEFT : DACC_RIGHT;
   extern __shared__ __attribute__((aligned(16))) double sm[];
   // blockIdx.y = chunk of Wc poses (one chunk = the whole window up to MAX_W_LDS poses)
@@ -543,8 +548,8 @@ __global__ __launch_bounds__(256) void k_feature_factors(const double *__restric
   __syncthreads();
 
   // cluster of (feature a, pose i): ten coalesced streams, loaded one feature ahead of its use.  (Two features ahead -- two
-  // register sets, the loop unrolled by two, 226 VGPRs -- measured SLOWER at config 2: 0.584 vs 0.551 ms, round 3; the kernel
-  // moves 2.24 GB at 4.1 TB/s, 64 % of it writes, and is not short of loads in flight.)
+  // register sets, the loop unrolled by two, 226 VGPRs -- measured SLOWER at config 2: 0.584 vs 0.551 ms, round 3: the kernel
+  // was not short of loads in flight; it was short of well-formed stores, see `staged` above.)
   double nxt[10];
   auto fetch = [&](int a, int i) {
     const double *ca = cl + (size_t)a * 10 * W + i;
@@ -552,20 +557,30 @@ __global__ __launch_bounds__(256) void k_feature_factors(const double *__restric
     for (int c = 0; c < 10; c++) nxt[c] = ca[(size_t)c * W];
   };
   const int i_first = p0 + (threadIdx.x < (unsigned)wc ? (int)threadIdx.x : 0);
-  if (f0 + (int)blockIdx.x < f1) fetch(f0 + blockIdx.x, i_first);
+  const int a_begin = f0 + (int)blockIdx.x, a_end = f1, a_step = (int)gridDim.x;
+  const int lane = threadIdx.x & 63;
+  double *stg = sm + (12 + DACC) * Wc + (threadIdx.x >> 6) * 384;      // (staged only: 3 KB per wavefront behind the accumulators)
+  if (a_begin < a_end) fetch(a_begin, i_first);
 
-  for (int a = f0 + blockIdx.x; a < f1; a += gridDim.x) {
+  for (int a = a_begin; a < a_end; a += a_step) {
     const double *f = feat + (size_t)a * FEAT_STRIDE;
     const FeatRec fr = {f[FT_NN], 1.0 / f[FT_NN], {f[FT_VBAR], f[FT_VBAR + 1], f[FT_VBAR + 2]}, {f[FT_U0], f[FT_U0 + 1], f[FT_U0 + 2]},
                         {f[FT_U1], f[FT_U1 + 1], f[FT_U1 + 2]}, {f[FT_U2], f[FT_U2 + 1], f[FT_U2 + 2]}, f[FT_C0], f[FT_C1], f[FT_C2], f[FT_COE]};
     const double *ca = cl + (size_t)a * 10 * W;
     double *g0 = Gt + (size_t)(3 * (slot ? slot[a] : a - f0)) * npad;      // slot: the block-sparse plan's column order
 
-    for (int il = threadIdx.x; il < wc; il += blockDim.x) {
-      const int i = p0 + il;
+    for (int ilb = 0; ilb < wc; ilb += blockDim.x) {
+      const int il = ilb + (int)threadIdx.x;
+      if (il - lane >= wc) break;            // (a whole wavefront beyond the window)
+      const bool act = il < wc;
+      const int i = p0 + (act ? il : wc - 1);
       double col0[6], col1[6], col2[6];
       double P[6], v[3];
-      if (il == (int)threadIdx.x) {         // first pose slot of this lane: prefetched
+      if (!act) {
+#pragma unroll
+        for (int c = 0; c < 6; c++) P[c] = 0.0;
+        v[0] = v[1] = v[2] = 0.0;
+      } else if (il == (int)threadIdx.x) {         // first pose slot of this lane: prefetched
 #pragma unroll
         for (int c = 0; c < 6; c++) P[c] = nxt[c];
 #pragma unroll
@@ -576,14 +591,38 @@ __global__ __launch_bounds__(256) void k_feature_factors(const double *__restric
 #pragma unroll
         for (int c = 0; c < 3; c++) v[c] = ca[(size_t)(6 + c) * W + i];
       }
-      const double N = il == (int)threadIdx.x ? nxt[9] : ca[(size_t)9 * W + i];
-      if (il == (int)threadIdx.x && a + (int)gridDim.x < f1) fetch(a + gridDim.x, i_first);
-      obs_factors<FORM>(fr, P, v, N, sp, sacc, Wc, il, col0, col1, col2);
-      // (Measured and rejected, round 4, profiles/r04d_factors_ab.txt: streaming (nontemporal) stores -- 0.555 vs 0.553 ms; the lane's
-      // pose in twelve registers instead of the LDS table, i.e. 43 KB per workgroup and THREE workgroups per CU -- 0.565 vs 0.554.)
-      store6(g0 + 6 * i, col0);
-      store6(g0 + (size_t)npad + 6 * i, col1);
-      store6(g0 + (size_t)2 * npad + 6 * i, col2);
+      const double N = !act ? 0.0 : (il == (int)threadIdx.x ? nxt[9] : ca[(size_t)9 * W + i]);
+      if (il == (int)threadIdx.x && a + a_step < a_end) fetch(a + a_step, i_first);
+      obs_factors<FORM>(fr, P, v, N, sp, sacc, Wc, act ? il : wc - 1, col0, col1, col2);
+      // (Measured and rejected on the lane-by-lane stores, round 4, profiles/r04d_factors_ab.txt: streaming (nontemporal) stores -- 0.555 vs
+      // 0.553 ms; the lane's pose in twelve registers instead of the LDS table, i.e. THREE workgroups per CU -- 0.565 vs 0.554.)
+      if (!staged) {
+        if (act) {
+          store6(g0 + 6 * i, col0);
+          store6(g0 + (size_t)npad + 6 * i, col1);
+          store6(g0 + (size_t)2 * npad + 6 * i, col2);
+        }
+      } else {
+        // the wavefront's block of a column: 6 x (its poses inside the window) doubles, contiguous from pose p0 + il - lane on
+        const int nval = 6 * min(64, wc - (il - lane));
+        double *gw = g0 + 6 * (size_t)(p0 + il - lane);
+        auto flush = [&](const double col[6], double *gcol) {
+          d2 *q = reinterpret_cast<d2 *>(stg + 6 * lane);
+          d2 t0 = {col[0], col[1]}, t1 = {col[2], col[3]}, t2 = {col[4], col[5]};
+          q[0] = t0; q[1] = t1; q[2] = t2;
+          asm volatile("" ::: "memory");       // (one wavefront: its LDS operations are performed in order)
+#pragma unroll
+          for (int j = 0; j < 3; j++) {
+            const int idx = 2 * (64 * j + lane);
+            const d2 w = *reinterpret_cast<const d2 *>(stg + idx);
+            if (idx < nval) *reinterpret_cast<d2 *>(gcol + idx) = w;
+          }
+          asm volatile("" ::: "memory");
+        };
+        flush(col0, gw);
+        flush(col1, gw + (size_t)npad);
+        flush(col2, gw + (size_t)2 * npad);
+      }
     }
   }
   __syncthreads();
@@ -745,9 +784,15 @@ static size_t factors_lds(int W, int form) {
   const int dacc = form == 0 ? DACC_LEFT : DACC_RIGHT;
   return (size_t)(12 + dacc) * factors_chunk(W) * sizeof(double);
 }
+constexpr size_t FACTORS_STAGE_BYTES = 4 * 384 * sizeof(double);      // a 3 KB staging block per wavefront
+// coalesced Gt stores through LDS wherever the staging blocks fit beside the accumulators (not for 470 < W <= 480); BALM_FACTORS_STAGE=0: A/B, tests
+static bool factors_staged(int W, int form) {
+  const char *es = getenv("BALM_FACTORS_STAGE");
+  return !(es && es[0] == '0') && factors_lds(W, form) + FACTORS_STAGE_BYTES <= 160 * 1024;
+}
 
 int factors_grid(int W, int nfeat, int form) {
-  size_t lds = factors_lds(W, form);
+  size_t lds = factors_lds(W, form) + (factors_staged(W, form) ? FACTORS_STAGE_BYTES : 0);
   int per_cu = (int)(160 * 1024 / lds);
   if (per_cu < 1) per_cu = 1;
   if (per_cu > 4) per_cu = 4;
@@ -785,12 +830,14 @@ int launch_moments_factors(hipStream_t s, int form, const double *cl, const doub
 void launch_factors(hipStream_t s, int form, const double *cl, const double *poses, const double *feat, int W,
                     int npad, int f0, int f1, double *Gt, double *dpart, int nblk, const int *slot) {
   const int Wc = factors_chunk(W), chunks = (W + Wc - 1) / Wc;
-  const size_t lds = factors_lds(W, form);
+  size_t lds = factors_lds(W, form);
   int bs = W <= 64 ? 64 : (W <= 128 ? 128 : 256);
+  const int staged = factors_staged(W, form);
+  if (staged) lds += FACTORS_STAGE_BYTES;
   if (form == 0)
-    hipLaunchKernelGGL(k_feature_factors<0>, dim3(nblk, chunks), dim3(bs), lds, s, cl, poses, feat, W, Wc, npad, f0, f1, Gt, dpart, slot);
+    hipLaunchKernelGGL(k_feature_factors<0>, dim3(nblk, chunks), dim3(bs), lds, s, cl, poses, feat, W, Wc, npad, f0, f1, Gt, dpart, slot, staged);
   else
-    hipLaunchKernelGGL(k_feature_factors<1>, dim3(nblk, chunks), dim3(bs), lds, s, cl, poses, feat, W, Wc, npad, f0, f1, Gt, dpart, slot);
+    hipLaunchKernelGGL(k_feature_factors<1>, dim3(nblk, chunks), dim3(bs), lds, s, cl, poses, feat, W, Wc, npad, f0, f1, Gt, dpart, slot, staged);
 }
 
 // ------------------------------------------------------------------------------------------------

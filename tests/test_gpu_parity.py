@@ -633,3 +633,20 @@ def test_device_eigen_matches_lapack_near_degenerate(gap):
         assert abs(r - rn) <= 1e-9 * abs(rn)
         assert rel_err(g, gn) < 1e-10 and rel_err(H, Hn) < 1e-12
     c.close()
+
+
+@pytest.mark.parametrize("W,F,form", [(20, 60, 0), (100, 300, 1), (200, 2000, 0), (230, 40, 0), (300, 64, 1), (475, 24, 0), (700, 10, 0)])
+def test_factor_kernel_store_paths_agree(W, F, form, monkeypatch):
+    """k_feature_factors' two ways of writing Gt -- lane by lane (48 bytes per pose and column) and, the default where the LDS has room,
+    coalesced through a staging block per wavefront -- must leave bit for bit the same H, g and residual (bavoxel.hpp:365-418 is what both
+    evaluate); window sizes with one, two and four wavefronts of poses, a last wavefront that is partly empty, a window whose accumulators
+    leave no room for the staging (475) and a pose-chunked one (700)"""
+    sc, _ = make_scene(300 + W, W, F, 4, drop=0.25, mode=1)
+    out = []
+    for stage in ("0", "1"):
+        monkeypatch.setenv("BALM_FACTORS_STAGE", stage)
+        c = ctx_for(sc)
+        out.append(c.evaluate(form, sc.poses_init))
+        c.close()
+    (H0, g0, r0), (H1, g1, r1) = out
+    assert np.array_equal(H0, H1) and np.array_equal(g0, g1) and r0 == r1

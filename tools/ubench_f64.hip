@@ -198,6 +198,16 @@ int main() {
       report("write-only float4, 16 blocks/CU", t, 1.0 * n * 32);
       t = time_ms([&] { hipLaunchKernelGGL((k_fill16<true>), dim3(CU * 16), dim3(256), 0, 0, b16, n16); });
       report("write-only float4, 16 blocks/CU, nontemporal", t, 1.0 * n * 32);
+      // (the copy is fastest with one element per thread -- dispatch order = address order; is the write rate a property of the grid-stride form?)
+      t = time_ms([&] { hipLaunchKernelGGL((k_fill16<false>), dim3((unsigned)(n16 / 256)), dim3(256), 0, 0, b16, n16); });
+      report("write-only float4, one element per thread (8M blocks)", t, 1.0 * n * 32);
+      t = time_ms([&] { hipLaunchKernelGGL((k_fill16<true>), dim3((unsigned)(n16 / 256)), dim3(256), 0, 0, b16, n16); });
+      report("write-only float4, one element per thread, nontemporal", t, 1.0 * n * 32);
+      for (int bpc : {2, 4, 64}) {
+        char nm[96]; snprintf(nm, sizeof nm, "write-only float4, %d blocks/CU", bpc);
+        t = time_ms([&] { hipLaunchKernelGGL((k_fill16<false>), dim3(CU * bpc), dim3(256), 0, 0, b16, n16); });
+        report(nm, t, 1.0 * n * 32);
+      }
     }
     hipFree(a); hipFree(b);
   }
