@@ -785,14 +785,18 @@ static size_t factors_lds(int W, int form) {
   return (size_t)(12 + dacc) * factors_chunk(W) * sizeof(double);
 }
 constexpr size_t FACTORS_STAGE_BYTES = 4 * 384 * sizeof(double);      // a 3 KB staging block per wavefront
-// coalesced Gt stores through LDS wherever the staging blocks fit beside the accumulators (not for 470 < W <= 480); BALM_FACTORS_STAGE=0: A/B, tests
-static bool factors_staged(int W, int form) {
-  const char *es = getenv("BALM_FACTORS_STAGE");
-  return !(es && es[0] == '0') && factors_lds(W, form) + FACTORS_STAGE_BYTES <= 160 * 1024;
+// Coalesced Gt stores through LDS where the kernel is bandwidth-bound -- a million observations or more (config 2: ten million) -- and the
+// staging blocks fit beside the accumulators (not for 470 < W <= 480).  Below that a workgroup sees a handful of features and the extra LDS round
+// trip per feature shows instead: the shipped window (0.4 M observations) 0.029 -> 0.037 ms (profiles/r04m_realshape_step.txt).
+// BALM_FACTORS_STAGE=0 / 1 forces either (A/B runs, tests).
+static bool factors_staged(int W, int nfeat, int form) {
+  if (factors_lds(W, form) + FACTORS_STAGE_BYTES > 160 * 1024) return false;
+  if (const char *es = getenv("BALM_FACTORS_STAGE")) return es[0] != '0';
+  return (long)nfeat * W >= 1000000;
 }
 
 int factors_grid(int W, int nfeat, int form) {
-  size_t lds = factors_lds(W, form) + (factors_staged(W, form) ? FACTORS_STAGE_BYTES : 0);
+  size_t lds = factors_lds(W, form) + (factors_staged(W, nfeat, form) ? FACTORS_STAGE_BYTES : 0);
   int per_cu = (int)(160 * 1024 / lds);
   if (per_cu < 1) per_cu = 1;
   if (per_cu > 4) per_cu = 4;
@@ -832,7 +836,7 @@ void launch_factors(hipStream_t s, int form, const double *cl, const double *pos
   const int Wc = factors_chunk(W), chunks = (W + Wc - 1) / Wc;
   size_t lds = factors_lds(W, form);
   int bs = W <= 64 ? 64 : (W <= 128 ? 128 : 256);
-  const int staged = factors_staged(W, form);
+  const int staged = factors_staged(W, f1 - f0, form);
   if (staged) lds += FACTORS_STAGE_BYTES;
   if (form == 0)
     hipLaunchKernelGGL(k_feature_factors<0>, dim3(nblk, chunks), dim3(bs), lds, s, cl, poses, feat, W, Wc, npad, f0, f1, Gt, dpart, slot, staged);

@@ -33,8 +33,9 @@ import numpy as np  # noqa: E402
 
 FP64_PEAK_TFLOPS = 78.6     # MI355X FP64 matrix = vector peak (MI355X_MICROARCH.md: 157.3 TF fp32 / 2)
 HBM_PEAK_TBS = 8.0          # MI355X_MICROARCH.md: HBM3E ~8 TB/s
-COPY_RATE_TBS = 6.21        # what the best plain copy kernel moves on the box (read + write; float4, one element per thread): tools/ubench_f64.hip,
-                            # profiles/r04c_ubench_f64.txt (the guide: 6.29).  Round 3 quoted 4.99 = its double4 grid-stride copy.  Write-only: 4.09 TB/s.
+COPY_RATE_TBS = 6.29        # what the best plain copy kernel moves on the box (read + write; float4, one element per thread): tools/ubench_f64.hip,
+                            # profiles/r04k_small_build_and_write_rate.txt (6.21 in r04c; the guide: 6.29).  Round 3 quoted 4.99 = its double4 grid-stride
+                            # copy.  Read-only 6.25, write-only 6.95 TB/s with one element per thread (4.0-4.2 in the grid-stride form).
 F_SINGLE = 50000            # BASELINE configs[2]
 F_SHARDED_TOTAL = 200000    # BASELINE configs[3]
 GOLDEN_SHARDED = os.path.join(ROOT, "tests", "golden", "lm_big_w200_f200000.npz")       # the reference's own run of configs[3]
