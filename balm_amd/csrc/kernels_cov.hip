@@ -63,8 +63,12 @@ constexpr int COV_DACC = 21;      // upper triangle of the 6x6 block S_j, row-ma
 // One workgroup per feature at a time, one lane per pose (like k_feature_factors).  Phase 1 computes the
 // pose's At / Rr rows (parked in the X / Y columns), its share of Q and of S_j; after the block-wide sum of Q
 // every lane factors the 3x3 Q redundantly and turns its own rows into X and Y.
+// ONEPASS (round 4; windows of up to 256 poses: one pose per lane): the pose's At / Rr rows stay in REGISTERS across the block-wide sum
+// instead of being parked in the X / Y columns (written as 8-byte pieces 48 bytes apart, read back the same way, written again), and the
+// finished X / Y columns leave through a 3 KB LDS staging block per wavefront as fully coalesced 16-byte stores, as k_feature_factors'
+// Gt columns do (kernels_accum.hip).  Same arithmetic, same order: bit for bit the two-pass result.
 // ------------------------------------------------------------------------------------------------
-template <bool EXPLICIT>
+template <bool EXPLICIT, bool ONEPASS>
 __global__ __launch_bounds__(256) void k_cov_factors(const double *__restrict__ cl, const double *__restrict__ ccov,
                                                      double sigma2, const double *__restrict__ poses,
                                                      const double *__restrict__ feat, int W, int npad, int F,
@@ -96,12 +100,18 @@ __global__ __launch_bounds__(256) void k_cov_factors(const double *__restrict__ 
     double *gx = Gx + (size_t)(3 * a) * npad, *gy = Gy + (size_t)(3 * a) * npad;
     double q[6] = {0, 0, 0, 0, 0, 0};
 
+    double at[6][3], rr[6][3];               // (ONEPASS: alive until the columns are written)
+#pragma unroll
+    for (int r = 0; r < 6; r++)
+#pragma unroll
+      for (int c = 0; c < 3; c++) at[r][c] = rr[r][c] = 0.0;
     for (int i = threadIdx.x; i < W; i += blockDim.x) {
-      double at[6][3], rr[6][3];
+      if (!ONEPASS) {
 #pragma unroll
-      for (int r = 0; r < 6; r++)
+        for (int r = 0; r < 6; r++)
 #pragma unroll
-        for (int c = 0; c < 3; c++) at[r][c] = rr[r][c] = 0.0;
+          for (int c = 0; c < 3; c++) at[r][c] = rr[r][c] = 0.0;
+      }
       const double N = ca[(size_t)9 * W + i];
       if ((int)N > 0) {
         double P[6], v[3], R[9], p[3];
@@ -331,13 +341,15 @@ __global__ __launch_bounds__(256) void k_cov_factors(const double *__restrict__ 
             for (int k = r; k < 6; k++) sacc[(t++) * W + i] += w2 * S6[r][k];
         }
       }
+      if (!ONEPASS) {
 #pragma unroll
-      for (int c = 0; c < 3; c++)
+        for (int c = 0; c < 3; c++)
 #pragma unroll
-        for (int r = 0; r < 6; r += 2) {
-          *reinterpret_cast<d2 *>(gx + (size_t)c * npad + 6 * i + r) = (d2){at[r][c], at[r + 1][c]};
-          *reinterpret_cast<d2 *>(gy + (size_t)c * npad + 6 * i + r) = (d2){rr[r][c], rr[r + 1][c]};
-        }
+          for (int r = 0; r < 6; r += 2) {
+            *reinterpret_cast<d2 *>(gx + (size_t)c * npad + 6 * i + r) = (d2){at[r][c], at[r + 1][c]};
+            *reinterpret_cast<d2 *>(gy + (size_t)c * npad + 6 * i + r) = (d2){rr[r][c], rr[r + 1][c]};
+          }
+      }
     }
     for (int r = 6 * W + threadIdx.x; r < npad; r += blockDim.x)
 #pragma unroll
@@ -377,7 +389,40 @@ __global__ __launch_bounds__(256) void k_cov_factors(const double *__restrict__ 
       Ci[2][1] = -C[2][1] * i1 * i2;
       Ci[2][0] = -(C[2][0] * Ci[0][0] + C[2][1] * Ci[1][0]) * i2;
     }
-    // phase 2: X = coe (At Cq + Y'), Y = coe Y', Y' = Rr Cq^-T  (each lane re-reads the rows it parked)
+    // phase 2: X = coe (At Cq + Y'), Y = coe Y', Y' = Rr Cq^-T
+    if (ONEPASS) {
+      // from the registers; a wavefront's block of a column (6 x its poses inside the window, contiguous) through the staging block
+      const int i0 = (int)threadIdx.x - lane;                   // the wavefront's first pose
+      if (i0 < W) {
+        const int nval = 6 * min(64, W - i0);
+        double *stg = sm + (12 + COV_DACC) * W + wv * 384;
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+          double xc[6], yc[6];
+#pragma unroll
+          for (int r = 0; r < 6; r++) {
+            const double y = rr[r][0] * Ci[c][0] + rr[r][1] * Ci[c][1] + rr[r][2] * Ci[c][2];
+            const double x = at[r][0] * C[0][c] + at[r][1] * C[1][c] + at[r][2] * C[2][c];
+            xc[r] = coe * (x + y);
+            yc[r] = coe * y;
+          }
+          auto flush = [&](const double col[6], double *gcol) {
+            d2 *q2 = reinterpret_cast<d2 *>(stg + 6 * lane);
+            q2[0] = (d2){col[0], col[1]}; q2[1] = (d2){col[2], col[3]}; q2[2] = (d2){col[4], col[5]};
+            asm volatile("" ::: "memory");       // (one wavefront: its LDS operations are performed in order)
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+              const int idx = 2 * (64 * j + lane);
+              const d2 w = *reinterpret_cast<const d2 *>(stg + idx);
+              if (idx < nval) *reinterpret_cast<d2 *>(gcol + idx) = w;
+            }
+            asm volatile("" ::: "memory");
+          };
+          flush(xc, gx + (size_t)c * npad + 6 * i0);
+          flush(yc, gy + (size_t)c * npad + 6 * i0);
+        }
+      }
+    } else
     for (int i = threadIdx.x; i < W; i += blockDim.x) {
 #pragma unroll
       for (int r = 0; r < 6; r++) {
@@ -533,8 +578,14 @@ inline int grid1(long total, int bs, int cap) {
 
 }  // namespace
 
+static bool cov_onepass(int W) {          // one pose per lane, and room for the staging blocks; BALM_COV_ONEPASS=0: the two-pass kernel (A/B, tests)
+  const char *e = getenv("BALM_COV_ONEPASS");
+  return W <= 256 && !(e && e[0] == '0');
+}
+constexpr size_t COV_STAGE_BYTES = 4 * 384 * sizeof(double);
+
 int cov_factors_grid(int W, int F) {
-  size_t lds = (size_t)(12 + COV_DACC) * W * sizeof(double);
+  size_t lds = (size_t)(12 + COV_DACC) * W * sizeof(double) + (cov_onepass(W) ? COV_STAGE_BYTES : 0);
   int per_cu = (int)(150 * 1024 / lds);
   if (per_cu < 1) per_cu = 1;
   if (per_cu > 4) per_cu = 4;
@@ -547,19 +598,22 @@ int cov_factors_grid(int W, int F) {
 // `feat` were computed for
 // see prepare_device_accum(): per-device attribute, set once per context by balm_create
 hipError_t prepare_device_cov() {
-  hipError_t e = hipFuncSetAttribute((const void *)k_cov_factors<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);   // + static sq
-  if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_cov_factors<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+  hipError_t e = hipFuncSetAttribute((const void *)k_cov_factors<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);   // + static sq
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_cov_factors<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_cov_factors<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_cov_factors<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
   return e;
 }
 
 void launch_cov_factors(hipStream_t s, const double *cl, const double *ccov, double sigma2, const double *poses,
                         const double *feat, int W, int npad, int F, double *Gx, double *Gy, double *dpart, int nblk) {
-  size_t lds = (size_t)(12 + COV_DACC) * W * sizeof(double);
+  const bool one = cov_onepass(W);
+  size_t lds = (size_t)(12 + COV_DACC) * W * sizeof(double) + (one ? COV_STAGE_BYTES : 0);
   int bs = W <= 64 ? 64 : (W <= 128 ? 128 : 256);
-  if (ccov)
-    hipLaunchKernelGGL(k_cov_factors<true>, dim3(nblk), dim3(bs), lds, s, cl, ccov, sigma2, poses, feat, W, npad, F, Gx, Gy, dpart);
-  else
-    hipLaunchKernelGGL(k_cov_factors<false>, dim3(nblk), dim3(bs), lds, s, cl, ccov, sigma2, poses, feat, W, npad, F, Gx, Gy, dpart);
+#define BALM_COV_FACTORS(E, O) hipLaunchKernelGGL((k_cov_factors<E, O>), dim3(nblk), dim3(bs), lds, s, cl, ccov, sigma2, poses, feat, W, npad, F, Gx, Gy, dpart)
+  if (ccov) { if (one) BALM_COV_FACTORS(true, true); else BALM_COV_FACTORS(true, false); }
+  else { if (one) BALM_COV_FACTORS(false, true); else BALM_COV_FACTORS(false, false); }
+#undef BALM_COV_FACTORS
 }
 
 void launch_cov_reduce_tiles(hipStream_t s, const double *part, int SG, long tile_total, double *red) {

@@ -269,3 +269,21 @@ def test_consistency_experiment_incremental_association():
     c.close()
     print("consistency experiment, incremental association: %d features, NEES %s" % (F, np.round(vals, 1)))
     assert np.all(np.abs(np.array(vals) - 600) < 6 * np.sqrt(1200))
+
+
+@pytest.mark.parametrize("seed,W,F,sparse,explicit", [(5, 20, 60, False, True), (6, 100, 90, True, False), (7, 200, 64, True, False), (8, 70, 40, False, True)])
+def test_cov_factor_kernel_paths_agree(seed, W, F, sparse, explicit, monkeypatch):
+    """k_cov_factors keeps a pose's At / Rr rows in registers across the block-wide sum of Q and writes the X / Y columns once, coalesced
+    (windows of <= 256 poses, the default) or parks them in the columns and re-reads them (BALM_COV_ONEPASS=0, wider windows): same
+    arithmetic in the same order (BAs_left.hpp:418-450 is what both evaluate) -> the same covariance bit for bit; one, two and four
+    wavefronts of poses, explicit cluster covariances and the isotropic closed form"""
+    cl, fix, poses, _, _ = anchored_scene(seed, W, F, 12, sparse)
+    cc = npo.cluster_noise_cov_closed_form(cl, 0.05) if explicit else None
+    out = []
+    for mode in ("0", "1"):
+        monkeypatch.setenv("BALM_COV_ONEPASS", mode)
+        c = capi.Context(W)
+        c.set_features(cl, fix, np.ones(F))
+        out.append(c.pose_covariance(poses, cluster_cov=cc) if explicit else c.pose_covariance(poses, point_sigma=0.05))
+        c.close()
+    assert np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][0], out[1][0])
