@@ -548,8 +548,8 @@ __global__ __launch_bounds__(256) void k_feature_factors(const double *__restric
   __syncthreads();
 
   // cluster of (feature a, pose i): ten coalesced streams, loaded one feature ahead of its use.  (Two features ahead -- two
-  // register sets, the loop unrolled by two, 226 VGPRs -- measured SLOWER at config 2: 0.584 vs 0.551 ms, round 3: the kernel
-  // was not short of loads in flight; it was short of well-formed stores, see `staged` above.)
+  // register sets, the loop unrolled by two -- measured SLOWER at config 2: 0.584 vs 0.551 ms in round 3, and again on top of the
+  // coalesced stores in round 4: 0.447 vs 0.437 ms, profiles/r04l_factors_staged.txt.  The kernel is not short of loads in flight.)
   double nxt[10];
   auto fetch = [&](int a, int i) {
     const double *ca = cl + (size_t)a * 10 * W + i;
