@@ -463,6 +463,17 @@ def main(argv=None):
     if accept is not None:
         accept.pop("_poses", None)
         out["acceptance"] = accept
+    if n_gpus > 1 and out["scaling"] == "strong" and F_total == F_SHARDED_TOTAL and os.path.exists(N1_TRACE):
+        # `value` at N = 1 is configs[2] (50 000 features), a 4x smaller problem than the one sharded here: the N = 1 point of THIS curve is the
+        # same 200 000-feature problem on one GPU, measured by the N = 1 bench run (strong_scaling_reference) and committed with its LM trace
+        try:
+            t1 = json.load(open(N1_TRACE)).get("timing")
+            if t1:
+                out["same_problem_on_one_gpu"] = {"iterations_per_sec": t1["iterations_per_sec"], "ms_per_step": t1["ms_per_step"],
+                                                  "source": "profiles/strong_scaling_n1_trace.json (" + t1.get("run", "the N = 1 bench run") + ")",
+                                                  "speedup_of_this_run": iters_per_s / t1["iterations_per_sec"]}
+        except Exception:
+            pass
     if n_gpus == 1 and not multi and not args.no_strong_ref and not args.no_cpu and args.features == 0 and W == 200:      # (--no-cpu: no extra legs at all)
         # the problem the N > 1 runs shard (BASELINE configs[3]: 200 000 features in total) on ONE GPU: the N = 1 point of the
         # strong-scaling curve (`value` above is configs[2], a 4x smaller problem, and not comparable with the N > 1 values)
@@ -509,6 +520,8 @@ def main(argv=None):
                     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
                     json.dump({"what": "balm_damping_iter (u0=0.01, <=10 it., >=20 planes) on configs[3], ONE GPU; rows: r1 r2 u v q q1 accepted",
                                "seed": args.seed, "W": W, "features_total": F_SHARDED_TOTAL, "pts": args.pts,
+                               "timing": {"what": "the same %d timed LM steps as the bench line, on this one GPU" % k4,
+                                          "ms_per_step": d4 / k4 * 1e3, "iterations_per_sec": k4 / d4},
                                "trace": acc["trace"], "poses": [[float(v) for v in row] for row in poses4]},
                               open(os.path.join(ROOT, "gpurun_out", "strong_scaling_n1_trace.json"), "w"))
                 except Exception:
