@@ -339,3 +339,40 @@ def test_small_window_kernel_lm_run(W, F, form):
     assert len(la) == len(lb) and np.allclose(la[:, :3], lb[:, :3], rtol=1e-9, atol=0) and np.abs(pa - pb).max() < 1e-10
     assert len(lc) == len(lb) and np.allclose(lc[:, :3], lb[:, :3], rtol=1e-12, atol=0) and np.abs(pc - pb).max() < 1e-12
     c.close()
+
+
+@pytest.mark.parametrize("W", [8, 20, 40, 200])
+def test_a_nan_in_the_hessian_neither_hangs_nor_sticks(W):
+    """A NaN on the diagonal (it takes part in the pivot ranking) or off it must come back as a non-finite step -- not as a hang, a crash or a
+    plausible-looking solution -- on the one-launch small-window kernel (W = 8, 20), the persistent chain (40, 200); and the context must
+    solve a clean system correctly right afterwards (Eigen's ldlt().solve() likewise just propagates the NaN: bavoxel.hpp:1113-1114)."""
+    H, g = _test_matrix(W, "spd", 5 * W)
+    u = 0.1
+    ref = np.linalg.solve(H + u * np.diag(np.diag(H)), -g)
+    c = capi.Context(W)
+    for where in ("diag", "off"):
+        Hb = H.copy()
+        if where == "diag":
+            Hb[7, 7] = np.nan
+        else:
+            Hb[5, 11] = Hb[11, 5] = np.nan
+        dx, q1 = c.solve_damped(Hb, g, u)
+        assert not np.all(np.isfinite(dx)), where
+        dx, q1 = c.solve_damped(H, g, u)
+        assert rel_err(dx, ref) < 1e-9, where
+    c.close()
+
+
+def test_lm_loop_reports_non_finite_input_on_a_small_window():
+    """NaN poses into balm_damping_iter on a window that takes the one-launch solve: BALM_ERR_NUMERIC, and the context stays usable"""
+    sc, _ = make_scene(77, 12, 80, 8, drop=0.1)
+    c = capi.Context(sc.W)
+    c.set_features(sc.clusters, None, sc.coeffs)
+    bad = sc.poses_init.copy()
+    bad[3, 9] = np.nan
+    with pytest.raises(capi.BalmError) as e:
+        c.damping_iter(bad, u0=0.01, max_iter=5)
+    assert e.value.code == capi.ERR_NUMERIC
+    out, lg = c.damping_iter(sc.poses_init, u0=0.01, max_iter=5)
+    assert np.all(np.isfinite(out)) and lg[-1, 1] < lg[0, 0]
+    c.close()
