@@ -512,7 +512,11 @@ __device__ __forceinline__ void obs_factors(const FeatRec &fr, const double P[6]
   }
 }
 
-template <int FORM>
+// REGS (round 4; the left form, one chunk, W <= blockDim: a lane owns ONE pose for the workgroup's whole life): the lane's pose and its DACC
+// accumulators live in registers instead of LDS -- no LDS traffic per observation but the staging block's (78 LDS instructions per observation
+// before): 0.434 -> 0.408 ms at config 2 on top of the coalesced stores, bit for bit the same sums (profiles/r04l_factors_staged.txt).  (Tried
+// in round 1 on the lane-by-lane stores: no gain -- the stores hid it.  The right form's 30 accumulators do not fit beside its working set.)
+template <int FORM, bool REGS>
 __global__ __launch_bounds__(256) void k_feature_factors(const double *__restrict__ cl,
                                                          const double *__restrict__ poses,
                                                          const double *__restrict__ feat, int W, int Wc, int npad, int f0,
@@ -529,8 +533,17 @@ __global__ __launch_bounds__(256) void k_feature_factors(const double *__restric
   const int p0 = blockIdx.y * Wc, wc = min(Wc, W - p0);
   double *sp = sm;                 // [12][Wc] poses of the chunk
   double *sacc = sm + 12 * Wc;     // [DACC][Wc]
+  double preg[12], racc[DACC];     // (REGS: the lane's own pose and accumulators)
+  if (REGS) {
+    const double *q = poses + 12 * (p0 + (threadIdx.x < (unsigned)wc ? (int)threadIdx.x : 0));
+#pragma unroll
+    for (int c = 0; c < 12; c++) preg[c] = q[c];
+#pragma unroll
+    for (int k = 0; k < DACC; k++) racc[k] = 0.0;
+  }
   // the pose table, ten loads per lane in flight at a time (rolled, this copy was one memory round trip per iteration -- ~10 dependent
   // trips at W = 200 before a workgroup's first feature: tools/find_rolled_copies.py)
+  if (!REGS)
   for (int t0 = 0; t0 < 12 * wc; t0 += 10 * (int)blockDim.x) {
     double pv[10];
 #pragma unroll
@@ -544,8 +557,10 @@ __global__ __launch_bounds__(256) void k_feature_factors(const double *__restric
       if (t < 12 * wc) { const int il = t / 12, c = t - 12 * il; sp[c * Wc + il] = pv[j]; }
     }
   }
-  for (int t = threadIdx.x; t < DACC * Wc; t += blockDim.x) sacc[t] = 0.0;
-  __syncthreads();
+  if (!REGS) {
+    for (int t = threadIdx.x; t < DACC * Wc; t += blockDim.x) sacc[t] = 0.0;
+    __syncthreads();
+  }
 
   // cluster of (feature a, pose i): ten coalesced streams, loaded one feature ahead of its use.  (Two features ahead -- two
   // register sets, the loop unrolled by two -- measured SLOWER at config 2: 0.584 vs 0.551 ms in round 3, and again on top of the
@@ -593,7 +608,8 @@ __global__ __launch_bounds__(256) void k_feature_factors(const double *__restric
       }
       const double N = !act ? 0.0 : (il == (int)threadIdx.x ? nxt[9] : ca[(size_t)9 * W + i]);
       if (il == (int)threadIdx.x && a + a_step < a_end) fetch(a + a_step, i_first);
-      obs_factors<FORM>(fr, P, v, N, sp, sacc, Wc, act ? il : wc - 1, col0, col1, col2);
+      if (REGS) obs_factors<FORM>(fr, P, v, N, preg, racc, 1, 0, col0, col1, col2);
+      else obs_factors<FORM>(fr, P, v, N, sp, sacc, Wc, act ? il : wc - 1, col0, col1, col2);
       // (Measured and rejected on the lane-by-lane stores, round 4, profiles/r04d_factors_ab.txt: streaming (nontemporal) stores -- 0.555 vs
       // 0.553 ms; the lane's pose in twelve registers instead of the LDS table, i.e. THREE workgroups per CU -- 0.565 vs 0.554.)
       if (!staged) {
@@ -625,8 +641,15 @@ __global__ __launch_bounds__(256) void k_feature_factors(const double *__restric
       }
     }
   }
-  __syncthreads();
   double *dp = dpart + (size_t)blockIdx.x * DACC * W + p0;
+  if (REGS) {                                        // a lane writes its own column of the partial sums: consecutive lanes, consecutive addresses
+    if (threadIdx.x < (unsigned)wc) {
+#pragma unroll
+      for (int k = 0; k < DACC; k++) dp[(size_t)k * W + threadIdx.x] = racc[k];
+    }
+    return;
+  }
+  __syncthreads();
   for (int t = threadIdx.x; t < DACC * wc; t += blockDim.x) {
     const int k = t / wc, il = t - k * wc;
     dp[(size_t)k * W + il] = sacc[k * Wc + il];
@@ -811,8 +834,9 @@ int factors_grid(int W, int nfeat, int form) {
 // The attribute belongs to the CURRENT device: balm_create calls this once per context, after hipSetDevice.
 hipError_t prepare_device_accum() {
   hipError_t e = hipFuncSetAttribute((const void *)k_world_moments, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_feature_factors<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_feature_factors<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_feature_factors<0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_feature_factors<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_feature_factors<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_moments_factors<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_moments_factors<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   return e;
@@ -838,10 +862,12 @@ void launch_factors(hipStream_t s, int form, const double *cl, const double *pos
   int bs = W <= 64 ? 64 : (W <= 128 ? 128 : 256);
   const int staged = factors_staged(W, f1 - f0, form);
   if (staged) lds += FACTORS_STAGE_BYTES;
-  if (form == 0)
-    hipLaunchKernelGGL(k_feature_factors<0>, dim3(nblk, chunks), dim3(bs), lds, s, cl, poses, feat, W, Wc, npad, f0, f1, Gt, dpart, slot, staged);
-  else
-    hipLaunchKernelGGL(k_feature_factors<1>, dim3(nblk, chunks), dim3(bs), lds, s, cl, poses, feat, W, Wc, npad, f0, f1, Gt, dpart, slot, staged);
+  const char *er = getenv("BALM_FACTORS_REGS");                     // 0: the accumulators in LDS at every window (A/B, tests)
+  const bool regs = form == 0 && chunks == 1 && W <= bs && !(er && er[0] == '0');
+#define BALM_FACTORS(F, R) hipLaunchKernelGGL((k_feature_factors<F, R>), dim3(nblk, chunks), dim3(bs), lds, s, cl, poses, feat, W, Wc, npad, f0, f1, Gt, dpart, slot, staged)
+  if (form == 0) { if (regs) BALM_FACTORS(0, true); else BALM_FACTORS(0, false); }
+  else BALM_FACTORS(1, false);
+#undef BALM_FACTORS
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -650,3 +650,20 @@ def test_factor_kernel_store_paths_agree(W, F, form, monkeypatch):
         c.close()
     (H0, g0, r0), (H1, g1, r1) = out
     assert np.array_equal(H0, H1) and np.array_equal(g0, g1) and r0 == r1
+
+
+@pytest.mark.parametrize("W,F", [(20, 60), (64, 700), (100, 300), (200, 2000), (256, 40)])
+def test_factor_kernel_accumulator_homes_agree(W, F, monkeypatch):
+    """k_feature_factors keeps a lane's pose and its 27 accumulators (gradient + block-diagonal sums, bavoxel.hpp:404-418) in registers for the left
+    form on windows of up to 256 poses, in LDS otherwise (BALM_FACTORS_REGS=0): the same additions in the same order -> bit for bit the same
+    H, g and residual; with the coalesced stores forced on and off"""
+    sc, _ = make_scene(400 + W, W, F, 4, drop=0.25, mode=1)
+    out = []
+    for regs, stage in (("0", "0"), ("1", "0"), ("0", "1"), ("1", "1")):
+        monkeypatch.setenv("BALM_FACTORS_REGS", regs)
+        monkeypatch.setenv("BALM_FACTORS_STAGE", stage)
+        c = ctx_for(sc)
+        out.append(c.evaluate(0, sc.poses_init))
+        c.close()
+    for H, g, r in out[1:]:
+        assert np.array_equal(H, out[0][0]) and np.array_equal(g, out[0][1]) and r == out[0][2]
