@@ -11,4 +11,4 @@ for f in glob.glob(root + "/*/*counter_collection.csv"):
 names = sorted({c for k in acc for c in acc[k]})
 print("kernel," + ",".join(names) + ",calls")
 for k, d in sorted(acc.items(), key=lambda kv: -sum(kv[1]["dur_ns"])):
-    print(k + "," + ",".join("%.6g" % (sum(d[c]) / len(d[c])) if c in d else "" for c in names) + ",%d" % max(len(v) for v in d.values()))
+    print('"' + k.replace('"', "'") + '",' + ",".join("%.6g" % (sum(d[c]) / len(d[c])) if c in d else "" for c in names) + ",%d" % max(len(v) for v in d.values()))
