@@ -1012,8 +1012,26 @@ SyrkPlan plan_syrk(int ntiles, long K) {
   SyrkPlan p;
   long steps = (K + 3) / 4;                         // MFMA k-steps (4 columns of Gt each)
   if (steps < 1) steps = 1;
-  long max_sg = steps / 64;                         // keep >= 256 columns per wave
+  long max_sg = steps / 64;                         // keep >= 256 columns per wave ...
   if (max_sg < 1) max_sg = 1;
+  {
+    // ... unless that leaves the chip mostly EMPTY: a small window has few jobs per k-slice (three at 20 poses, 13 at 64), and with >= 64
+    // k-steps per wave a 20-pose window with 150 features ran its whole K range in ONE wave per job -- 113 k-steps x 25 MFMAs in series,
+    // 83 of the iteration's 155 us (profiles/r04w_small_lm_kernels.txt).  While one round of the 1024 wave slots is not full: the shortest
+    // waves (whole turns of the prefetch ring) whose slices still fit that round, and as many slices as that length needs -- so the padding
+    // of K stays below one wave's length.  Their partial tiles (51 KB each, <= 52 MB in all) are noise next to the serial MFMAs they replace.
+    static const bool off = getenv("BALM_SYRK_SMALL") && getenv("BALM_SYRK_SMALL")[0] == '0';      // A/B
+    const long one_round = 1024 / ntiles > 1 ? 1024 / ntiles : 1;
+    if (max_sg < one_round && !off) {
+      long nst = SYRK_NBUF;
+      while ((steps + nst - 1) / nst > one_round) nst += SYRK_NBUF;
+      p.SG = (int)((steps + nst - 1) / nst);
+      p.nsteps = (int)nst;
+      p.Kpad = (int)(p.SG * nst * 4);
+      p.nblocks = (long)p.SG * ntiles;
+      return p;
+    }
+  }
   // ~4 resident rounds of the 1024 wave slots (128 per XCD): pick the slice count in that
   // neighbourhood whose last round is fullest (measured with 114 jobs per slice: 35 / 44 / 53 slices = 4 / 5 / 6
   // rounds are within 0.7 % of each other, the extra partial tiles of the larger counts cost it back in the reduce)
