@@ -1097,6 +1097,36 @@ __device__ __forceinline__ void reduce_tiles(const double *__restrict__ part, in
   }
 }
 
+// The same sums with FOUR LANES per element, one per chain (round 4): on a small window plan_syrk cuts K into many short waves (up to 341 slices at
+// 20 poses) over few tile elements (19 200), and one thread per element then walks its 341 partials four at a time -- ~85 dependent trips, the
+// largest kernel of a 20-pose / 3 000-feature iteration beside the solve.  Lane c of a quad adds chain c (g = c, c + 4, ...; the tail on chain 0) with
+// eight loads in flight, two xor-shuffles form (s0 + s1) + (s2 + s3): the additions of reduce_tiles in its order, bit for bit.
+template <class Sink>
+__device__ __forceinline__ void reduce_tiles_quads(const double *__restrict__ part, int SG, long tile_total, Sink sink, int bid, int nb) {
+  const int c = threadIdx.x & 3;
+  const int full = SG / 4;                           // rounds of four
+  // (a quad = four consecutive lanes of one wavefront: they share t and leave the loop together, so the shuffles below stay inside live lanes)
+  for (long t = ((long)bid * blockDim.x + threadIdx.x) >> 2; t < tile_total; t += ((long)nb * blockDim.x) >> 2) {
+    const double *pp = part + t + (size_t)c * tile_total;
+    double s = 0.0;
+    int m = 0;
+    for (; m + 3 < full; m += 4) {                    // four loads of the chain in flight (sixteen per element), added in order
+      const double v0 = pp[(size_t)(4 * m) * tile_total], v1 = pp[(size_t)(4 * m + 4) * tile_total],
+                   v2 = pp[(size_t)(4 * m + 8) * tile_total], v3 = pp[(size_t)(4 * m + 12) * tile_total];
+      s += v0;
+      s += v1;
+      s += v2;
+      s += v3;
+    }
+    for (; m < full; m++) s += pp[(size_t)(4 * m) * tile_total];
+    if (c == 0)
+      for (int g = 4 * full; g < SG; g++) s += part[(size_t)g * tile_total + t];
+    s += __shfl_xor(s, 1, 64);                       // (s0 + s1), (s2 + s3)
+    s += __shfl_xor(s, 2, 64);
+    if (c == 0) sink(t, s);
+  }
+}
+
 // block-sparse plan: the partial tiles of job j are slots ptr[j] .. ptr[j+1]-1 (chunk order: deterministic)
 template <class Sink>
 __device__ __forceinline__ void reduce_tiles_csr(const double *__restrict__ part, const int *__restrict__ ptr, long tile_total,
@@ -1163,10 +1193,11 @@ __device__ __forceinline__ void reduce_dacc(const double *__restrict__ dpart, in
 // [0, tile_blocks) sum the split-K partial tiles, the blocks behind them the per-pose accumulators and the residual partials
 __global__ __launch_bounds__(256) void k_reduce_all(const double *__restrict__ part, int SG, const int *__restrict__ csr_ptr, long tile_total,
                                                     int tile_blocks, const double *__restrict__ dpart, int nblk, int dacc_len, int dacc_cap,
-                                                    const double *__restrict__ rpart, int nr, double *__restrict__ red, long dacc_off, long r_off) {
+                                                    const double *__restrict__ rpart, int nr, double *__restrict__ red, long dacc_off, long r_off, int quads) {
   if ((int)blockIdx.x < tile_blocks) {
     auto to_payload = [&](long t, double v) { red[t] = v; };
     if (csr_ptr) reduce_tiles_csr(part, csr_ptr, tile_total, to_payload, blockIdx.x, tile_blocks);
+    else if (quads) reduce_tiles_quads(part, SG, tile_total, to_payload, blockIdx.x, tile_blocks);
     else reduce_tiles(part, SG, tile_total, to_payload, blockIdx.x, tile_blocks);
   } else {
     reduce_dacc(dpart, nblk, dacc_len, dacc_cap, rpart, nr, red + dacc_off, red + r_off, (int)blockIdx.x - tile_blocks);
@@ -1176,10 +1207,13 @@ __global__ __launch_bounds__(256) void k_reduce_all(const double *__restrict__ p
 void launch_reduce(hipStream_t s, const double *part, int SG, long tile_total, const double *dpart, int nblk,
                    int dacc_len, const double *rpart, int nr, double *red, long dacc_off, long r_off, const int *csr_ptr) {
   const int dacc_cap = (int)(r_off - dacc_off);        // every slot of the payload between the tiles and the residual is written
-  int grid = (int)((tile_total + 255) / 256);
+  // few tile elements, many k-slices (small windows since plan_syrk fills a round of wave slots with short waves): four lanes per element
+  static const bool no_quads = getenv("BALM_REDUCE_QUADS") && getenv("BALM_REDUCE_QUADS")[0] == '0';      // A/B
+  const int quads = !csr_ptr && !no_quads && tile_total <= 32768 && SG >= 8;      // (windows of up to ~30 poses: 0.121 -> 0.115 ms per iteration at W = 20 / F = 3000; at 64 poses one thread per element is the faster form: profiles/r04x_small_windows_syrk_plan.txt)
+  int grid = (int)(((quads ? 4 : 1) * tile_total + 255) / 256);
   if (grid > 8192) grid = 8192;
   hipLaunchKernelGGL(k_reduce_all, dim3(grid + (dacc_cap + 63) / 64), dim3(256), 0, s, part, SG, csr_ptr, tile_total, grid, dpart, nblk, dacc_len,
-                     dacc_cap, rpart, nr, red, dacc_off, r_off);
+                     dacc_cap, rpart, nr, red, dacc_off, r_off, quads);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -667,3 +667,21 @@ def test_factor_kernel_accumulator_homes_agree(W, F, monkeypatch):
         c.close()
     for H, g, r in out[1:]:
         assert np.array_equal(H, out[0][0]) and np.array_equal(g, out[0][1]) and r == out[0][2]
+
+
+@pytest.mark.parametrize("W,F,form", [(20, 150, 0), (20, 3000, 0), (24, 1000, 1), (7, 40, 0), (30, 700, 0)])
+def test_tile_reduction_with_four_lanes_per_element_is_the_one_lane_sum(W, F, form, monkeypatch):
+    """k_reduce_all sums the split-K partial tiles of a small window with four lanes per element (one per chain of reduce_tiles, the tail on
+    chain 0, (s0 + s1) + (s2 + s3) by shuffles) instead of one thread walking up to 341 partials: the same additions in the same order -> bit
+    for bit the same H (bavoxel.hpp:404-418); sizes whose slice counts are and are not multiples of four"""
+    sc, _ = make_scene(900 + W, W, F, 4, drop=0.2, mode=1)
+    monkeypatch.setenv("BALM_SYRK", "dense")
+    out = []
+    for q in ("0", "1"):
+        monkeypatch.setenv("BALM_REDUCE_QUADS", q)
+        c = ctx_for(sc)
+        out.append(c.evaluate(form, sc.poses_init))
+        out.append(c.evaluate(form, sc.poses_init, 3, F - 5))
+        c.close()
+    for k in (0, 1):
+        assert np.array_equal(out[k][0], out[2 + k][0]) and np.array_equal(out[k][1], out[2 + k][1]) and out[k][2] == out[2 + k][2]
