@@ -7,4 +7,4 @@ binding of that ABI), ``scene`` (synthetic-scene generator = the reference's ben
 the reference, ROS-free, on the GPU path), ``sliding`` (a sliding-window BA on the device-resident voxel map: the
 incremental use of the reference's octree that none of its shipped drivers runs).
 """
-__version__ = "0.2.0"
+__version__ = "0.5.0"      # = balm_version() of the library, ABI revision 5

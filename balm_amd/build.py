@@ -13,7 +13,7 @@ LIBDIR = os.path.join(_HERE, "lib")
 HIP_SOURCES = ["kernels_accum.hip", "kernels_solve.hip", "kernels_build.hip", "kernels_voxel.hip", "kernels_cov.hip", "balm_multi.hip", "balm_capi.hip"]
 # association decisions must reproduce the reference's un-fused float/double arithmetic bit for bit
 EXTRA_FLAGS = {"kernels_voxel.hip": ["-ffp-contract=off"]}
-HIP_DEPS = ["balm_internal.h", "syrk_mfma_asm.inc", "kernels_window.inc", "kernels_chain.inc", "kernels_small.inc", os.path.join("..", "..", "include", "balm_hip.h")]
+HIP_DEPS = ["balm_internal.h", "host_stage.h", "syrk_mfma_asm.inc", "kernels_window.inc", "kernels_chain.inc", "kernels_small.inc", os.path.join("..", "..", "include", "balm_hip.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=on", "-Wall",
              "-Wno-unused-value", "-Wno-unused-result", "-Wno-unused-function"]

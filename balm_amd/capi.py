@@ -13,14 +13,14 @@ LIB_PATH = os.environ.get("BALM_HIP_LIB") or os.path.join(_HERE, "lib", "libbalm
 
 FORM_LEFT, FORM_RIGHT = 0, 1
 OK, ERR_ARG, ERR_HIP, ERR_STATE, ERR_TOO_FEW_PLANES, ERR_NUMERIC = range(6)
-ABI_VERSION = 4            # include/balm_hip.h: BALM_ABI_VERSION
+ABI_VERSION = 5            # include/balm_hip.h: BALM_ABI_VERSION
 FLAG_TIMING = 1
 FLAG_LOOPBACK_SHARDS = 2
-T_MOMENTS, T_FACTORS, T_SYRK, T_ASSEMBLE, T_SOLVE, T_UPDATE, T_BUILD, T_VOXEL, T_COV, T_COMM, T_COUNT = range(11)
-TIMING_NAMES = ["moments", "factors", "syrk", "assemble", "solve", "update", "build", "voxel", "cov", "comm"]
+T_MOMENTS, T_FACTORS, T_SYRK, T_ASSEMBLE, T_SOLVE, T_UPDATE, T_BUILD, T_VOXEL, T_COV, T_COMM, T_UPLOAD, T_COUNT = range(12)
+TIMING_NAMES = ["moments", "factors", "syrk", "assemble", "solve", "update", "build", "voxel", "cov", "comm", "upload"]
 
 # every symbol include/balm_hip.h declares
-EXPORTS = ["balm_create", "balm_create_multi", "balm_destroy", "balm_set_features", "balm_evaluate", "balm_only_residual",
+EXPORTS = ["balm_create", "balm_create_multi", "balm_destroy", "balm_set_features", "balm_set_features_cb", "balm_evaluate", "balm_only_residual",
            "balm_solve_damped", "balm_damping_iter", "balm_build_clusters", "balm_voxel_defaults", "balm_associate", "balm_get_features", "balm_get_association", "balm_pose_covariance",
            "balm_window_open", "balm_window_add_scan", "balm_window_recut", "balm_window_get_points", "balm_window_features", "balm_window_marginalize", "balm_window_info", "balm_window_close",
            "balm_set_allreduce", "balm_comm_unique_id", "balm_comm_init_rank", "balm_comm_info",
@@ -46,6 +46,7 @@ class VoxelOpts(C.Structure):
 
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_long, C.c_void_p)
+FILL_CLUSTERS_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double))
 
 _LIB = None
 
@@ -63,6 +64,11 @@ def lib():
             raise ImportError("libbalm_hip.so is not built (%s missing): run `python -m balm_amd.build`. "
                               "There is no CPU fallback for the HIP path." % LIB_PATH)
         L = C.CDLL(LIB_PATH)
+        abi = getattr(L, "balm_abi_version", None)      # (a library older than the symbol itself: revision 0)
+        abi = abi() if abi is not None else 0
+        if abi != ABI_VERSION:
+            raise ImportError("libbalm_hip.so has ABI revision %d, this binding was written for %d: rebuild (python -m balm_amd.build)"
+                              % (abi, ABI_VERSION))
         L.balm_create.restype = C.c_void_p
         L.balm_create.argtypes = [C.c_int, C.c_int, C.c_int]
         L.balm_create_multi.restype = C.c_void_p
@@ -70,6 +76,7 @@ def lib():
         L.balm_destroy.restype = None
         L.balm_destroy.argtypes = [C.c_void_p]
         L.balm_set_features.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.balm_set_features_cb.argtypes = [C.c_void_p, C.c_int, FILL_CLUSTERS_FN, C.c_void_p, C.c_void_p, C.c_void_p]
         L.balm_evaluate.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                     C.POINTER(C.c_double)]
         L.balm_only_residual.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]
@@ -106,9 +113,6 @@ def lib():
         L.balm_last_error.restype = C.c_char_p
         L.balm_last_error.argtypes = [C.c_void_p]
         L.balm_version.restype = C.c_char_p
-        if L.balm_abi_version() != ABI_VERSION:
-            raise ImportError("libbalm_hip.so has ABI revision %d, this binding was written for %d: rebuild (python -m balm_amd.build)"
-                              % (L.balm_abi_version(), ABI_VERSION))
         _LIB = L
     return _LIB
 
@@ -172,6 +176,24 @@ class Context:
         assert coeffs.shape == (F,)
         assert fix is None or fix.shape == (F, 10)
         self._check(self.L.balm_set_features(self.h, F, _p(clusters), _p(fix), _p(coeffs)))
+        self.F = F
+
+    def set_features_cb(self, per_feature, fix, coeffs):
+        """balm_set_features_cb: `per_feature` is a sequence of F separate [W, 10] arrays (the shape of VOX_HESS's borrowed
+        `vector<PointCluster>*`); the library's host threads pull feature ranges straight into its pinned staging chunks."""
+        tabs = [_c(t) for t in per_feature]
+        F = len(tabs)
+        assert all(t.shape == (self.W, 10) for t in tabs)
+        fix, coeffs = _c(fix), _c(coeffs)
+        row = self.W * 10
+
+        def fill(_user, f0, f1, dst):
+            out = np.ctypeslib.as_array(dst, shape=((f1 - f0) * row,))
+            for a in range(f0, f1):
+                out[(a - f0) * row:(a - f0 + 1) * row] = tabs[a].reshape(-1)
+
+        cb = FILL_CLUSTERS_FN(fill)
+        self._check(self.L.balm_set_features_cb(self.h, F, cb, None, _p(fix), _p(coeffs)))
         self.F = F
 
     def build_clusters(self, F, xyz, feat_id, pose_id, fix, coeffs, want_clusters=True):

@@ -160,8 +160,6 @@ static void collect_timing_if_idle(balm_ctx *ctx) {
 // stream synchronise (long iterations: nothing to gain from spinning).  Errors of the stream surface there or at the
 // next synchronising call.
 int wait_scalars(balm_ctx *ctx) {
-  static const bool no_poll = getenv("BALM_NO_POLL") != nullptr;      // A/B: the plain stream synchronise
-  if (no_poll) return sync_stream(ctx);
   volatile double *stamp = ctx->h_scal + SCAL_STAMP;
   const double want = (double)ctx->mail_seq;
   const auto t0 = std::chrono::steady_clock::now();
@@ -347,7 +345,9 @@ int read_scalars(balm_ctx *ctx) {
 // obs[a * W + i] != 0: pose i observes feature a (obs_of: from a host table; launch_obs_mask: from a table built on the device)
 std::vector<unsigned char> obs_of(const double *clusters, int F, int W) {
   std::vector<unsigned char> obs((size_t)F * W);
-  for (size_t t = 0; t < obs.size(); t++) obs[t] = clusters[t * 10 + 9] != 0 ? 1 : 0;
+  parallel_ranges(obs.size(), (size_t)1 << 16, [&](size_t lo, size_t hi) {
+    for (size_t t = lo; t < hi; t++) obs[t] = clusters[t * 10 + 9] != 0 ? 1 : 0;
+  });
   return obs;
 }
 
@@ -355,22 +355,37 @@ int feature_bookkeeping(balm_ctx *ctx, int F, const unsigned char *obs, const do
   const int W = ctx->W;
   ctx->planes_per_pose.assign(W, 0);
   double S = 0, B = 0;
-  for (int a = 0; a < F; a++) {
-    int na = 0;
-    const unsigned char *oa = obs + (size_t)a * W;
-    for (int i = 0; i < W; i++)
-      if (oa[i]) { ctx->planes_per_pose[i]++; na++; }
-    if (na == 0 && !(fix && fix[(size_t)a * 10 + 9] != 0)) {
-      ctx->err = "feature " + std::to_string(a) + " has no observation and no fix cluster (zero point count)";
-      return BALM_ERR_NUMERIC;
+  int bad_a = F, bad_rc = BALM_OK;          // the first offending feature, whichever thread meets it
+  std::mutex mu;
+  parallel_ranges((size_t)F, (size_t)(65536 / W + 1), [&](size_t lo, size_t hi) {
+    std::vector<int> ppp((size_t)W, 0);
+    double s = 0, b = 0;
+    int my_bad = F, my_rc = BALM_OK;
+    for (size_t a = lo; a < hi; a++) {
+      int na = 0;
+      const unsigned char *oa = obs + a * W;
+      for (int i = 0; i < W; i++)
+        if (oa[i]) { ppp[(size_t)i]++; na++; }
+      if (my_rc == BALM_OK) {
+        if (na == 0 && !(fix && fix[a * 10 + 9] != 0)) { my_bad = (int)a; my_rc = BALM_ERR_NUMERIC; }
+        else if (!(coeffs[a] >= 0) || !std::isfinite(coeffs[a])) { my_bad = (int)a; my_rc = BALM_ERR_ARG; }
+      }
+      s += na; b += 0.5 * na * (na + 1.0);
     }
-    if (!(coeffs[a] >= 0) || !std::isfinite(coeffs[a])) {
-      ctx->err = "feature " + std::to_string(a) + " has a negative or non-finite weight";
-      return BALM_ERR_ARG;
-    }
-    S += na; B += 0.5 * na * (na + 1.0);
+    std::lock_guard<std::mutex> lk(mu);
+    for (int i = 0; i < W; i++) ctx->planes_per_pose[(size_t)i] += ppp[(size_t)i];
+    S += s; B += b;
+    if (my_rc != BALM_OK && my_bad < bad_a) { bad_a = my_bad; bad_rc = my_rc; }
+  });
+  if (bad_rc == BALM_ERR_NUMERIC) {
+    ctx->err = "feature " + std::to_string(bad_a) + " has no observation and no fix cluster (zero point count)";
+    return BALM_ERR_NUMERIC;
   }
-  ctx->work_S = S; ctx->work_B = B;
+  if (bad_rc == BALM_ERR_ARG) {
+    ctx->err = "feature " + std::to_string(bad_a) + " has a negative or non-finite weight";
+    return BALM_ERR_ARG;
+  }
+  ctx->work_S = S; ctx->work_B = B;       // (integers below 2^53: the sum does not depend on the split)
   return BALM_OK;
 }
 
@@ -378,7 +393,7 @@ int feature_bookkeeping(balm_ctx *ctx, int F, const unsigned char *obs, const do
 
 extern "C" {
 
-const char *balm_version(void) { return "balm_hip 0.4.0 (gfx950)"; }
+const char *balm_version(void) { return "balm_hip 0.5.0 (gfx950)"; }
 int balm_abi_version(void) { return BALM_ABI_VERSION; }
 
 const char *balm_last_error(balm_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
@@ -442,17 +457,7 @@ balm_ctx *balm_create(int win_size, int device, int flags) {
   }
   ctx->ntiles = (int)(jobs.size() / 4);
   ctx->h_jobs = jobs;
-  {
-    // BALM_STREAM_PRIORITY=high: the context's stream at the device's greatest priority (experiment: does a process that also holds
-    // RCCL's streams get its kernels dispatched sooner?  tools/exp_dist_overhead.py)
-    const char *sp = getenv("BALM_STREAM_PRIORITY");
-    int lo = 0, hi = 0;
-    if (sp && !strcmp(sp, "high") && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess) {
-      if (hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, hi) != hipSuccess) return fail();
-    } else if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
-      return fail();
-    }
-  }
+  if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) return fail();
   const int W = ctx->W, n = ctx->n, nA = ctx->nA;
   ctx->red_len = (size_t)ctx->ntiles * TILE_ELEMS + (size_t)DACC_MAX * W + 2;
   if (dalloc(ctx, &ctx->d_poses, (size_t)12 * W) || dalloc(ctx, &ctx->d_poses_tmp, (size_t)12 * W) ||
@@ -482,11 +487,13 @@ balm_ctx *balm_create(int win_size, int device, int flags) {
   if (hipMemset(ctx->d_scal, 0, 16 * sizeof(double)) != hipSuccess) return fail();
   if (hipMemset(ctx->d_red, 0, ctx->red_len * sizeof(double)) != hipSuccess) return fail();
   if (hipMemset(ctx->d_minv, 0, (size_t)2 * (nA / NB) * NB * NB * sizeof(double)) != hipSuccess) return fail();
+  context_born(device); ctx->counted_live = true;
   return ctx;
 }
 
 static void one_destroy(balm_ctx *ctx) {
   if (!ctx) return;
+  if (ctx->counted_live) { context_gone(ctx->device); ctx->counted_live = false; }
   comm_destroy(ctx);
   drop_lm_graphs(ctx);
   hipSetDevice(ctx->device);
@@ -497,6 +504,7 @@ static void one_destroy(balm_ctx *ctx) {
                   ctx->d_g, ctx->d_A, ctx->d_Wp, ctx->d_dvec, ctx->d_z, ctx->d_x, ctx->d_perm, ctx->d_dx, ctx->d_scal, ctx->d_arena, ctx->d_pre, ctx->d_flags, ctx->d_minv, ctx->d_macro_tab, ctx->d_trace, ctx->d_slot, ctx->d_items, ctx->d_csr, ctx->d_chunk_ids, ctx->d_stage};
   for (void *p : ptrs) if (p) hipFree(p);
   if (ctx->h_scal) hipHostFree(ctx->h_scal);
+  ctx->ring.release();
   for (auto &sp : ctx->timer.pending) { hipEventDestroy(sp.a); hipEventDestroy(sp.b); }
   for (auto e : ctx->timer.pool) hipEventDestroy(e);
   if (ctx->stream) hipStreamDestroy(ctx->stream);
@@ -518,16 +526,18 @@ static int build_sparse_plan(balm_ctx *ctx, int F, const unsigned char *obs) {
                                                          //  sliding window installs a table per slide: the plan's host time is not free)
   struct Key { uint64_t hi, lo; int a; };
   std::vector<Key> keys((size_t)F);
-  for (int a = 0; a < F; a++) {
-    uint64_t hi = 0, lo = 0;
-    const unsigned char *oa = obs + (size_t)a * W;
-    for (int i = 0; i < W; i++)
-      if (oa[i])
-        for (int b = (6 * i) / TILE; b <= (6 * i + 5) / TILE; b++) {      // a pose's six rows may straddle two blocks
-          if (b < 64) hi |= 1ull << (63 - b); else lo |= 1ull << (127 - b);   // block 0 = most significant bit
-        }
-    keys[(size_t)a] = {hi, lo, a};
-  }
+  parallel_ranges((size_t)F, (size_t)(65536 / W + 1), [&](size_t a0, size_t a1) {
+    for (size_t a = a0; a < a1; a++) {
+      uint64_t hi = 0, lo = 0;
+      const unsigned char *oa = obs + a * W;
+      for (int i = 0; i < W; i++)
+        if (oa[i])
+          for (int b = (6 * i) / TILE; b <= (6 * i + 5) / TILE; b++) {      // a pose's six rows may straddle two blocks
+            if (b < 64) hi |= 1ull << (63 - b); else lo |= 1ull << (127 - b);   // block 0 = most significant bit
+          }
+      keys[a] = {hi, lo, (int)a};
+    }
+  });
   // order: first touched block, then last touched block, then the pattern itself (measured on the shipped window against a
   // plain lexicographic order and a centre/span order: the tightest chunk unions)
   auto first_of = [&](const Key &k) { for (int b = 0; b < T; b++) if (b < 64 ? (k.hi >> (63 - b)) & 1 : (k.lo >> (127 - b)) & 1) return b; return T; };
@@ -620,10 +630,15 @@ static int install_feature_buffers(balm_ctx *ctx, int F, const double *fix, cons
 
 static int assoc_clusters_host(balm_ctx *ctx);
 
-static int one_set_features(balm_ctx *ctx, int F, const double *clusters, const double *fix, const double *coeffs) {
+// fill(f0, f1, dst): the clusters of features [f0, f1) in the ABI's layout ((f1 - f0) * W * 10 doubles) -> dst, a pinned staging
+// chunk; called from several host threads at once on disjoint ranges (host_stage.h).  The observation mask is read off the chunk
+// while it is hot in the filling thread's cache.
+using FillClusters = std::function<void(int, int, double *)>;
+
+static int one_set_features_fn(balm_ctx *ctx, int F, const FillClusters &fill, const double *fix, const double *coeffs) {
   if (!ctx) return BALM_ERR_ARG;
   if (ctx->multi && F == 0) { ctx->F = 0; ctx->feat_cur_valid = false; ctx->gt_cur_valid = false; return BALM_OK; }      // a shard without features
-  if (F < 1 || !clusters || !coeffs) { ctx->err = "balm_set_features: bad argument"; return BALM_ERR_ARG; }
+  if (F < 1 || !fill || !coeffs) { ctx->err = "balm_set_features: bad argument"; return BALM_ERR_ARG; }
   HIP_TRY(hipSetDevice(ctx->device));
   const int W = ctx->W;
   const size_t count = (size_t)F * W * 10;
@@ -633,19 +648,35 @@ static int one_set_features(balm_ctx *ctx, int F, const double *clusters, const 
   if ((rc = keep(ctx, &ctx->d_cl, &ctx->cap_cl, count))) return rc;
   if ((rc = stage_begin(ctx, count * sizeof(double)))) return rc;
   double *d_aos = stage_take<double>(ctx, count);
-  hipError_t e = hipMemcpyAsync(d_aos, clusters, count * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
-  if (e == hipSuccess) {
-    launch_transpose_clusters(ctx->stream, d_aos, ctx->d_cl, F, W);
-    e = hipStreamSynchronize(ctx->stream);
-  }
-  HIP_TRY(e);
+  std::vector<unsigned char> obs((size_t)F * W);
+  const size_t unit = (size_t)W * 10 * sizeof(double);
+  hipError_t e;
   {
-    const std::vector<unsigned char> obs = obs_of(clusters, F, W);
-    if (!ctx->multi && (rc = feature_bookkeeping(ctx, F, obs.data(), fix, coeffs))) return rc;    // sharded: done once on the whole table
-    if ((rc = build_sparse_plan(ctx, F, obs.data()))) return rc;
+    Span sp(ctx, BALM_T_UPLOAD);
+    e = staged_upload(ctx->ring, ctx->stream, d_aos, count * sizeof(double), unit, [&](char *dst, size_t off, size_t len) {
+      const int f0 = (int)(off / unit), f1 = f0 + (int)(len / unit);
+      double *q = reinterpret_cast<double *>(dst);
+      fill(f0, f1, q);
+      unsigned char *o = obs.data() + (size_t)f0 * W;
+      const size_t cnt = (size_t)(f1 - f0) * W;
+      for (size_t t = 0; t < cnt; t++) o[t] = q[t * 10 + 9] != 0 ? 1 : 0;
+    });
   }
-  if ((rc = install_feature_buffers(ctx, F, fix, coeffs))) return rc;
+  if (e == hipSuccess) launch_transpose_clusters(ctx->stream, d_aos, ctx->d_cl, F, W);
+  HIP_TRY(e);
+  // (the host's bookkeeping runs beside the last DMAs and the transpose)
+  if (!ctx->multi && (rc = feature_bookkeeping(ctx, F, obs.data(), fix, coeffs))) { hipStreamSynchronize(ctx->stream); return rc; }    // sharded: done once on the whole table
+  if ((rc = build_sparse_plan(ctx, F, obs.data()))) { hipStreamSynchronize(ctx->stream); return rc; }
+  if ((rc = install_feature_buffers(ctx, F, fix, coeffs))) { hipStreamSynchronize(ctx->stream); return rc; }
   return sync_stream(ctx);
+}
+
+static int one_set_features(balm_ctx *ctx, int F, const double *clusters, const double *fix, const double *coeffs) {
+  if (ctx && !(ctx->multi && F == 0) && !clusters) { ctx->err = "balm_set_features: bad argument"; return BALM_ERR_ARG; }
+  const size_t row = ctx ? (size_t)ctx->W * 10 : 0;
+  return one_set_features_fn(ctx, F, [clusters, row](int f0, int f1, double *dst) {
+    std::memcpy(dst, clusters + (size_t)f0 * row, (size_t)(f1 - f0) * row * sizeof(double));
+  }, fix, coeffs);
 }
 
 static int one_build_clusters(balm_ctx *ctx, int F, const float *xyz, const int *feat_id, const int *pose_id, long n_pts,
@@ -667,9 +698,12 @@ static int one_build_clusters(balm_ctx *ctx, int F, const float *xyz, const int 
   int *d_f = stage_take<int>(ctx, np1), *d_p = stage_take<int>(ctx, np1);
   double *d_aos = stage_take<double>(ctx, count);
   hipError_t e = hipSuccess;
-  if (e == hipSuccess) e = hipMemcpyAsync(d_xyz, xyz, (size_t)n_pts * 3 * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
-  if (e == hipSuccess) e = hipMemcpyAsync(d_f, feat_id, (size_t)n_pts * sizeof(int), hipMemcpyHostToDevice, ctx->stream);
-  if (e == hipSuccess) e = hipMemcpyAsync(d_p, pose_id, (size_t)n_pts * sizeof(int), hipMemcpyHostToDevice, ctx->stream);
+  {
+    Span sp(ctx, BALM_T_UPLOAD);
+    if (e == hipSuccess) e = staged_copy(ctx->ring, ctx->stream, d_xyz, xyz, (size_t)n_pts * 3 * sizeof(float));
+    if (e == hipSuccess) e = staged_copy(ctx->ring, ctx->stream, d_f, feat_id, (size_t)n_pts * sizeof(int));
+    if (e == hipSuccess) e = staged_copy(ctx->ring, ctx->stream, d_p, pose_id, (size_t)n_pts * sizeof(int));
+  }
   if (e == hipSuccess) e = hipMemsetAsync(ctx->d_cl, 0, count * sizeof(double), ctx->stream);
   int *d_flag = reinterpret_cast<int *>(ctx->d_scal + 8);           // a spare device scalar slot
   if (e == hipSuccess) e = hipMemsetAsync(d_flag, 0, sizeof(int), ctx->stream);
@@ -691,18 +725,25 @@ static int one_build_clusters(balm_ctx *ctx, int F, const float *xyz, const int 
     }
   }
   HIP_TRY(e);
-  // host copy of the cluster table (also feeds the planes-per-pose precheck)
-  std::vector<double> host(count);
-  launch_soa_to_aos(ctx->stream, ctx->d_cl, d_aos, F, W);
-  e = hipMemcpyAsync(host.data(), d_aos, count * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-  HIP_TRY(e);
-  if (clusters_out) std::memcpy(clusters_out, host.data(), count * sizeof(double));
+  // the host's bookkeeping (planes per pose, work model, sparse plan) needs one byte per (feature, pose); the table itself
+  // crosses PCIe only if the caller asked for a copy
+  std::vector<unsigned char> obs((size_t)F * W);
   {
-    const std::vector<unsigned char> obs = obs_of(host.data(), F, W);
-    if ((rc = feature_bookkeeping(ctx, F, obs.data(), fix, coeffs))) return rc;
-    if ((rc = build_sparse_plan(ctx, F, obs.data()))) return rc;
+    unsigned char *d_obs = reinterpret_cast<unsigned char *>(d_f);       // (the ids are consumed; 4 n_pts bytes -- but F * W may exceed them)
+    if (obs.size() > np1 * sizeof(int)) d_obs = reinterpret_cast<unsigned char *>(d_aos);
+    launch_obs_mask(ctx->stream, ctx->d_cl, F, W, d_obs);
+    e = hipMemcpyAsync(obs.data(), d_obs, obs.size(), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    HIP_TRY(e);
   }
+  if (clusters_out) {
+    launch_soa_to_aos(ctx->stream, ctx->d_cl, d_aos, F, W);
+    e = hipMemcpyAsync(clusters_out, d_aos, count * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    HIP_TRY(e);
+  }
+  if ((rc = feature_bookkeeping(ctx, F, obs.data(), fix, coeffs))) return rc;
+  if ((rc = build_sparse_plan(ctx, F, obs.data()))) return rc;
   if ((rc = install_feature_buffers(ctx, F, fix, coeffs))) return rc;
   return sync_stream(ctx);
 }
@@ -808,8 +849,11 @@ static int one_associate(balm_ctx *ctx, const balm_voxel_opts *opts, const float
   d_f = stage_take<int>(ctx, (size_t)n_pts);
   d_pos = stage_take<double>(ctx, (size_t)12 * WT);
   hipError_t e = hipSuccess;
-  if (e == hipSuccess) e = hipMemcpyAsync(d_xyz, xyz, (size_t)n_pts * 3 * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
-  if (e == hipSuccess) e = hipMemcpyAsync(d_f, frame_id, (size_t)n_pts * sizeof(int), hipMemcpyHostToDevice, ctx->stream);
+  {
+    Span sp(ctx, BALM_T_UPLOAD);
+    if (e == hipSuccess) e = staged_copy(ctx->ring, ctx->stream, d_xyz, xyz, (size_t)n_pts * 3 * sizeof(float));
+    if (e == hipSuccess) e = staged_copy(ctx->ring, ctx->stream, d_f, frame_id, (size_t)n_pts * sizeof(int));
+  }
   if (e == hipSuccess) e = hipMemcpyAsync(d_pos, poses, (size_t)12 * WT * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
   if (e == hipSuccess) {
     Span sp(ctx, BALM_T_VOXEL);
@@ -973,7 +1017,7 @@ static int one_pose_covariance(balm_ctx *ctx, const double *poses, const double 
   hipError_t e = hipSuccess;
   if (ncc) {
     d_cc = stage_take<double>(ctx, ncc);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_cc, cluster_cov, (size_t)F * W * 81 * sizeof(double), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) { Span sp(ctx, BALM_T_UPLOAD); e = staged_copy(ctx->ring, s, d_cc, cluster_cov, (size_t)F * W * 81 * sizeof(double)); }
   }
   double *Gx = ctx->d_Gt, *Gy = ctx->d_Gt + gcols * ctx->npad;
   if (e == hipSuccess && F == 0) e = hipMemsetAsync(buf, 0, pay * sizeof(double), s);      // a shard without features
@@ -1089,6 +1133,15 @@ int balm_solve_damped(balm_ctx *ctx, const double *Hess, const double *JacT, dou
   HIP_TRY(hipMemcpyAsync(dxi, ctx->d_dx, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   int rc = read_scalars(ctx);
   if (rc) return rc;
+  if (!std::isfinite(ctx->h_scal[2]) && !ctx->persistent_off && solve_timed_out(ctx)) {      // (see one_damping_iter: once, on the launch path)
+    ctx->persistent_off = true;
+    {
+      Span sp(ctx, BALM_T_SOLVE);
+      launch_solve(ctx, true);
+    }
+    HIP_TRY(hipMemcpyAsync(dxi, ctx->d_dx, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if ((rc = read_scalars(ctx))) return rc;
+  }
   if (q1) *q1 = ctx->h_scal[2];
   return BALM_OK;
 }
@@ -1214,12 +1267,17 @@ static int one_damping_iter(balm_ctx *ctx, const balm_lm_opts *o, double *poses,
   int it = 0;
   // fault injection for tests/test_gpu_multi.py (a device thread that leaves the loop must take its peers out with it, not
   // leave them waiting): BALM_FAULT_INJECT="<rank>,<iteration>" makes that device of a sharded context fail there
-  int fault_rank = -1, fault_it = -1;
-  if (ctx->multi)
-    if (const char *fi = getenv("BALM_FAULT_INJECT")) sscanf(fi, "%d,%d", &fault_rank, &fault_it);
+  // ... and BALM_FAULT_INJECT="timeout,<iteration>" (any context): that iteration's solve finds its abort flag raised, as a wait
+  // inside a persistent solve kernel that hit its poll limit leaves it (tests/test_gpu_solve.py: the retry on the launch path)
+  int fault_rank = -1, fault_it = -1, timeout_it = -1;
+  if (const char *fi = getenv("BALM_FAULT_INJECT")) {
+    if (!strncmp(fi, "timeout,", 8)) timeout_it = atoi(fi + 8);
+    else if (ctx->multi) sscanf(fi, "%d,%d", &fault_rank, &fault_it);
+  }
   while (it < o->max_iter) {
     const bool evaluated = calc || o->force_hess;
     if (ctx->rank == fault_rank && it == fault_it) { ctx->err = "balm_damping_iter: injected fault"; return BALM_ERR_HIP; }
+    if (it == timeout_it) { ctx->inject_solve_timeout = true; timeout_it = -1; }
     if ((rc = set_damping(ctx, u))) return rc;
     if ((rc = lm_iteration(ctx, o->form, evaluated, it))) return rc;
     double sc[3] = {ctx->h_scal[0], ctx->h_scal[1], ctx->h_scal[2]};
@@ -1227,6 +1285,16 @@ static int one_damping_iter(balm_ctx *ctx, const balm_lm_opts *o, double *poses,
     r1 = sc[0]; r2 = sc[1];
     const double q1 = sc[2];
     double q = r1 - r2;
+    if (!ctx->multi && !ctx->persistent_off && !(std::isfinite(r2) && std::isfinite(q1)) && std::isfinite(r1) && solve_timed_out(ctx)) {
+      // not arithmetic: a wait inside the persistent solve kernel ran into its poll limit -- its workgroups were not all resident
+      // (another process or another stream's kernel held CUs).  The Hessian of this iteration is intact; the solve is repeated on
+      // the launch path (no co-residency needed), where this context then stays.
+      ctx->persistent_off = true;
+      drop_lm_graphs(ctx);
+      ctx->feat_cur_valid = false; ctx->gt_cur_valid = false;      // (the iteration is re-issued from its evaluation)
+      calc = true;
+      continue;
+    }
     if (!(std::isfinite(r1) && std::isfinite(r2))) {
       ctx->err = "balm_damping_iter: non-finite residual";
       return BALM_ERR_NUMERIC;
@@ -1322,7 +1390,8 @@ int balm_comm_init_rank(balm_ctx *ctx, int n_ranks, int rank, const void *id128)
 static int multi_set_features(balm_ctx *ctx, balm_multi *m, int F, const double *clusters, const double *fix, const double *coeffs) {
   if (F < 1 || !clusters || !coeffs) { ctx->err = "balm_set_features: bad argument"; return BALM_ERR_ARG; }
   m->F = 0;
-  int rc = feature_bookkeeping(ctx, F, obs_of(clusters, F, ctx->W).data(), fix, coeffs);
+  const std::vector<unsigned char> obs = obs_of(clusters, F, ctx->W);
+  int rc = feature_bookkeeping(ctx, F, obs.data(), fix, coeffs);
   if (rc) return rc;
   // contiguous shards of equal COST: a feature costs its observed pose pairs n_a (n_a + 1) / 2 (the block-sparse SYRK
   // plan skips what it does not observe; with dense co-visibility every feature costs the same and this is an equal split)
@@ -1330,12 +1399,15 @@ static int multi_set_features(balm_ctx *ctx, balm_multi *m, int F, const double 
   {
     const int W = ctx->W;
     std::vector<double> cum((size_t)F + 1, 0.0);
-    for (int a = 0; a < F; a++) {
-      int na = 0;
-      const double *ca = clusters + (size_t)a * W * 10;
-      for (int i = 0; i < W; i++) na += ca[(size_t)i * 10 + 9] != 0;
-      cum[(size_t)a + 1] = cum[(size_t)a] + 0.5 * na * (na + 1.0) + 4.0 * na + 1.0;
-    }
+    parallel_ranges((size_t)F, (size_t)(65536 / W + 1), [&](size_t lo, size_t hi) {
+      for (size_t a = lo; a < hi; a++) {
+        int na = 0;
+        const unsigned char *oa = obs.data() + a * W;
+        for (int i = 0; i < W; i++) na += oa[i];
+        cum[a + 1] = 0.5 * na * (na + 1.0) + 4.0 * na + 1.0;
+      }
+    });
+    for (int a = 0; a < F; a++) cum[(size_t)a + 1] += cum[(size_t)a];
     m->fbeg[0] = 0;
     for (int k = 1; k < m->n; k++) {
       const double target = cum[(size_t)F] * k / m->n;
@@ -1359,6 +1431,20 @@ static int multi_set_features(balm_ctx *ctx, balm_multi *m, int F, const double 
 int balm_set_features(balm_ctx *ctx, int F, const double *clusters, const double *fix, const double *coeffs) {
   if (balm_multi *m = leader_of(ctx)) return multi_set_features(ctx, m, F, clusters, fix, coeffs);
   return one_set_features(ctx, F, clusters, fix, coeffs);
+}
+
+int balm_set_features_cb(balm_ctx *ctx, int F, balm_fill_clusters_fn fill, void *user, const double *fix, const double *coeffs) {
+  if (!ctx) return BALM_ERR_ARG;
+  if (F < 1 || !fill || !coeffs) { ctx->err = "balm_set_features_cb: bad argument"; return BALM_ERR_ARG; }
+  if (balm_multi *m = leader_of(ctx)) {
+    // sharded: the cost-balanced cut needs every feature's observation count before any shard can be installed -- the
+    // table is flattened once (all pool threads), then cut like balm_set_features'
+    const size_t row = (size_t)ctx->W * 10;
+    std::vector<double> flat((size_t)F * row);
+    parallel_ranges((size_t)F, (size_t)(32768 / row + 1), [&](size_t lo, size_t hi) { fill(user, (int)lo, (int)hi, flat.data() + lo * row); });
+    return multi_set_features(ctx, m, F, flat.data(), fix, coeffs);
+  }
+  return one_set_features_fn(ctx, F, [fill, user](int f0, int f1, double *dst) { fill(user, f0, f1, dst); }, fix, coeffs);
 }
 
 int balm_build_clusters(balm_ctx *ctx, int F, const float *xyz, const int *feat_id, const int *pose_id, long n_pts,

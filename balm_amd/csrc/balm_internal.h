@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "../../include/balm_hip.h"
+#include "host_stage.h"
 
 namespace balm {
 
@@ -117,11 +118,14 @@ struct balm_ctx {
   double *h_scal = nullptr;         // pinned mirror (16) + a ring of damping values on their way to d_scal[SCAL_U] (64) + a stamp
   double *d_hscal = nullptr;        // its device alias: k_scalars_mail writes the mirror and the stamp straight into host memory
   unsigned long long mail_seq = 0;  // stamp of the last k_scalars_mail launch
-  double comm_host_us = 0.0; long comm_calls = 0;      // BALM_COMM_DEBUG: host time inside the transport's calls
   bool need_minv = false;           // the caller wants M = L^-T D^+ in the identity rows of d_A (balm_pose_covariance): no back-substitution path
   bool solve_tiled = false;         // d_A holds [A ; rhs] tile by tile (k_build_A -> k_ldl_chain without identity rows -> k_ldl_backsolve)
   int chain_refused_P[2] = {-1, -1};   // panels for which launch_factor_chain refused [without / with identity rows] (too few co-resident helpers, ...)
   bool solve_backsub = false;       // the last factorisation ran without identity rows: k_ldl_backsolve instead of k_ldl_apply
+  bool counted_live = false;        // this context is in the per-device count of live contexts (context_born / context_gone)
+  bool persistent_off = false;      // a wait inside k_ldl_chain / k_ldl_fused / k_ldl_backsolve timed out on this context (its workgroups were not all
+                                    // resident: another process or stream held CUs): that solve was retried on the launch path, and so is every later one
+  bool inject_solve_timeout = false;   // tests: the next solve finds its abort flag raised (BALM_FAULT_INJECT="timeout,<iteration>")
   bool small_ready = false, small_refused = false;   // k_solve_small (windows of <= 24 poses): its LDS attribute is set on this device / the device refused it
   double u_value = 0.0;             // damping of the next solve (set_damping)
   bool u_on_device = false;         // ... read by the solve's kernels from d_scal[SCAL_U] (graph capture / replay) instead of their arguments
@@ -145,6 +149,7 @@ struct balm_ctx {
   size_t arena_cap = 0;
   char *d_stage = nullptr;          // per-call staging (uploads, layout changes, covariance work matrices): grown, never
   size_t stage_cap = 0, stage_off = 0;   // shrunk, carved by a bump pointer -- no hipMalloc / hipFree per call
+  balm::PinnedRing ring;            // pinned chunks the caller's big host arrays travel through (host_stage.h), allocated on first use
   balm_allreduce_fn allreduce = nullptr;
   void *allreduce_user = nullptr;
   balm::Timer timer;
@@ -243,6 +248,9 @@ int multi_host_barrier_rc(balm_ctx *ctx, int rc);             // all device thre
 constexpr int SCAL_U = 5;            // d_scal slot of the damping u
 constexpr int SCAL_STAMP = 16 + 64;  // h_scal slot of k_scalars_mail's stamp (behind the mirror and the damping ring)
 bool chain_macro_plan(int P, int NH, std::vector<int> &tab);      // who owns which 2 x 2 macro-tile in k_ldl_chain (kernels_chain.inc; host only)
+void context_born(int device);   // contexts of this process alive per device: the persistent solve kernels size their grids for their share of the slots
+void context_gone(int device);
+bool solve_timed_out(balm_ctx *c);     // host-synchronous: the last solve's abort flag (a poll limit was hit)
 bool solve_is_persistent(const balm_ctx *c);      // the factorisation of this window runs as k_ldl_fused
 void launch_solve(balm_ctx *c, bool new_hessian, int upd_form = 0, const double *upd_poses = nullptr, double *upd_out = nullptr);      // (H + u diag H) dx = -g, u = d_scal[SCAL_U]; q1 -> d_scal[2]
 void launch_update_poses(hipStream_t s, int form, int W, const double *poses, const double *dx, double *out);

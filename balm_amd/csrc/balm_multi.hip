@@ -110,10 +110,6 @@ void comm_query(const balm_ctx *ctx, int *count, int *rank) {
 
 int comm_allreduce(balm_ctx *ctx, double *buf, long n) {
   const Rccl *r = rccl();
-  static const bool dbg = getenv("BALM_COMM_DEBUG") != nullptr;      // host time spent INSIDE the collective calls (does the call wait for the stream?)
-  static const bool skip = getenv("BALM_COMM_SKIP_ONE_RANK") != nullptr;      // experiment (tools/exp_dist_overhead.py): a one-rank sum is the identity
-  if (skip && ctx->nranks == 1) return BALM_OK;
-  const auto t0 = std::chrono::steady_clock::now();
   ncclResult_t e;
   {
     // the enqueue and a peer's ncclCommAbort of this communicator (multi_abort) exclude each other: the handle is
@@ -125,12 +121,6 @@ int comm_allreduce(balm_ctx *ctx, double *buf, long n) {
       return BALM_ERR_STATE;
     }
     e = r->AllReduce(buf, buf, (size_t)n, ncclDouble, ncclSum, (ncclComm_t)comm, ctx->stream);
-  }
-  if (dbg) {
-    ctx->comm_host_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
-    if ((++ctx->comm_calls % 64) == 0)
-      fprintf(stderr, "balm_hip: %ld ncclAllReduce calls, %.1f us of host time per call (last: %ld doubles)\n", ctx->comm_calls,
-              ctx->comm_host_us / ctx->comm_calls, n);
   }
   if (e != ncclSuccess) { ctx->err = std::string("ncclAllReduce: ") + r->GetErrorString(e); return BALM_ERR_HIP; }
   return BALM_OK;

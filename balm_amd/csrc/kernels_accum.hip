@@ -824,7 +824,7 @@ int factors_grid(int W, int nfeat, int form) {
   if (per_cu < 1) per_cu = 1;
   if (per_cu > 4) per_cu = 4;
   int grid = 256 * per_cu;
-  if (const char *e = getenv("BALM_FACTORS_GRID")) { const int g = atoi(e); if (g > 0) grid = g; }      // A/B runs
+  // (grids of 256 / 768 / 1024 workgroups instead of 256 per resident workgroup of a CU: 0.72 / 0.65 / 0.55 vs 0.54 ms, profiles/r04d_factors_ab.txt)
   if (grid > nfeat) grid = nfeat;
   if (grid < 1) grid = 1;
   return grid;
@@ -1020,9 +1020,9 @@ SyrkPlan plan_syrk(int ntiles, long K) {
     // 83 of the iteration's 155 us (profiles/r04w_small_lm_kernels.txt).  While one round of the 1024 wave slots is not full: the shortest
     // waves (whole turns of the prefetch ring) whose slices still fit that round, and as many slices as that length needs -- so the padding
     // of K stays below one wave's length.  Their partial tiles (51 KB each, <= 52 MB in all) are noise next to the serial MFMAs they replace.
-    static const bool off = getenv("BALM_SYRK_SMALL") && getenv("BALM_SYRK_SMALL")[0] == '0';      // A/B
+    // (A/B against >= 64 k-steps per wave: W = 20 / F = 150 0.156 -> 0.081 ms per iteration, profiles/r04x_small_windows_syrk_plan.txt)
     const long one_round = 1024 / ntiles > 1 ? 1024 / ntiles : 1;
-    if (max_sg < one_round && !off) {
+    if (max_sg < one_round) {
       long nst = SYRK_NBUF;
       while ((steps + nst - 1) / nst > one_round) nst += SYRK_NBUF;
       p.SG = (int)((steps + nst - 1) / nst);

@@ -716,6 +716,16 @@ __global__ __launch_bounds__(256) void k_ldl_apply(const double *__restrict__ A,
 }
 
 // un-permute, q1 = 0.5 dx.(u D dx - g)    (bavoxel.hpp:1127)
+// The last solve of this context gave up on a wait (poll limit: its workgroups were not all resident -- somebody else held CUs):
+// k_ldl_finish has poisoned dx.  Host-synchronous; called only after a non-finite step was seen.
+bool solve_timed_out(balm_ctx *c) {
+  const int P = c->nA / NB;
+  int flag = 0;
+  if (hipStreamSynchronize(c->stream) != hipSuccess) return false;
+  if (hipMemcpy(&flag, c->d_flags + (size_t)2 * (2 * P + 1) * P + P, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return false;
+  return flag != 0;
+}
+
 // ------------------------------------------------------------------------------------------------
 // pose update: left  R <- Exp(dth) R, p <- Exp(dth) p + dt   (bavoxel.hpp:1123-1125)
 //              right R <- R Exp(dth), p <- p + dt            (bavoxel.hpp:1119-1120)
@@ -829,27 +839,32 @@ __global__ __launch_bounds__(1024) void k_ldl_finish(const double *__restrict__ 
 //     step, round 3's unexplained "communicator tax".  With plain launches it is gone (4.29 vs 4.26 ms/step at config 2);
 //   * issued from a thread other than the process's first it leaves ROCm 7.2 in a state that segfaults at exit (tools/exp_crash.py),
 //     which is why the device threads of balm_create_multi had no persistent solve in round 3.
-// BALM_COOP=1 brings the cooperative launch back (A/B).
-static bool coop_wanted(const balm_ctx *c) {
-  static const char *e = getenv("BALM_COOP");
-  if (e && e[0] == '1') return !(c->multi && c->multi->n > 1);      // (never from a device thread of a multi-device context)
-  return false;
+// Round 5: the cooperative form is gone from the library (its A/B: profiles/r04b_solve_coop.txt).  What it used to guarantee --
+// co-residency when somebody else holds CUs -- is covered in two ways: (1) the grid is sized for the device's slots DIVIDED by the
+// contexts of this process alive on that device (live_contexts_on: two ordinary contexts driven from two threads each get half, as
+// loopback shards always did), and (2) a wait that does time out (another PROCESS on the GPU, a foreign stream's long kernel) raises
+// the abort flag, and the host retries that solve ONCE on the launch path and stays there (balm_capi.hip: solve_timed_out /
+// persistent_off) instead of reporting BALM_ERR_NUMERIC.
+static std::atomic<int> g_live_contexts[64];
+void context_born(int device) { if (device >= 0 && device < 64) g_live_contexts[device].fetch_add(1); }
+void context_gone(int device) { if (device >= 0 && device < 64) g_live_contexts[device].fetch_sub(1); }
+static int live_contexts_on(int device) {
+  const int v = (device >= 0 && device < 64) ? g_live_contexts[device].load() : 1;
+  return v < 1 ? 1 : v;
 }
-// Loopback shards (the one-GPU test vehicle of the multi-device context) run their replicated solves on n streams of ONE device at
-// the same time: each replica may only count on 1/n of the device's slots, or the plain launches would wait for each other's CUs.
+// (The shards of a loopback multi-device context are contexts of one device like any others: n replicated solves at the same time.)
 static int persistent_slots(const balm_ctx *c, int cap) {
-  if (cap > 0 && c->multi && c->multi->n > 1 && c->multi->loopback) return cap / c->multi->n;
-  return cap;
+  return cap > 0 ? cap / live_contexts_on(c->device) : cap;
 }
 template <class Args>
 static hipError_t persistent_launch(const balm_ctx *c, void (*kernel)(Args), dim3 grid, dim3 block, Args &a, size_t lds, hipStream_t s) {
-  if (coop_wanted(c)) {
-    void *args[] = {(void *)&a};
-    return hipLaunchCooperativeKernel((const void *)kernel, grid, block, args, (unsigned)lds, s);
-  }
+  (void)c;
   hipLaunchKernelGGL(kernel, grid, block, lds, s, a);
   return hipGetLastError();
 }
+
+// BALM_SOLVE (A/B runs, tests/test_gpu_solve.py): "launches" / "fused" / "chain" / "chainb" / "small" force one path; read per call
+static const char *solve_mode() { return getenv("BALM_SOLVE"); }
 
 #include "kernels_chain.inc"
 
@@ -877,15 +892,11 @@ constexpr int CHAIN_MIN_P = 5, CHAIN_MAX_P = 40;      // (from 31 panels on the 
 // k_ldl_backsolve (kernels_chain.inc): the identity rows that yield L^-T D^+ are 70 % of the far updates at P = 63.  Not when the
 // caller needs that inverse (balm_pose_covariance: c->need_minv).  BALM_SOLVE=chainb forces it from CHAIN_MIN_P panels on.
 constexpr int CHAINB_MIN_P = 31, CHAINB_MAX_P = 100;      // n = 1488 .. 4800 (profiles/r03z_solve_paths_by_window.txt: n = 3600 1.44 vs 2.11 ms on the launch path, n = 4800 3.00 vs 4.10)
-static bool multi_persistent_off() {
-  static const char *e = getenv("BALM_MULTI_PERSISTENT");
-  return e && e[0] == '0';
-}
 static bool solve_wants_backsub(const balm_ctx *c) {
   const int P = c->nA / NB;
-  const char *mode = getenv("BALM_SOLVE");
-  if (c->need_minv || c->chain_cap == 0 || c->chain_refused_P[0] == P || (c->multi && c->multi->n > 1 && multi_persistent_off())) return false;
-  if (c->multi && c->multi->n > 1 && c->multi->loopback && P * c->multi->n > (c->chain_cap > 0 ? c->chain_cap : 256)) return false;   // k_ldl_backsolve's P workgroups per replica, all resident
+  const char *mode = solve_mode();
+  if (c->need_minv || c->chain_cap == 0 || c->chain_refused_P[0] == P || c->persistent_off) return false;
+  if (P * live_contexts_on(c->device) > (c->chain_cap > 0 ? c->chain_cap : 256)) return false;   // k_ldl_backsolve's P workgroups per context of the device, all resident
   if (mode && !strcmp(mode, "chainb")) return P >= CHAIN_MIN_P && P <= 100;
   if (mode) return false;                              // launches / fused / chain: the other paths, as asked
   return P >= CHAINB_MIN_P && P <= CHAINB_MAX_P;
@@ -898,12 +909,9 @@ static bool solve_wants_chain(const balm_ctx *c, const char *mode) {
 
 bool solve_is_persistent(const balm_ctx *c) {
   const int P = c->nA / NB;
-  const char *mode = getenv("BALM_SOLVE");              // A/B: "launches" / "fused" / "chain" force one path
+  const char *mode = solve_mode();
   const bool forced = mode && (!strcmp(mode, "fused") || !strcmp(mode, "chain"));
-  // The device threads of an in-process multi-device context launch it PLAINLY (persistent_launch: a cooperative launch from a
-  // thread other than the process's first leaves ROCm 7.2 in a state that segfaults at process exit, tools/exp_crash.py).
-  // BALM_MULTI_PERSISTENT=0: those replicas take the launch path instead (0.45 vs 0.28 ms per solve at n = 1200).
-  if (c->multi && c->multi->n > 1 && multi_persistent_off()) return false;
+  if (c->persistent_off) return false;                  // a wait of a persistent kernel timed out on this context once: launch path from then on
   if (mode && !strcmp(mode, "launches")) return false;
   if (solve_wants_backsub(c)) return true;
   if (forced) return P >= 2 && (c->fused_cap != 0 || c->chain_cap != 0);
@@ -934,12 +942,11 @@ static void launch_factor(balm_ctx *c) {
   if (dbg) fprintf(stderr, "balm_hip: solve P=%d persistent=%d backsub=%d chain_cap=%d fused_cap=%d multi=%d\n", P, (int)want_fused,
                    (int)solve_wants_backsub(c), c->chain_cap, c->fused_cap, c->multi ? c->multi->n : 0);
   if (want_fused && solve_wants_backsub(c)) {
-    if (launch_factor_chain(c, /*ident=*/getenv("BALM_CHAINB_IDENT") != nullptr, c->solve_tiled)) { c->solve_backsub = true; return; }      // (debug: identity rows kept)
+    if (launch_factor_chain(c, /*ident=*/false, c->solve_tiled)) { c->solve_backsub = true; return; }
     if (P > FUSED_MAX_P) want_fused = false;             // (refused: such a window is the launch path's, not k_ldl_fused's)
     if (c->solve_tiled) { c->solve_tiled = false; launch_build_A(c); }      // ... and the other paths read the column-major matrix
   } else {
-    const char *mode = getenv("BALM_SOLVE");
-    if (want_fused && solve_wants_chain(c, mode) && launch_factor_chain(c, true, false)) return;
+    if (want_fused && solve_wants_chain(c, solve_mode()) && launch_factor_chain(c, true, false)) return;
   }
   if (want_fused) {
     const size_t lds = (size_t)(12 * FLR + 2 * NB * NB + NB) * sizeof(double);
@@ -1014,12 +1021,14 @@ void launch_solve(balm_ctx *c, bool new_hessian, int upd_form, const double *upd
     else if (nA <= 256 * 16) hipLaunchKernelGGL(k_rank_diag<16>, grid, dim3(256), lds, s, c->d_H, n, nA, c->d_perm);
     else hipLaunchKernelGGL(k_rank_diag<25>, grid, dim3(256), lds, s, c->d_H, n, nA, c->d_perm);
   }
-  // [A ; rhs] tile by tile for k_ldl_chain + k_ldl_backsolve (no identity rows, nobody else reads the matrix); BALM_TILED=0: A/B
-  {
-    const char *te = getenv("BALM_TILED");
-    c->solve_tiled = solve_wants_backsub(c) && !getenv("BALM_CHAINB_IDENT") && !(te && te[0] == '0');
-  }
+  // [A ; rhs] tile by tile for k_ldl_chain + k_ldl_backsolve (no identity rows, nobody else reads the matrix)
+  c->solve_tiled = solve_wants_backsub(c);
   launch_build_A(c);
+  if (c->inject_solve_timeout) {       // tests (BALM_FAULT_INJECT="timeout,<iteration>"): the abort flag as a timed-out wait leaves it
+    const int P = nA / NB;
+    hipMemsetAsync(c->d_flags + (size_t)2 * (2 * P + 1) * P + P, 1, sizeof(int), s);
+    c->inject_solve_timeout = false;
+  }
   launch_factor(c);
   if (c->solve_backsub) {           // x (permuted order) -> chunk 0 of d_x; chunk 1 is the workgroups' exchange buffer
     const int P = nA / NB;

@@ -92,16 +92,79 @@ def load_window(data_dir, max_poses=None):
     return relative_to_first(poses), frames
 
 
+SHIPPED_WINDOW_NPZ = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "datasets", "realworld_w177.npz")
+
+
+def end_to_end(npz_path=SHIPPED_WINDOW_NPZ, device=0, reps=5):
+    """benchmark_realworld.cpp:183-218 on the shipped window, from HOST memory to optimised poses, through the C ABI: scans in
+    pageable numpy arrays -> balm_associate (pinned-ring upload + device association) -> balm_damping_iter with the driver's
+    constants.  `npz_path`: xyz [n,3] float32 in scan order, counts [W], poses [W,12] (tools/make_realworld_fixture.py writes it
+    from datas/benchmark_realworld with this module's readers), optionally ref_poses / ref_log = the reference's own result.
+    First repetition = cold (arena, pinned ring, code objects); the figures are the median of the others.  -> dict."""
+    from . import capi
+    d = np.load(npz_path)
+    xyz = np.ascontiguousarray(d["xyz"], dtype=np.float32).reshape(-1, 3)
+    counts = np.asarray(d["counts"]).astype(np.int64)
+    poses = np.ascontiguousarray(d["poses"], dtype=np.float64)
+    W = int(counts.shape[0])
+    fid = np.repeat(np.arange(W, dtype=np.int32), counts)
+    ctx = capi.Context(W, device, capi.FLAG_TIMING)
+    rows = []
+    out = lg = None
+    F = nroots = 0
+    for rep in range(reps + 1):
+        ctx.reset_timing()
+        t0 = time.perf_counter()
+        F, nroots, _ = ctx.associate(xyz, fid, poses, 2.0, want_features=False)
+        t1 = time.perf_counter()
+        out, lg = ctx.damping_iter(poses, form=capi.FORM_LEFT, u0=0.01, max_iter=10, min_planes=20)
+        t2 = time.perf_counter()
+        tm = ctx.timing()
+        rows.append(dict(total=(t2 - t0) * 1e3, associate=(t1 - t0) * 1e3, lm=(t2 - t1) * 1e3, upload=tm["upload"][0],
+                         assoc_device=tm["voxel"][0]))
+    ctx.close()
+    med = {k: float(np.median([r[k] for r in rows[1:]])) for k in rows[0]}
+    up_bytes = xyz.nbytes + fid.nbytes
+    res = {
+        "what": "BASELINE configs[4] as shipped (datas/benchmark_realworld: %d scans, %d points): host scans -> balm_associate -> "
+                "balm_damping_iter (u0=0.01, <=10 it., >=20 planes/pose) -> poses, wall clock through the C ABI from pageable host "
+                "memory; median of %d warm repetitions" % (W, xyz.shape[0], reps),
+        "scans": W, "points": int(xyz.shape[0]), "root_voxels": int(nroots), "features": int(F), "lm_iterations": int(len(lg)),
+        "ms_total": med["total"], "ms_associate_call": med["associate"], "ms_lm_call": med["lm"],
+        "ms_upload": med["upload"], "upload_bytes": int(up_bytes), "upload_gb_per_s": up_bytes / med["upload"] / 1e6 if med["upload"] > 0 else None,
+        "ms_associate_device": med["assoc_device"], "ms_cold_first_call": rows[0]["total"],
+        "lm_ms_per_iteration": med["lm"] / max(len(lg), 1), "final_residual": float(lg[-1, 1]),
+    }
+    if "ref_poses" in d.files:
+        ref, rl = d["ref_poses"], d["ref_log"]
+        rot = tr = 0.0
+        for x, y in zip(out, ref):
+            D = x[:9].reshape(3, 3) @ y[:9].reshape(3, 3).T
+            c = min(1.0, max(-1.0, (np.trace(D) - 1.0) * 0.5))
+            sn = 0.5 * np.linalg.norm([D[2, 1] - D[1, 2], D[0, 2] - D[2, 0], D[1, 0] - D[0, 1]])
+            rot = max(rot, float(np.arctan2(sn, c)))
+            tr = max(tr, float(np.linalg.norm(x[9:] - y[9:])))
+        res["vs_reference"] = {"max_rot_rad": rot, "max_trans_m": tr, "iterations_reference": int(len(rl)),
+                               "ok": bool(rot <= 1e-5 and tr <= 1e-4 and len(rl) == len(lg)),
+                               "what": "final poses against the reference's compiled cut_voxel/recut/tras_opt + BALM2::damping_iter on the same files"}
+    return res
+
+
 def main(argv=None):
     import argparse
     ap = argparse.ArgumentParser()
-    ap.add_argument("data_dir")
+    ap.add_argument("data_dir", help="directory with alidarPose.csv + full<k>.pcd; or --npz")
+    ap.add_argument("--npz", action="store_true", help="data_dir is a window file as end_to_end() reads it: print its timing dict")
     ap.add_argument("--voxel", type=float, default=2.0)
     ap.add_argument("--device", type=int, default=0)
     ap.add_argument("--gpu-assoc", action="store_true", help="(default since round 2; accepted for old command lines)")
     ap.add_argument("--out", default=None, help="write optimised poses (W x 12) here as .npy")
     a = ap.parse_args(argv)
     from . import capi
+    if a.npz:
+        import json
+        print(json.dumps(end_to_end(a.data_dir, a.device)))
+        return 0
     t = time.time()
     poses, frames = load_window(a.data_dir)
     t_read = time.time() - t

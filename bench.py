@@ -269,6 +269,7 @@ def main(argv=None):
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--no-strong-ref", action="store_true",
                     help="N = 1: skip the extra untimed-contract leg that runs configs[3]'s 200 000 features on the one GPU")
+    ap.add_argument("--no-realworld", action="store_true", help="N = 1: skip the shipped-window end-to-end leg (datasets/realworld_w177.npz)")
     ap.add_argument("--no-accept", action="store_true", help="N > 1: skip the untimed acceptance run against the reference's golden trace")
     ap.add_argument("--transport", default="rccl", choices=["rccl", "hook"],
                     help="N > 1: RCCL inside the library (stream-ordered) or the torch.distributed hook")
@@ -532,6 +533,20 @@ def main(argv=None):
             ctx.set_features(sc.clusters, None, sc.coeffs)
         except Exception as e:
             out["strong_scaling_reference"] = {"error": repr(e)}
+    if n_gpus == 1 and not multi and not args.no_cpu and not args.no_realworld:
+        # the path the reference ships data for (benchmark_realworld.cpp:183-218), end to end from host memory; an extra key,
+        # outside the timed region of `value`
+        from balm_amd import realworld as rw
+        if os.path.exists(rw.SHIPPED_WINDOW_NPZ):
+            try:
+                ctx.close()
+                out["realworld_end_to_end"] = rw.end_to_end(rw.SHIPPED_WINDOW_NPZ, local_rank)
+                ctx = capi.Context(W, local_rank, capi.FLAG_TIMING)
+                ctx.set_features(sc.clusters, None, sc.coeffs)
+            except Exception as e:
+                out["realworld_end_to_end"] = {"error": repr(e)}
+        else:
+            out["realworld_end_to_end"] = {"skipped": "datasets/realworld_w177.npz not present (tools/make_realworld_fixture.py writes it where the shipped data exists)"}
     if n_gpus == 1 and not args.no_cpu:
         try:
             out["cpu_baseline"] = cpu_baseline(sc, ctx, args.cpu_seconds)

@@ -107,6 +107,17 @@ int balm_comm_info(balm_ctx *ctx, long *out4);
 int balm_set_features(balm_ctx *ctx, int F, const double *clusters, const double *fix,
                       const double *coeffs);
 
+/* The same for a caller whose clusters are NOT one flat array -- VOX_HESS keeps F borrowed
+ * `const vector<PointCluster>*` (bavoxel.hpp:24-26, filled by push_voxel :30-51): `fill(user, f0, f1, dst)`
+ * writes the clusters of features [f0, f1), (f1 - f0) * W * 10 doubles in the layout above, to dst.  dst is
+ * a pinned staging chunk of the library that leaves for the device as soon as it is full, so the table is
+ * never flattened into a second host copy.  fill is called from several host threads of the library at
+ * once, on disjoint feature ranges, every feature exactly once, before the call returns; it must only read
+ * the caller's data.  balm_set_features is this call with a memcpy as fill. */
+typedef void (*balm_fill_clusters_fn)(void *user, int f0, int f1, double *dst);
+int balm_set_features_cb(balm_ctx *ctx, int F, balm_fill_clusters_fn fill, void *user, const double *fix,
+                         const double *coeffs);
+
 /* Replaces VOX_HESS::left_evaluate_acc2 (bavoxel.hpp:304-426; form 0) and
  * VOX_HESS::acc_evaluate2 (bavoxel.hpp:53-158; form 1) over features [head,end), and -- with
  * head=0,end=F -- BALM2::divide_thread_left/right (bavoxel.hpp:1025-1059,989-1023).  Outputs are
@@ -255,7 +266,9 @@ enum {
   BALM_T_VOXEL = 7,     /* adaptive-voxel association (balm_associate, device part only)      */
   BALM_T_COV = 8,       /* balm_pose_covariance: covariance factors, its two SYRKs, H^-1 R H^-T */
   BALM_T_COMM = 9,      /* the all-reduces of the sharded path (stream time: includes waiting for the slowest rank) */
-  BALM_T_COUNT = 10
+  BALM_T_UPLOAD = 10,   /* the caller's big host arrays on their way to HBM (clusters, points, ids): first DMA start to last DMA
+                           end on the library's stream, i.e. including the host threads' fills of the pinned chunks            */
+  BALM_T_COUNT = 11
 };
 int balm_get_timing(balm_ctx *ctx, double *ms, long *count);
 
@@ -283,9 +296,9 @@ const char *balm_version(void);
 
 /* ABI revision of this header.  It changes whenever a struct above grows, an enum gains a member that sizes a caller's array
  * (BALM_T_COUNT) or an entry point changes its meaning: 3 = round 3 (balm_voxel_opts gained fix_point_limit / defer_recut,
- * BALM_T_COUNT went from 9 to 10), 4 = this header (balm_abi_version itself).  A caller built against another revision must not call anything else:
+ * BALM_T_COUNT went from 9 to 10), 4 = round 4 (balm_abi_version itself), 5 = this header (balm_set_features_cb, BALM_T_UPLOAD: BALM_T_COUNT 11).  A caller built against another revision must not call anything else:
  *     if (balm_abi_version() != BALM_ABI_VERSION) { refuse }                                                              */
-#define BALM_ABI_VERSION 4
+#define BALM_ABI_VERSION 5
 int balm_abi_version(void);
 
 #ifdef __cplusplus

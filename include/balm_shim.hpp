@@ -240,16 +240,23 @@ class BALM2_HIP {
     const size_t F = vh.plvec_voxels.size();
     if (!force && loaded_ == (const void *)&vh && loaded_F_ == F) return;
     const int W = win_size;
-    std::vector<double> cl(F * (size_t)W * 10), fx(F * 10), co(F);
+    std::vector<double> fx(F * 10), co(F);
     bool any_fix = false;
     for (size_t a = 0; a < F; a++) {
-      const std::vector<PointCluster> &v = *vh.plvec_voxels[a];
-      for (int i = 0; i < W; i++) put(v[(size_t)i], cl.data() + (a * W + i) * 10);
       put(*vh.sig_vecs[a], fx.data() + a * 10);
       any_fix = any_fix || vh.sig_vecs[a]->N != 0;
       co[a] = vh.coeffs[a];
     }
-    check(balm_set_features(ctx_, (int)F, cl.data(), any_fix ? fx.data() : nullptr, co.data()));
+    // the F x W clusters go from the octree's own vectors straight into the library's pinned upload chunks, pulled by its
+    // host threads (balm_set_features_cb): no flattened 80-bytes-per-cluster copy of the table on the way
+    struct Src { const VOX_HESS *vh; int W; } src{&vh, W};
+    check(balm_set_features_cb(ctx_, (int)F, [](void *user, int f0, int f1, double *dst) {
+      const Src &s = *static_cast<const Src *>(user);
+      for (int a = f0; a < f1; a++) {
+        const std::vector<PointCluster> &v = *s.vh->plvec_voxels[(size_t)a];
+        for (int i = 0; i < s.W; i++) put(v[(size_t)i], dst + ((size_t)(a - f0) * s.W + i) * 10);
+      }
+    }, &src, any_fix ? fx.data() : nullptr, co.data()));
     loaded_ = (const void *)&vh;
     loaded_F_ = F;
   }

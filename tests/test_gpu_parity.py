@@ -95,6 +95,31 @@ def test_feature_subranges_add_up():
     c.close()
 
 
+@pytest.mark.parametrize("W,F,drop", [(20, 37, 0.2), (177, 900, 0.6), (200, 3000, 0.0)])
+def test_set_features_through_the_fill_callback_is_the_flat_upload(W, F, drop):
+    """balm_set_features_cb (include/balm_shim.hpp's upload: VOX_HESS's borrowed per-feature vectors pulled straight into the
+    library's pinned chunks by its host threads) installs the same table as balm_set_features on the flat array: H, g, r bit for
+    bit, same work model and sparse plan; the 3 000-feature table (48 MB) takes the multi-chunk ring path."""
+    sc, _ = make_scene(77, W, F, 6, drop=drop)
+    a = capi.Context(W, 0, capi.FLAG_TIMING)
+    a.set_features(sc.clusters, None, sc.coeffs)
+    Ha, ga, ra = a.evaluate(0, sc.poses_init)
+    b = capi.Context(W, 0, capi.FLAG_TIMING)
+    b.set_features_cb([sc.clusters[k].copy() for k in range(F)], None, sc.coeffs)
+    Hb, gb, rb = b.evaluate(0, sc.poses_init)
+    assert np.array_equal(Ha, Hb) and np.array_equal(ga, gb) and ra == rb
+    assert a.work_model() == b.work_model()
+    assert a.timing()["upload"][1] == 1 and b.timing()["upload"][1] == 1 and a.timing()["upload"][0] > 0
+    Ho, go, ro = orc.evaluate_threads(0, sc.clusters, None, sc.coeffs, sc.poses_init, 8)
+    assert rel_err(Hb, Ho) < HTOL and rel_err(gb, go) < HTOL and abs(rb - ro) / ro < 1e-12
+    # a second table through the same ring (its chunks may still be draining), smaller and larger than the first
+    for F2 in (max(2, F // 3), F):
+        b.set_features_cb([sc.clusters[k].copy() for k in range(F2)], None, sc.coeffs[:F2])
+        a.set_features(sc.clusters[:F2], None, sc.coeffs[:F2])
+        assert np.array_equal(a.evaluate(0, sc.poses_init)[0], b.evaluate(0, sc.poses_init)[0])
+    a.close(); b.close()
+
+
 def test_linearity_in_weights():
     """size-independent property: H, g, r are linear in the feature weights"""
     sc, _ = make_scene(13, 24, 80, 6)

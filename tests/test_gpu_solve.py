@@ -376,3 +376,82 @@ def test_lm_loop_reports_non_finite_input_on_a_small_window():
     out, lg = c.damping_iter(sc.poses_init, u0=0.01, max_iter=5)
     assert np.all(np.isfinite(out)) and lg[-1, 1] < lg[0, 0]
     c.close()
+
+
+def test_solve_trace_switch_records_the_chain_phases(monkeypatch):
+    """BALM_SOLVE_TRACE=1 at balm_create: balm_get_solve_trace returns the persistent kernel's per-(row block, column, phase) ticks
+    of the last factorisation (tools/chain_check.py reads them); without the switch: no buffer, BALM_ERR_STATE."""
+    monkeypatch.setenv("BALM_SOLVE_TRACE", "1")
+    W = 100
+    n = 6 * W
+    rng = np.random.default_rng(3)
+    B = rng.standard_normal((n, n))
+    H = B @ B.T / n + np.diag(rng.uniform(0.5, 5.0, n))
+    g = rng.standard_normal(n)
+    c = capi.Context(W)
+    dx, _ = c.solve_damped(H, g, 0.1)
+    assert rel_err(dx, np.linalg.solve(H + 0.1 * np.diag(np.diag(H)), -g)) < 1e-9
+    tr = c.solve_trace()
+    assert tr.shape[2] == 6 and (tr != 0).any()
+    c.close()
+    monkeypatch.delenv("BALM_SOLVE_TRACE")
+    c = capi.Context(W)
+    c.solve_damped(H, g, 0.1)
+    with pytest.raises(capi.BalmError):
+        c.solve_trace()
+    c.close()
+
+
+@pytest.mark.parametrize("W,F", [(100, 400), (200, 900), (40, 200)])
+def test_a_timed_out_persistent_solve_is_retried_on_the_launch_path(W, F, monkeypatch):
+    """A wait inside k_ldl_chain that hits its poll limit (its workgroups not all resident: another process or stream holds CUs)
+    raises the abort flag and k_ldl_finish poisons the step.  The LM loop then repeats that iteration's solve on the launch path and
+    stays there (BALM_FAULT_INJECT="timeout,<iteration>" raises the flag the way the kernel would): same accept sequence, same poses
+    to rounding as the undisturbed run, no BALM_ERR_NUMERIC."""
+    sc, _ = make_scene(5, W, F, 6, drop=0.2)
+    c = capi.Context(W)
+    c.set_features(sc.clusters, None, sc.coeffs)
+    p0, l0 = c.damping_iter(sc.poses_init, u0=0.01, max_iter=10)
+    c.close()
+    monkeypatch.setenv("BALM_FAULT_INJECT", "timeout,1")
+    monkeypatch.setenv("BALM_SOLVE_DEBUG", "1")
+    c = capi.Context(W)
+    c.set_features(sc.clusters, None, sc.coeffs)
+    p1, l1 = c.damping_iter(sc.poses_init, u0=0.01, max_iter=10)
+    assert len(l0) == len(l1) and np.array_equal(l0[:, 6], l1[:, 6])
+    assert np.allclose(l0[:, :3], l1[:, :3], rtol=1e-9, atol=0) and np.abs(p0 - p1).max() < 1e-10
+    # ... and the context keeps solving (on the launch path) afterwards
+    monkeypatch.delenv("BALM_FAULT_INJECT")
+    p2, l2 = c.damping_iter(sc.poses_init, u0=0.01, max_iter=10)
+    assert np.abs(p2 - p0).max() < 1e-10
+    c.close()
+
+
+def test_two_live_contexts_on_one_device_solve_at_the_same_time():
+    """Plain launches of the persistent kernels need every workgroup resident; two ordinary contexts driven from two threads
+    each size their grids for HALF the device's slots (contexts alive per device are counted), so neither can starve the other
+    into its poll limit.  40 concurrent solves per thread at n = 1200, each against LAPACK."""
+    import threading
+    W = 200
+    n = 6 * W
+    rng = np.random.default_rng(11)
+    B = rng.standard_normal((n, n))
+    H = B @ B.T / n + np.diag(rng.uniform(0.5, 5.0, n))
+    g = rng.standard_normal(n)
+    ref = np.linalg.solve(H + 0.1 * np.diag(np.diag(H)), -g)
+    ctxs = [capi.Context(W), capi.Context(W)]
+    errs = [[], []]
+
+    def work(k):
+        for _ in range(40):
+            dx, _ = ctxs[k].solve_damped(H, g, 0.1)
+            errs[k].append(rel_err(dx, ref))
+
+    th = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert len(errs[0]) == 40 and len(errs[1]) == 40 and max(errs[0] + errs[1]) < 1e-9
+    for c in ctxs:
+        c.close()

@@ -6,7 +6,10 @@ sys.path.insert(0, ROOT)
 import numpy as np
 from balm_amd import capi, scene
 
-for W, F in ((100, 2000), (200, 20000), (200, 50000)):
+SIZES = ((100, 2000), (200, 20000), (200, 50000))
+if len(sys.argv) == 3:                      # one size: python tools/bench_cov.py 200 50000  (kernel tables, PMC passes)
+    SIZES = ((int(sys.argv[1]), int(sys.argv[2])),)
+for W, F in SIZES:
     sc = scene.generate(9, W, F, 6, mode=1)
     fix = 0.3 * sc.clusters[:, 0]
     fix[:, 9] = np.round(fix[:, 9])

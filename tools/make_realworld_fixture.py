@@ -51,8 +51,17 @@ print("sub-window W=%d: %d points, %d features -> %s (%.1f MB)" % (WS, npts, cl.
 poses_p, frames = rw.load_window(src)
 g = np.load(os.path.join(ROOT, "oracle", "_ref", "realworld_features.npz"))
 assert np.abs(poses_p - g["poses"]).max() < 1e-13 and sum(f.shape[0] for f in frames) == int(g["n_points"])
-dst = os.path.join(ROOT, "oracle", "_ref", "realworld_scans_w177.npz")
-np.savez_compressed(dst, xyz=np.concatenate(frames), counts=np.array([f.shape[0] for f in frames]))
+# INPUT data (scans + initial poses) and the reference's final poses as the expected output: datasets/realworld_w177.npz is what
+# bench.py's `realworld_end_to_end` leg and `python -m balm_amd.realworld --npz` read -- no checker code involved; the tests'
+# older name under oracle/_ref is a link to it
+os.makedirs(os.path.join(ROOT, "datasets"), exist_ok=True)
+dst = os.path.join(ROOT, "datasets", "realworld_w177.npz")
+np.savez_compressed(dst, xyz=np.concatenate(frames), counts=np.array([f.shape[0] for f in frames]), poses=g["poses"],
+                    ref_poses=g["ref_poses"], ref_log=g["ref_log"])
+lnk = os.path.join(ROOT, "oracle", "_ref", "realworld_scans_w177.npz")
+if os.path.lexists(lnk):
+    os.remove(lnk)
+os.symlink(os.path.join("..", "..", "datasets", "realworld_w177.npz"), lnk)
 print("full window: %d scans -> %s (%.1f MB)" % (len(frames), dst, os.path.getsize(dst) / 1e6))
 
 # --- the consistency experiment's shipped scans (datas/consistency: 101 x 28 800 points, simulator output) -> N4
