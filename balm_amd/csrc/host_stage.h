@@ -2,7 +2,7 @@
 //
 // The caller's memory is pageable; hipMemcpyAsync from it is the runtime's own bounce copy, one thread, 10-14 GB/s of a
 // 63 GB/s link (round 4: 161 MB of points in 15 ms in front of a 3.6 ms association).  Here a ring of pinned chunks is
-// filled by a small pool of host threads -- memcpy of the caller's array, or the caller's fill callback writing its
+// filled by a small pool of host threads (15 + the caller on a big host) -- memcpy of the caller's array, or the caller's fill callback writing its
 // clusters straight into the chunk (balm_set_features_cb: no flattened copy in between) -- while the DMA engine drains the
 // previous chunk.  One wake-up of the pool per upload, not per chunk: the workers take (chunk, slice) tasks off one
 // counter and wait for the chunk's buffer to be free; the calling thread only issues the DMAs and frees buffers.
@@ -42,6 +42,9 @@ class HostPool {
   HostPool() {
     unsigned hc = std::thread::hardware_concurrency();
     int n = hc >= 64 ? 15 : hc >= 16 ? 7 : hc >= 4 ? 3 : 1;      // + the calling thread
+#ifdef BALM_HOST_POOL_THREADS                                     // (tools/ubench_h2d.hip: the pipeline by thread count)
+    n = BALM_HOST_POOL_THREADS - 1;
+#endif
     for (int t = 0; t < n; t++) th_.emplace_back([this, t] { loop(t); });
   }
   ~HostPool() {
@@ -92,11 +95,20 @@ inline void parallel_ranges(size_t n, size_t grain, const std::function<void(siz
 }
 
 struct PinnedRing {
-  static constexpr int NBUF = 3;
-  static constexpr size_t CHUNK = (size_t)16 << 20;
-  char *buf[NBUF] = {nullptr, nullptr, nullptr};
-  hipEvent_t ev[NBUF] = {nullptr, nullptr, nullptr};
-  bool busy[NBUF] = {false, false, false};      // a DMA out of this buffer was enqueued and its event not yet waited for
+// Ring geometry, measured on the box (tools/ubench_h2d.hip, profiles/r05c_ubench_h2d.txt; 512 MB from a fresh pageable buffer; the link
+// does 55-57 GB/s from pinned memory): 16 threads, 3 x 32 MB: 51-54 GB/s; 3 x 16 MB: 43-48; 4 x 8 MB: 34; 4 x 4 MB: 40-44; 8 threads: 33;
+// 32 threads: 35 (the spinning workers get in each other's way).  The runtime's own pageable path: 27-54 GB/s on a fresh buffer.
+#ifndef BALM_STAGE_NBUF
+#define BALM_STAGE_NBUF 3
+#endif
+#ifndef BALM_STAGE_CHUNK_MB
+#define BALM_STAGE_CHUNK_MB 32
+#endif
+  static constexpr int NBUF = BALM_STAGE_NBUF;
+  static constexpr size_t CHUNK = (size_t)BALM_STAGE_CHUNK_MB << 20;
+  char *buf[NBUF] = {};
+  hipEvent_t ev[NBUF] = {};
+  bool busy[NBUF] = {};      // a DMA out of this buffer was enqueued and its event not yet waited for
 
   hipError_t init() {
     if (buf[0]) return hipSuccess;
@@ -109,8 +121,8 @@ struct PinnedRing {
   }
   void release() {
     for (int b = 0; b < NBUF; b++) {
-      if (ev[b]) { if (busy[b]) hipEventSynchronize(ev[b]); hipEventDestroy(ev[b]); ev[b] = nullptr; }
-      if (buf[b]) { hipHostFree(buf[b]); buf[b] = nullptr; }
+      if (ev[b]) { if (busy[b]) (void)hipEventSynchronize(ev[b]); (void)hipEventDestroy(ev[b]); ev[b] = nullptr; }
+      if (buf[b]) { (void)hipHostFree(buf[b]); buf[b] = nullptr; }
       busy[b] = false;
     }
   }
@@ -127,7 +139,7 @@ inline hipError_t staged_upload(PinnedRing &ring, hipStream_t stream, void *d_ds
   if (unit == 0 || unit > PinnedRing::CHUNK) return hipErrorInvalidValue;
   // the buffers may still feed the DMAs of an earlier upload
   for (int b = 0; b < PinnedRing::NBUF; b++)
-    if (ring.busy[b]) { hipEventSynchronize(ring.ev[b]); ring.busy[b] = false; }
+    if (ring.busy[b]) { (void)hipEventSynchronize(ring.ev[b]); ring.busy[b] = false; }
   if (bytes <= ((size_t)1 << 20)) {      // small: the calling thread alone, no pool wake-up
     fill(ring.buf[0], 0, bytes);
     e = hipMemcpyAsync(d_dst, ring.buf[0], bytes, hipMemcpyHostToDevice, stream);

@@ -68,8 +68,13 @@ constexpr int COV_DACC = 21;      // upper triangle of the 6x6 block S_j, row-ma
 // finished X / Y columns leave through a 3 KB LDS staging block per wavefront as fully coalesced 16-byte stores, as k_feature_factors'
 // Gt columns do (kernels_accum.hip).  Same arithmetic, same order: bit for bit the two-pass result.
 // ------------------------------------------------------------------------------------------------
+// What bounds it (round 5, profiles/r05c_cov_*.txt): registers.  ~150 doubles are alive per observation (At, Rr, Y, c_cov Gm^T, the cluster,
+// the pose): 256 VGPRs + 40-118 spilled to AGPRs = ONE wave per SIMD, 1.96 ms at W = 200 / F = 50 000 for 3.7 GB of traffic (0.30 of the
+// copy rate; the kernel is latency-bound at that occupancy, not bandwidth- or FP64-bound: ~2 000 flops per observation are 0.3 ms of
+// the FP64 pipes).  Two waves per SIMD (at most 256 registers each, 156-530 bytes of scratch per lane instead of the AGPR spills) + At
+// computed last: 1.63 ms, bit-identical.  Three are not possible: the [12 + 21][W] doubles of LDS per workgroup cap a CU at two workgroups.
 template <bool EXPLICIT, bool ONEPASS>
-__global__ __launch_bounds__(256) void k_cov_factors(const double *__restrict__ cl, const double *__restrict__ ccov,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_cov_factors(const double *__restrict__ cl, const double *__restrict__ ccov,
                                                      double sigma2, const double *__restrict__ poses,
                                                      const double *__restrict__ feat, int W, int npad, int F,
                                                      double *__restrict__ Gx, double *__restrict__ Gy,
@@ -143,32 +148,7 @@ __global__ __launch_bounds__(256) void k_cov_factors(const double *__restrict__ 
             for (int c = 0; c < 3; c++)
               Pw[r][c] = RP[r][0] * R[c] + RP[r][1] * R[3 + c] + RP[r][2] * R[6 + c] + Rv[r] * p[c] + p[r] * b[c];
         }
-        // At = [(2/NN) A u1, (2/NN) A u2, -(2/NN^2) w]: A u_k = [m0 x u_k + m_k x u0 ; s0 u_k + s_k u0],
-        // m_k = (P' - b vbar^T) u_k, s_k = (b - N vbar).u_k, w = [b x u0 ; N u0]   (BAs_left.hpp:418-428,445-446)
-        double m0[3], m1[3], m2[3], cvec[3];
-        const double vu1 = vbar[0] * u1[0] + vbar[1] * u1[1] + vbar[2] * u1[2];
-        const double vu2 = vbar[0] * u2[0] + vbar[1] * u2[1] + vbar[2] * u2[2];
-#pragma unroll
-        for (int r = 0; r < 3; r++) {
-          cvec[r] = b[r] - N * vbar[r];
-          m0[r] = Pw[r][0] * u0[0] + Pw[r][1] * u0[1] + Pw[r][2] * u0[2] - b[r] * vu0;
-          m1[r] = Pw[r][0] * u1[0] + Pw[r][1] * u1[1] + Pw[r][2] * u1[2] - b[r] * vu1;
-          m2[r] = Pw[r][0] * u2[0] + Pw[r][1] * u2[1] + Pw[r][2] * u2[2] - b[r] * vu2;
-        }
-        const double s0 = cvec[0] * u0[0] + cvec[1] * u0[1] + cvec[2] * u0[2];
-        const double s1 = cvec[0] * u1[0] + cvec[1] * u1[1] + cvec[2] * u1[2];
-        const double s2 = cvec[0] * u2[0] + cvec[1] * u2[1] + cvec[2] * u2[2];
-        double x01[3], x10[3], x02[3], x20[3], bxu[3];
-        cross3(m0, u1, x01); cross3(m1, u0, x10);
-        cross3(m0, u2, x02); cross3(m2, u0, x20);
-        cross3(b, u0, bxu);
-        const double c2 = 2.0 * iNN, c3 = -2.0 * iNN * iNN;
-#pragma unroll
-        for (int r = 0; r < 3; r++) {
-          at[r][0] = c2 * (x01[r] + x10[r]); at[3 + r][0] = c2 * (s0 * u1[r] + s1 * u0[r]);
-          at[r][1] = c2 * (x02[r] + x20[r]); at[3 + r][1] = c2 * (s0 * u2[r] + s2 * u0[r]);
-          at[r][2] = c3 * bxu[r];            at[3 + r][2] = c3 * N * u0[r];
-        }
+        const double c2 = 2.0 * iNN;
         // Gm (3x9): rows u_k^T Gkl / ((lam0 - lam_k) NN), k = 1, 2, and m = [0 0 0 0 0 0 r3]      (:431-441)
         //   Gkl[:3] = R g1([r3; p.u0])[:3] + (p - vbar) (x) [0..0 r3] - [0 | (vbar.u0) R]
         double r3[3];
@@ -339,6 +319,34 @@ __global__ __launch_bounds__(256) void k_cov_factors(const double *__restrict__ 
           for (int r = 0; r < 6; r++)
 #pragma unroll
             for (int k = r; k < 6; k++) sacc[(t++) * W + i] += w2 * S6[r][k];
+        }
+        {       // At LAST (round 5): its 18 values are not alive across the noise products above (50 -> 40 spilled registers)
+        // At = [(2/NN) A u1, (2/NN) A u2, -(2/NN^2) w]: A u_k = [m0 x u_k + m_k x u0 ; s0 u_k + s_k u0],
+          // m_k = (P' - b vbar^T) u_k, s_k = (b - N vbar).u_k, w = [b x u0 ; N u0]   (BAs_left.hpp:418-428,445-446)
+          double m0[3], m1[3], m2[3], cvec[3];
+          const double vu1 = vbar[0] * u1[0] + vbar[1] * u1[1] + vbar[2] * u1[2];
+          const double vu2 = vbar[0] * u2[0] + vbar[1] * u2[1] + vbar[2] * u2[2];
+#pragma unroll
+          for (int r = 0; r < 3; r++) {
+            cvec[r] = b[r] - N * vbar[r];
+            m0[r] = Pw[r][0] * u0[0] + Pw[r][1] * u0[1] + Pw[r][2] * u0[2] - b[r] * vu0;
+            m1[r] = Pw[r][0] * u1[0] + Pw[r][1] * u1[1] + Pw[r][2] * u1[2] - b[r] * vu1;
+            m2[r] = Pw[r][0] * u2[0] + Pw[r][1] * u2[1] + Pw[r][2] * u2[2] - b[r] * vu2;
+          }
+          const double s0 = cvec[0] * u0[0] + cvec[1] * u0[1] + cvec[2] * u0[2];
+          const double s1 = cvec[0] * u1[0] + cvec[1] * u1[1] + cvec[2] * u1[2];
+          const double s2 = cvec[0] * u2[0] + cvec[1] * u2[1] + cvec[2] * u2[2];
+          double x01[3], x10[3], x02[3], x20[3], bxu[3];
+          cross3(m0, u1, x01); cross3(m1, u0, x10);
+          cross3(m0, u2, x02); cross3(m2, u0, x20);
+          cross3(b, u0, bxu);
+          const double c3 = -2.0 * iNN * iNN;
+#pragma unroll
+          for (int r = 0; r < 3; r++) {
+            at[r][0] = c2 * (x01[r] + x10[r]); at[3 + r][0] = c2 * (s0 * u1[r] + s1 * u0[r]);
+            at[r][1] = c2 * (x02[r] + x20[r]); at[3 + r][1] = c2 * (s0 * u2[r] + s2 * u0[r]);
+            at[r][2] = c3 * bxu[r];            at[3 + r][2] = c3 * N * u0[r];
+          }
         }
       }
       if (!ONEPASS) {

@@ -94,6 +94,46 @@ def acceptance_check(ctx, poses_init, seed, W, F_total, pts):
     return res
 
 
+COMM_MODEL_MS = 0.03 + 0.07     # what the N = 1 line's prediction assumes per step: RCCL call overhead measured with a one-rank
+                                # communicator (profiles/r04b_dist_overhead.txt) + link time of the 5.9 MB all-reduce
+
+
+def one_gpu_same_problem(sc_full, W, device, steps=20):
+    """The N = 1 point of THIS run's curve, measured by THIS run: the whole problem the N ranks are about to shard, on one GPU
+    of the same box, same timed loop as the bench line (20 forced-Hessian LM steps from the noisy start), before any
+    communicator exists in the process.  -> dict"""
+    import torch
+    from balm_amd import capi
+    c = capi.Context(W, device, capi.FLAG_TIMING)
+    c.set_features(sc_full.clusters, None, sc_full.coeffs)
+    c.damping_iter(sc_full.poses_init, form=0, u0=0.1, max_iter=3, force_hess=True, no_stop=True, reanchor=False)
+    c.reset_timing()
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    done = 0
+    while done < steps:
+        m = min(20, steps - done)
+        c.damping_iter(sc_full.poses_init, form=0, u0=0.1, max_iter=m, force_hess=True, no_stop=True, reanchor=False)
+        done += m
+    torch.cuda.synchronize(device)
+    dt = time.perf_counter() - t0
+    tm = c.timing()
+    c.close()
+    return {"what": "the same %d-feature problem on ONE GPU of this box, timed by this run before any communicator existed "
+                    "(%d forced-Hessian LM steps, as the bench line)" % (sc_full.F, steps),
+            "features_total": int(sc_full.F), "steps": steps, "iterations_per_sec": steps / dt, "ms_per_step": dt / steps * 1e3,
+            "kernel_ms_per_step": {k: v[0] / steps for k, v in tm.items()}}
+
+
+def scaling_fields(ips_n, one_gpu, n_gpus):
+    """top-level keys of an N > 1 line that let a reader compute nothing himself: speed-up and efficiency against the one-GPU
+    run of the SAME problem measured in the same bench run (one_gpu = one_gpu_same_problem()'s dict, or None)"""
+    if not one_gpu or not one_gpu.get("iterations_per_sec"):
+        return {"speedup_vs_one_gpu_same_problem": None, "scaling_efficiency": None}
+    sp = ips_n / one_gpu["iterations_per_sec"]
+    return {"speedup_vs_one_gpu_same_problem": sp, "scaling_efficiency": sp / n_gpus}
+
+
 def cpu_baseline(sc, ctx, target_seconds=20.0):
     """CPU baseline leg (rank 0, N=1), timed on the box's host cores on a bounded feature sample of the same
     workload and scaled by F/F_sample, plus one full (6W)^2 LDLT solve.  Build flags are the reference's own
@@ -270,6 +310,8 @@ def main(argv=None):
     ap.add_argument("--no-strong-ref", action="store_true",
                     help="N = 1: skip the extra untimed-contract leg that runs configs[3]'s 200 000 features on the one GPU")
     ap.add_argument("--no-realworld", action="store_true", help="N = 1: skip the shipped-window end-to-end leg (datasets/realworld_w177.npz)")
+    ap.add_argument("--no-one-gpu-ref", action="store_true",
+                    help="N > 1: skip rank 0's run of the whole problem on one GPU (speedup_vs_one_gpu_same_problem / scaling_efficiency stay null)")
     ap.add_argument("--no-accept", action="store_true", help="N > 1: skip the untimed acceptance run against the reference's golden trace")
     ap.add_argument("--transport", default="rccl", choices=["rccl", "hook"],
                     help="N > 1: RCCL inside the library (stream-ordered) or the torch.distributed hook")
@@ -296,9 +338,6 @@ def main(argv=None):
     n_gpus = args.gpus if inproc else world
     multi = world > 1 or os.environ.get("BALM_BENCH_FORCE_DIST") == "1"   # the latter: exercise the N>1 code path on one GPU
     torch.cuda.set_device(local_rank)
-    if multi:
-        bdist.init_process_group("nccl")
-
     W = args.win
     if args.features > 0:
         Fg = args.features
@@ -306,10 +345,26 @@ def main(argv=None):
         Fg = F_SHARDED_TOTAL // n_gpus
     else:
         Fg = F_SINGLE
+    # N > 1: rank 0 first runs the WHOLE problem alone on its GPU -- before the process group, before any RCCL communicator --
+    # so that the line carries its own N = 1 point (the other ranks wait in the rendezvous meanwhile)
+    one_gpu = None
+    sc_full = None
+    if n_gpus > 1 and rank == 0 and not args.no_one_gpu_ref:
+        try:
+            sc_full = scene.generate(args.seed, W, Fg * n_gpus, args.pts, mode=1, feature_offset=0)
+            one_gpu = one_gpu_same_problem(sc_full, W, local_rank)
+        except Exception as e:
+            one_gpu = {"error": repr(e)}
+        if not inproc:
+            sc_full = None          # (a rank keeps only its shard)
+    if multi:
+        bdist.init_process_group("nccl")
     # every rank draws its own shard of one global scene: same trajectory and initial pose noise on all ranks
     # (engine(seed)), disjoint per-feature streams (feature_offset)
     # (one process driving all N GPUs draws the whole scene -- the same features -- and the context shards it)
-    sc = scene.generate(args.seed, W, Fg * n_gpus if inproc else Fg, args.pts, mode=1, feature_offset=0 if inproc else rank * Fg)
+    sc = sc_full if (inproc and sc_full is not None) else scene.generate(args.seed, W, Fg * n_gpus if inproc else Fg, args.pts, mode=1,
+                                                                        feature_offset=0 if inproc else rank * Fg)
+    sc_full = None
 
     loopback = inproc and os.environ.get("BALM_BENCH_LOOPBACK") == "1"
     ctx = (capi.Context(W, 0, capi.FLAG_TIMING | (capi.FLAG_LOOPBACK_SHARDS if loopback else 0), n_devices=n_gpus) if inproc
@@ -450,6 +505,7 @@ def main(argv=None):
         "comm": {"transport": comm["transport"], "ranks_reported_by_transport": comm["ranks"], "world_size": n_gpus,
                  "payload_bytes_per_evaluation": comm["payload_doubles"] * 8,
                  "allreduce_ms_per_step": timing["comm"][0] / args.steps, "allreduces_per_step": timing["comm"][1] / args.steps,
+                 "model_ms_per_step_assumed": COMM_MODEL_MS,      # what the N = 1 line's predicted curve charges per step: this run confirms or falsifies it
                  "note": "stream time of the all-reduces on rank 0 (HIP events around the RCCL calls on the library's stream): "
                          "includes waiting for the slowest rank"} if (multi or inproc) else None,
         "kernel_ms_per_step": per_step,
@@ -464,15 +520,19 @@ def main(argv=None):
     if accept is not None:
         accept.pop("_poses", None)
         out["acceptance"] = accept
+    if n_gpus > 1:
+        out["one_gpu_same_problem"] = one_gpu
+        out.update(scaling_fields(iters_per_s, one_gpu if one_gpu and "error" not in one_gpu else None, n_gpus))
     if n_gpus > 1 and out["scaling"] == "strong" and F_total == F_SHARDED_TOTAL and os.path.exists(N1_TRACE):
         # `value` at N = 1 is configs[2] (50 000 features), a 4x smaller problem than the one sharded here: the N = 1 point of THIS curve is the
         # same 200 000-feature problem on one GPU, measured by the N = 1 bench run (strong_scaling_reference) and committed with its LM trace
         try:
             t1 = json.load(open(N1_TRACE)).get("timing")
             if t1:
-                out["same_problem_on_one_gpu"] = {"iterations_per_sec": t1["iterations_per_sec"], "ms_per_step": t1["ms_per_step"],
-                                                  "source": "profiles/strong_scaling_n1_trace.json (" + t1.get("run", "the N = 1 bench run") + ")",
-                                                  "speedup_of_this_run": iters_per_s / t1["iterations_per_sec"]}
+                out["same_problem_on_one_gpu_committed"] = {"iterations_per_sec": t1["iterations_per_sec"], "ms_per_step": t1["ms_per_step"],
+                                                            "source": "profiles/strong_scaling_n1_trace.json (" + t1.get("run", "the N = 1 bench run") + "): "
+                                                                      "another box's run -- a cross-check of one_gpu_same_problem, not the basis of scaling_efficiency",
+                                                            "speedup_of_this_run": iters_per_s / t1["iterations_per_sec"]}
         except Exception:
             pass
     if n_gpus == 1 and not multi and not args.no_strong_ref and not args.no_cpu and args.features == 0 and W == 200:      # (--no-cpu: no extra legs at all)
@@ -502,7 +562,7 @@ def main(argv=None):
             # the wire time; an estimate until a multi-GPU node has measured it
             fixed_ms = per_step.get("solve", 0) + per_step.get("assemble", 0) + per_step.get("update", 0)
             t4 = d4 / k4 * 1e3
-            comm_ms = 0.03 + 0.07
+            comm_ms = COMM_MODEL_MS
             out["strong_scaling_reference"]["predicted"] = {
                 "model": "T(N) = (T(1) - fixed) / N + fixed + comm; fixed = replicated solve + assemble + pose update of this run; "
                          "comm = one-rank RCCL call overhead measured on one GPU (0.03 ms/step, profiles/r04b_dist_overhead.txt) + link time of the 5.9 MB all-reduce (0.07 ms)",
@@ -553,6 +613,13 @@ def main(argv=None):
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
         except Exception as e:   # the baseline leg must never take the GPU number down with it
             out["cpu_baseline"] = {"error": repr(e)}
+    # a sharded run must prove it really was N ranks: what the transport itself counts (ncclCommCount / the shard count)
+    ranks_seen = out["comm"]["ranks_reported_by_transport"] if out.get("comm") else 1
+    if n_gpus > 1 and ranks_seen != n_gpus:
+        out["error"] = "the transport reports %s ranks, the run was asked for %d" % (ranks_seen, n_gpus)
+        print(json.dumps(out), flush=True)
+        print("bench.py: " + out["error"], file=sys.stderr)
+        sys.exit(5)
     print(json.dumps(out), flush=True)
 
 

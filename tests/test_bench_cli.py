@@ -40,6 +40,16 @@ def test_resolve_launch_table():
         os.environ.pop("BALM_BENCH_INPROC")
 
 
+def test_scaling_fields_of_an_n_gpu_line():
+    """the N > 1 line's top-level speed-up / efficiency come from the one-GPU run of the same problem made by the same bench run"""
+    import bench
+    f = bench.scaling_fields(400.0, {"iterations_per_sec": 66.0}, 8)
+    assert abs(f["speedup_vs_one_gpu_same_problem"] - 400.0 / 66.0) < 1e-12 and abs(f["scaling_efficiency"] - 400.0 / 66.0 / 8) < 1e-12
+    assert bench.scaling_fields(400.0, None, 8) == {"speedup_vs_one_gpu_same_problem": None, "scaling_efficiency": None}
+    assert bench.scaling_fields(400.0, {"error": "x"}, 8)["scaling_efficiency"] is None
+    assert abs(bench.COMM_MODEL_MS - 0.10) < 1e-12
+
+
 @pytest.mark.skipif(__import__("torch").cuda.is_available(), reason="CPU-box behaviour")
 def test_gpus_2_without_a_gpu_says_no_gpu():
     p = _run(["--gpus", "2", "--steps", "1", "--warmup", "0"])
@@ -69,3 +79,9 @@ def test_one_process_fallback_runs_two_loopback_shards():
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["config"]["features_total"] == 3000
     assert d["config"]["launch"] == "one process, balm_create_multi"
     assert d["comm"]["ranks_reported_by_transport"] == 2
+    # the line is self-contained: its own one-GPU point of the same 3 000-feature problem, speed-up and efficiency from it
+    one = d["one_gpu_same_problem"]
+    assert one["features_total"] == 3000 and one["iterations_per_sec"] > 0
+    assert abs(d["speedup_vs_one_gpu_same_problem"] - d["value"] / one["iterations_per_sec"]) < 1e-9
+    assert abs(d["scaling_efficiency"] - d["speedup_vs_one_gpu_same_problem"] / 2) < 1e-12
+    assert d["comm"]["allreduce_ms_per_step"] > 0 and d["comm"]["model_ms_per_step_assumed"] == 0.1

@@ -5,7 +5,7 @@ root = sys.argv[1]
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(root + "/*/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
-        k = r["Kernel_Name"].split("(")[0]
+        k = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0]
         acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
         acc[k]["dur_ns"].append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
 names = sorted({c for k in acc for c in acc[k]})

@@ -28,7 +28,7 @@ def main():
         print("# %s: %d dispatches" % (dbp, len(rows)))
         prev, agg = None, {}
         for name, s, e, gx, wx, lds, scr in rows:
-            short = re.sub(r"\(.*", "", name).replace("(anonymous namespace)::", "")
+            short = re.sub(r"\(.*", "", name.replace("(anonymous namespace)::", ""))
             short = re.sub(r"^void ", "", short)
             if flt in short and not short.startswith("__amd_rocclr"):
                 gap = "%8.1f" % ((s - prev) / 1000.0) if prev is not None and s - prev < 5e6 else "       -"

@@ -4,7 +4,9 @@
 //   3. host memcpy pageable -> pinned by thread count
 //   4. hipMemcpyAsync straight from pageable memory (what round 4's entry points did)
 // hipcc --offload-arch=gfx950 -O3 -pthread tools/ubench_h2d.hip -o tools/bin/ubench_h2d
+//   5. the library's own pipeline (balm_amd/csrc/host_stage.h) on the same buffer: -DBALM_HOST_POOL_THREADS / _STAGE_CHUNK_MB / _STAGE_NBUF
 #include <hip/hip_runtime.h>
+#include "../balm_amd/csrc/host_stage.h"
 #include <chrono>
 #include <cstdio>
 #include <cstring>
@@ -90,6 +92,34 @@ int main() {
       if (gbs > best) best = gbs;
     }
     printf("hipMemcpyAsync straight from pageable memory: %6.1f GB/s\n", best);
+  }
+  {   // a FRESH pageable buffer every time (what a caller's first upload of a new array sees)
+    for (int rep = 0; rep < 3; rep++) {
+      std::vector<char> fresh(total, (char)rep);
+      const double t0 = now();
+      CK(hipMemcpyAsync(dev, fresh.data(), total, hipMemcpyHostToDevice, s0));
+      CK(hipStreamSynchronize(s0));
+      printf("hipMemcpyAsync from a fresh pageable buffer, rep %d: %6.1f GB/s\n", rep, total / (now() - t0) / 1e9);
+    }
+  }
+  {
+    balm::PinnedRing ring;
+    for (int rep = 0; rep < 4; rep++) {
+      std::vector<char> fresh(total, (char)rep);
+      const double t0 = now();
+      CK(balm::staged_copy(ring, s0, dev, fresh.data(), total));
+      const double t1 = now();
+      CK(hipStreamSynchronize(s0));
+      printf("host_stage.h pipeline (%d threads, %d x %d MB), fresh buffer, rep %d: %6.1f GB/s  (host side done after %.2f of %.2f ms)\n",
+             balm::HostPool::get().workers() + 1, BALM_STAGE_NBUF, BALM_STAGE_CHUNK_MB, rep, total / (now() - t0) / 1e9, (t1 - t0) * 1e3, (now() - t0) * 1e3);
+    }
+    for (int rep = 0; rep < 2; rep++) {
+      const double t0 = now();
+      CK(balm::staged_copy(ring, s0, dev, page.data(), total));
+      CK(hipStreamSynchronize(s0));
+      printf("host_stage.h pipeline, the warm buffer, rep %d: %6.1f GB/s\n", rep, total / (now() - t0) / 1e9);
+    }
+    ring.release();
   }
   printf("host threads: %u\n", std::thread::hardware_concurrency());
   return 0;
