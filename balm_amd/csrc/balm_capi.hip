@@ -505,6 +505,7 @@ static void one_destroy(balm_ctx *ctx) {
   for (void *p : ptrs) if (p) hipFree(p);
   if (ctx->h_scal) hipHostFree(ctx->h_scal);
   ctx->ring.release();
+  if (ctx->amail.host) hipHostFree((void *)ctx->amail.host);
   for (auto &sp : ctx->timer.pending) { hipEventDestroy(sp.a); hipEventDestroy(sp.b); }
   for (auto e : ctx->timer.pool) hipEventDestroy(e);
   if (ctx->stream) hipStreamDestroy(ctx->stream);
@@ -633,7 +634,7 @@ static int assoc_clusters_host(balm_ctx *ctx);
 // fill(f0, f1, dst): the clusters of features [f0, f1) in the ABI's layout ((f1 - f0) * W * 10 doubles) -> dst, a pinned staging
 // chunk; called from several host threads at once on disjoint ranges (host_stage.h).  The observation mask is read off the chunk
 // while it is hot in the filling thread's cache.
-using FillClusters = std::function<void(int, int, double *)>;
+using FillClusters = std::function<void(int, int, double *, unsigned char *)>;      // (f0, f1, dst, obs of those features: W bytes each)
 
 static int one_set_features_fn(balm_ctx *ctx, int F, const FillClusters &fill, const double *fix, const double *coeffs) {
   if (!ctx) return BALM_ERR_ARG;
@@ -653,13 +654,9 @@ static int one_set_features_fn(balm_ctx *ctx, int F, const FillClusters &fill, c
   hipError_t e;
   {
     Span sp(ctx, BALM_T_UPLOAD);
-    e = staged_upload(ctx->ring, ctx->stream, d_aos, count * sizeof(double), unit, [&](char *dst, size_t off, size_t len) {
+    e = staged_upload(ctx->ring, ctx->device, ctx->stream, d_aos, count * sizeof(double), unit, [&](char *dst, size_t off, size_t len) {
       const int f0 = (int)(off / unit), f1 = f0 + (int)(len / unit);
-      double *q = reinterpret_cast<double *>(dst);
-      fill(f0, f1, q);
-      unsigned char *o = obs.data() + (size_t)f0 * W;
-      const size_t cnt = (size_t)(f1 - f0) * W;
-      for (size_t t = 0; t < cnt; t++) o[t] = q[t * 10 + 9] != 0 ? 1 : 0;
+      fill(f0, f1, reinterpret_cast<double *>(dst), obs.data() + (size_t)f0 * W);
     });
   }
   if (e == hipSuccess) launch_transpose_clusters(ctx->stream, d_aos, ctx->d_cl, F, W);
@@ -674,8 +671,11 @@ static int one_set_features_fn(balm_ctx *ctx, int F, const FillClusters &fill, c
 static int one_set_features(balm_ctx *ctx, int F, const double *clusters, const double *fix, const double *coeffs) {
   if (ctx && !(ctx->multi && F == 0) && !clusters) { ctx->err = "balm_set_features: bad argument"; return BALM_ERR_ARG; }
   const size_t row = ctx ? (size_t)ctx->W * 10 : 0;
-  return one_set_features_fn(ctx, F, [clusters, row](int f0, int f1, double *dst) {
-    std::memcpy(dst, clusters + (size_t)f0 * row, (size_t)(f1 - f0) * row * sizeof(double));
+  return one_set_features_fn(ctx, F, [clusters, row](int f0, int f1, double *dst, unsigned char *o) {
+    const double *src = clusters + (size_t)f0 * row;
+    stream_copy(dst, src, (size_t)(f1 - f0) * row * sizeof(double));      // (streaming stores: the mask is read off the SOURCE)
+    const size_t cnt = (size_t)(f1 - f0) * (row / 10);
+    for (size_t t = 0; t < cnt; t++) o[t] = src[t * 10 + 9] != 0 ? 1 : 0;
   }, fix, coeffs);
 }
 
@@ -700,9 +700,9 @@ static int one_build_clusters(balm_ctx *ctx, int F, const float *xyz, const int 
   hipError_t e = hipSuccess;
   {
     Span sp(ctx, BALM_T_UPLOAD);
-    if (e == hipSuccess) e = staged_copy(ctx->ring, ctx->stream, d_xyz, xyz, (size_t)n_pts * 3 * sizeof(float));
-    if (e == hipSuccess) e = staged_copy(ctx->ring, ctx->stream, d_f, feat_id, (size_t)n_pts * sizeof(int));
-    if (e == hipSuccess) e = staged_copy(ctx->ring, ctx->stream, d_p, pose_id, (size_t)n_pts * sizeof(int));
+    if (e == hipSuccess) e = staged_copy(ctx->ring, ctx->device, ctx->stream, d_xyz, xyz, (size_t)n_pts * 3 * sizeof(float));
+    if (e == hipSuccess) e = staged_copy(ctx->ring, ctx->device, ctx->stream, d_f, feat_id, (size_t)n_pts * sizeof(int));
+    if (e == hipSuccess) e = staged_copy(ctx->ring, ctx->device, ctx->stream, d_p, pose_id, (size_t)n_pts * sizeof(int));
   }
   if (e == hipSuccess) e = hipMemsetAsync(ctx->d_cl, 0, count * sizeof(double), ctx->stream);
   int *d_flag = reinterpret_cast<int *>(ctx->d_scal + 8);           // a spare device scalar slot
@@ -836,6 +836,7 @@ static int one_associate(balm_ctx *ctx, const balm_voxel_opts *opts, const float
   float *d_xyz = nullptr; int *d_f = nullptr;
   double *d_out = nullptr, *d_coe = nullptr, *d_fix = nullptr, *d_pos = nullptr; int *d_lay = nullptr, *d_pf = nullptr;
   int F = 0; long nroots = 0; int arc = 0;
+  bool owned = true;
   size_t need = 0;
   if (!ctx->d_arena) {                  // first call: ~100 B per point covers the per-point arrays + sort scratch
     const size_t want = (size_t)n_pts * 100 + (64u << 20);
@@ -849,20 +850,41 @@ static int one_associate(balm_ctx *ctx, const balm_voxel_opts *opts, const float
   d_f = stage_take<int>(ctx, (size_t)n_pts);
   d_pos = stage_take<double>(ctx, (size_t)12 * WT);
   hipError_t e = hipSuccess;
+#ifdef BALM_STAGE_TRACE
+  const auto tw0 = std::chrono::steady_clock::now();
+#endif
   {
     Span sp(ctx, BALM_T_UPLOAD);
-    if (e == hipSuccess) e = staged_copy(ctx->ring, ctx->stream, d_xyz, xyz, (size_t)n_pts * 3 * sizeof(float));
-    if (e == hipSuccess) e = staged_copy(ctx->ring, ctx->stream, d_f, frame_id, (size_t)n_pts * sizeof(int));
+    if (e == hipSuccess) e = staged_copy(ctx->ring, ctx->device, ctx->stream, d_xyz, xyz, (size_t)n_pts * 3 * sizeof(float));
+#ifdef BALM_STAGE_TRACE
+    fprintf(stderr, "[stage] xyz copy returned after %.3f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw0).count());
+#endif
+    if (e == hipSuccess) e = staged_copy(ctx->ring, ctx->device, ctx->stream, d_f, frame_id, (size_t)n_pts * sizeof(int));
   }
+#ifdef BALM_STAGE_TRACE
+  fprintf(stderr, "[stage] both copies returned after %.3f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw0).count());
+  hipStreamSynchronize(ctx->stream);
+  fprintf(stderr, "[stage] stream drained after %.3f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw0).count());
+#endif
   if (e == hipSuccess) e = hipMemcpyAsync(d_pos, poses, (size_t)12 * WT * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
   if (e == hipSuccess) {
     Span sp(ctx, BALM_T_VOXEL);
     AssocOpts ao{WT, opts->voxel_size, {opts->eigen_thr[0], opts->eigen_thr[1], opts->eigen_thr[2]}, opts->min_ps,
                  opts->layer_limit, opts->min_observers, opts->fix_frames, opts->max_plane_dist, opts->max_lambda21,
                  opts->max_lambda0, opts->fix_point_limit > 0 ? opts->fix_point_limit : 50, 0};
+    if (!ctx->amail.host) {
+      unsigned int *h = nullptr, *d = nullptr;
+      if (hipHostMalloc((void **)&h, 16 * sizeof(unsigned int), hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess &&
+          hipHostGetDevicePointer((void **)&d, h, 0) == hipSuccess) {
+        h[0] = h[1] = 0; ctx->amail.host = h; ctx->amail.dev = d;
+      } else { if (h) hipHostFree(h); hipGetLastError(); }
+    }
     arc = associate_device(ctx->stream, d_xyz, d_f, d_pos, n_pts, ao, ctx->d_arena, ctx->arena_cap, &need, &F, &d_out, &d_coe,
-                           &d_fix, &d_lay, opts->want_point_features ? &d_pf : nullptr, &nroots);
+                           &d_fix, &d_lay, opts->want_point_features ? &d_pf : nullptr, &nroots, &ctx->amail, &owned);
   }
+  int rc = BALM_OK;
+  if (e == hipSuccess && arc == 0 && F > 0)       // (the table may live in the arena: installed before the arena can be replaced)
+    rc = install_associated(ctx, F, d_out, d_coe, d_fix, d_lay, d_pf, n_pts, opts->fix_frames > 0, owned);
   if (need > ctx->arena_cap) {          // grow for the next call of this size
     hipStreamSynchronize(ctx->stream);
     if (ctx->d_arena) hipFree(ctx->d_arena);
@@ -874,7 +896,6 @@ static int one_associate(balm_ctx *ctx, const balm_voxel_opts *opts, const float
   if (arc) { ctx->err = arc == -2 ? "balm_associate: unsupported size" : "balm_associate: device failure"; return BALM_ERR_HIP; }
   if (n_root_voxels) *n_root_voxels = nroots;
   if (F == 0) return BALM_OK;
-  int rc = install_associated(ctx, F, d_out, d_coe, d_fix, d_lay, d_pf, n_pts, opts->fix_frames > 0);
   if (rc) return rc;
   *F_out = F;
   return BALM_OK;
@@ -1017,7 +1038,7 @@ static int one_pose_covariance(balm_ctx *ctx, const double *poses, const double 
   hipError_t e = hipSuccess;
   if (ncc) {
     d_cc = stage_take<double>(ctx, ncc);
-    if (e == hipSuccess) { Span sp(ctx, BALM_T_UPLOAD); e = staged_copy(ctx->ring, s, d_cc, cluster_cov, (size_t)F * W * 81 * sizeof(double)); }
+    if (e == hipSuccess) { Span sp(ctx, BALM_T_UPLOAD); e = staged_copy(ctx->ring, ctx->device, s, d_cc, cluster_cov, (size_t)F * W * 81 * sizeof(double)); }
   }
   double *Gx = ctx->d_Gt, *Gy = ctx->d_Gt + gcols * ctx->npad;
   if (e == hipSuccess && F == 0) e = hipMemsetAsync(buf, 0, pay * sizeof(double), s);      // a shard without features
@@ -1444,7 +1465,12 @@ int balm_set_features_cb(balm_ctx *ctx, int F, balm_fill_clusters_fn fill, void 
     parallel_ranges((size_t)F, (size_t)(32768 / row + 1), [&](size_t lo, size_t hi) { fill(user, (int)lo, (int)hi, flat.data() + lo * row); });
     return multi_set_features(ctx, m, F, flat.data(), fix, coeffs);
   }
-  return one_set_features_fn(ctx, F, [fill, user](int f0, int f1, double *dst) { fill(user, f0, f1, dst); }, fix, coeffs);
+  const size_t Wc = (size_t)ctx->W;
+  return one_set_features_fn(ctx, F, [fill, user, Wc](int f0, int f1, double *dst, unsigned char *o) {
+    fill(user, f0, f1, dst);                                             // (the caller's ordinary stores: the chunk is in this thread's cache)
+    const size_t cnt = (size_t)(f1 - f0) * Wc;
+    for (size_t t = 0; t < cnt; t++) o[t] = dst[t * 10 + 9] != 0 ? 1 : 0;
+  }, fix, coeffs);
 }
 
 int balm_build_clusters(balm_ctx *ctx, int F, const float *xyz, const int *feat_id, const int *pose_id, long n_pts,

@@ -44,7 +44,10 @@ struct Timer {
 
 }  // namespace balm
 
-namespace balm { struct WindowSession; }
+namespace balm {
+struct WindowSession;
+struct AssocMail { volatile unsigned int *host = nullptr; unsigned int *dev = nullptr; unsigned int seq = 0; };   // pinned mailbox for the counts the host reads between kernels
+}
 
 struct balm_ctx {
   int W = 0, n = 0, npad = 0, T = 0, ntiles = 0, device = 0, flags = 0;
@@ -145,6 +148,7 @@ struct balm_ctx {
   std::vector<double> assoc_fix;
   balm::WindowSession *window = nullptr;   // balm_window_*: the sliding-window map (kernels_window.inc)
   bool window_dead = false;         // a window call failed on the device half-way: the map is in an undefined state until re-opened
+  balm::AssocMail amail;            // pinned mailbox of balm_associate's host-read counts (allocated on first use)
   void *d_arena = nullptr;          // balm_associate scratch, grown to what the last call needed
   size_t arena_cap = 0;
   char *d_stage = nullptr;          // per-call staging (uploads, layout changes, covariance work matrices): grown, never
@@ -268,9 +272,10 @@ struct AssocOpts {
   int fix_limit = 50;       // to_margi: fix_point.N < fix_limit (bavoxel.hpp:793: 50; BAs_left.hpp:756: 30)
   int defer_recut = 0;      // window map: add_scan is cut_voxel only
 };
+// *outputs_owned: the output arrays were hipMalloc'ed for the caller (true) or live in the arena until the next call (false)
 int associate_device(hipStream_t s, const float *d_xyz, const int *d_frame, const double *d_poses, long n, const AssocOpts &o,
                      void *arena, size_t arena_cap, size_t *arena_need, int *F_out, double **d_out, double **d_coe,
-                     double **d_fix, int **d_layer, int **d_point_feat, long *n_roots);
+                     double **d_fix, int **d_layer, int **d_point_feat, long *n_roots, AssocMail *mail, bool *outputs_owned);
 
 // sliding-window map: the incremental use of the reference's octree (kernels_window.inc, part of kernels_voxel.hip).
 // Return codes as associate_device.

@@ -837,7 +837,7 @@ __global__ __launch_bounds__(1024) void k_ldl_finish(const double *__restrict__ 
 //   * in a process that also holds an RCCL communicator on the same stream (one rank per GPU) the cross-queue barriers multiply: EVERY
 //     kernel of the step runs late (k_rank_diag 51 instead of 9 us, assemble 0.19 instead of 0.06 ms, the SYRK +6 %): 0.7 ms per LM
 //     step, round 3's unexplained "communicator tax".  With plain launches it is gone (4.29 vs 4.26 ms/step at config 2);
-//   * issued from a thread other than the process's first it leaves ROCm 7.2 in a state that segfaults at exit (tools/exp_crash.py),
+//   * issued from a thread other than the process's first it leaves ROCm 7.2 in a state that segfaults at exit,
 //     which is why the device threads of balm_create_multi had no persistent solve in round 3.
 // Round 5: the cooperative form is gone from the library (its A/B: profiles/r04b_solve_coop.txt).  What it used to guarantee --
 // co-residency when somebody else holds CUs -- is covered in two ways: (1) the grid is sized for the device's slots DIVIDED by the
@@ -971,7 +971,7 @@ static void launch_factor(balm_ctx *c) {
   // (Also measured: A(p) folded into panel p+1's workgroups as an in-register update, one launch per panel: 1.61 instead
   // of 1.39 ms at n = 2880 -- every panel workgroup then repeats the diagonal block's update, 72 MFMAs on the critical path.)
   // What the shared launch costs: the panel's workgroups run 17 us instead of 11.6 at n = 2880 when trailing-tile waves
-  // sit on their CUs (tools/gpu_solve_trace.sh).  Keeping them apart was tried three ways: the whole CU's LDS requested
+  // sit on their CUs.  Keeping them apart was tried three ways: the whole CU's LDS requested
   // per workgroup (one workgroup per CU: 0.89 instead of 0.94 ms at n = 2100, but 1.47 instead of 1.39 at n = 2880 -- the
   // trailing tiles starve); trailing tiles as workers that leave CUs marked busy by a panel workgroup (__smid) and pull
   // tiles from a counter (one counter: 12 ns per fetch serialised, 5.9 ms; one per XCD with eight tiles per fetch: 2.6 ms).

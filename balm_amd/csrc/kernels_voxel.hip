@@ -27,6 +27,8 @@
 #include <hip/hip_runtime.h>
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
+#include <rocprim/iterator/counting_iterator.hpp>
+#include <rocprim/iterator/transform_iterator.hpp>
 
 #include "balm_internal.h"
 
@@ -293,12 +295,336 @@ __global__ __launch_bounds__(256) void k_seg_clusters(const float *__restrict__ 
   else if (lane == SEG_TERMS) seg_body[s * 10 + 9] = seg_world[s * 10 + 9] = (double)(i1 - i0);
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Round 5: the batch association without the library sorts inside root voxels, and without gathers.
+//   * the root sort moves (key, point index) only; ONE gather then lays the points down in root order as 16-byte records
+//     {x, y, z, (o1, o2, scan)} -- every later pass streams them (the three segment kernels used to gather 12 bytes per point out
+//     of 64-byte lines through the sorted indices: 350 us per level on the shipped window, 1.05 ms of the association's 3.6);
+//   * levels 1 and 2 are a STABLE PARTITION inside each root voxel by the 3 / 6 octant bits (the list is already grouped by root and in
+//     scan order inside it): per-tile histograms, per-root offsets, one scatter that writes both levels -- one read of the records
+//     instead of the library's make-key + 2 + 3 onesweep passes (9 launches of ~71 us + 2 x 44).  Stable, so the points of a (node, scan)
+//     segment stay in scan order: the sums below are the reference's, bit for bit.
+// Points that do not arrive scan by scan, or windows whose level-2 key needs more than 32 bits, take the sorted path above.
+constexpr int PART_TS = 2048;          // records per partition tile (a tile never spans two roots)
+
+// pass B of the fast path: root key + the record's tag (o1 << 12 | o2 << 9 | scan); the sort value is the point's index
+template <class K>
+__global__ __launch_bounds__(256) void k_vox_keys_tag(const float *__restrict__ xyz, const int *__restrict__ frame,
+                                                      const double *__restrict__ poses, long n, double vs, KeyPack kp,
+                                                      K *__restrict__ k0, unsigned int *__restrict__ idx, unsigned short *__restrict__ tag) {
+  const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  double q[3], po[3];
+  const int fr = frame[p];
+  world_point(xyz, poses + 12 * (long)fr, p, q, po);
+  const float q1 = (float)(vs / 4.0);
+  unsigned long long key = 0;
+  int o1 = 0, o2 = 0;
+#pragma unroll
+  for (int j = 0; j < 3; j++) {
+    const long long kj = voxel_key(q[j], vs);
+    const float c0 = (float)((0.5 + (double)kj) * vs);
+    const int b1 = q[j] > (double)c0;
+    const float c1 = __fadd_rn(c0, __fmul_rn((float)(2 * b1 - 1), q1));
+    const int b2 = q[j] > (double)c1;
+    key = (key << kp.bits[j]) | (unsigned long long)(kj - kp.off[j]);
+    o1 = (o1 << 1) | b1;
+    o2 = (o2 << 1) | b2;
+  }
+  k0[p] = (K)key;
+  idx[p] = (unsigned int)p;
+  tag[p] = (unsigned short)((o1 << 12) | (o2 << 9) | fr);
+}
+
+// the points in root order: rec[i] = {x, y, z bits, tag}; level-0 composite key (root, scan); the tags again as a dense 2-byte stream
+// for the histogram pass
+__global__ __launch_bounds__(256) void k_gather_records(const float *__restrict__ xyz, const unsigned short *__restrict__ tag,
+                                                        const unsigned int *__restrict__ idxs, const unsigned int *__restrict__ rootid_incl,
+                                                        long n, int fb, uint4 *__restrict__ rec, unsigned int *__restrict__ ck0,
+                                                        unsigned short *__restrict__ tags) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const size_t p = idxs[i];
+  const unsigned int t = tag[p];
+  rec[i] = make_uint4(__float_as_uint(xyz[3 * p]), __float_as_uint(xyz[3 * p + 1]), __float_as_uint(xyz[3 * p + 2]), t);
+  ck0[i] = ((rootid_incl[i] - 1) << fb) | (t & 511u);
+  tags[i] = (unsigned short)t;
+}
+
+// the sorted path's 64-bit sort values (point << 15 | octants << 9 | scan) in root order, from the fast path's root sort
+__global__ void k_vals_from_tags(const unsigned int *__restrict__ idxs, const unsigned short *__restrict__ tag, long n,
+                                 unsigned long long *__restrict__ vals) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const unsigned long long p = idxs[i];
+  vals[i] = (p << 15) | (unsigned long long)tag[p];
+}
+
+__global__ void k_root_starts(const unsigned int *__restrict__ keys_sorted, const unsigned int *__restrict__ rootid_incl, long n, long NR,
+                              unsigned int *__restrict__ root_start) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && (i == 0 || keys_sorted[i] != keys_sorted[i - 1])) root_start[rootid_incl[i] - 1] = (unsigned int)i;
+  if (i == 0) root_start[NR] = (unsigned int)n;
+}
+
+__global__ void k_root_tiles(const unsigned int *__restrict__ root_start, long NR, unsigned int *__restrict__ tiles) {
+  const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < NR) tiles[r] = (root_start[r + 1] - root_start[r] + PART_TS - 1) / PART_TS;
+  else if (r == NR) tiles[r] = 0;
+}
+
+// the root of tile t: the last r with tile_base[r] <= t
+__device__ __forceinline__ int part_tile_root(const unsigned int *__restrict__ tile_base, int NR, unsigned int t) {
+  int lo = 0, hi = NR - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (tile_base[mid] <= t) lo = mid; else hi = mid - 1;
+  }
+  return lo;
+}
+
+// per tile: how many of its records fall into each of the 64 (o1, o2) cells
+__global__ __launch_bounds__(256) void k_part_hist(const unsigned short *__restrict__ tags, const unsigned int *__restrict__ root_start,
+                                                   const unsigned int *__restrict__ tile_base, int NR, unsigned int *__restrict__ hist) {
+  __shared__ unsigned int h[64];
+  const unsigned int t = blockIdx.x;
+  const int r = part_tile_root(tile_base, NR, t);
+  const unsigned int a = root_start[r] + (t - tile_base[r]) * PART_TS, e = min(a + PART_TS, root_start[r + 1]);
+  if (threadIdx.x < 64) h[threadIdx.x] = 0;
+  __syncthreads();
+  for (unsigned int j = a + threadIdx.x; j < e; j += 256) atomicAdd(&h[(tags[j] >> 9) & 63u], 1u);
+  __syncthreads();
+  if (threadIdx.x < 64) hist[(size_t)t * 64 + threadIdx.x] = h[threadIdx.x];
+}
+
+// per root (one wavefront, lane = cell): where each tile's records of each cell go, for the 64-way (level 2) and the 8-way (level 1)
+// partition -- cell-major inside the root, tile order inside a cell (= the stable order)
+__global__ __launch_bounds__(64) void k_part_offsets(const unsigned int *__restrict__ hist, const unsigned int *__restrict__ root_start,
+                                                     const unsigned int *__restrict__ tile_base, int NR, unsigned int *__restrict__ off1,
+                                                     unsigned int *__restrict__ off2) {
+  const int r = blockIdx.x, lane = threadIdx.x;
+  if (r >= NR) return;
+  const unsigned int t0 = tile_base[r], t1 = tile_base[r + 1];
+  unsigned int tot2 = 0, tot1 = 0;
+  for (unsigned int t = t0; t < t1; t++) {
+    const unsigned int c = hist[(size_t)t * 64 + lane];
+    unsigned int g = c;                              // sum over the lane's group of eight cells (one level-1 child) -> lanes 8k
+    g += __shfl_down(g, 1, 64); g += __shfl_down(g, 2, 64); g += __shfl_down(g, 4, 64);
+    tot2 += c; tot1 += g;
+  }
+  // exclusive prefix over the cells (lanes), and over the children (lanes 0, 8, 16, ...)
+  unsigned int inc2 = tot2;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) { const unsigned int v = __shfl_up(inc2, d, 64); if (lane >= d) inc2 += v; }
+  unsigned int run2 = root_start[r] + inc2 - tot2;
+  unsigned int g1 = (lane & 7) == 0 ? tot1 : 0u, inc1 = g1;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) { const unsigned int v = __shfl_up(inc1, d, 64); if (lane >= d) inc1 += v; }
+  unsigned int run1 = root_start[r] + inc1 - g1;     // (meaningful on lanes 8k)
+  for (unsigned int t = t0; t < t1; t++) {
+    const unsigned int c = hist[(size_t)t * 64 + lane];
+    unsigned int g = c;
+    g += __shfl_down(g, 1, 64); g += __shfl_down(g, 2, 64); g += __shfl_down(g, 4, 64);
+    off2[(size_t)t * 64 + lane] = run2; run2 += c;
+    if ((lane & 7) == 0) { off1[(size_t)t * 8 + (lane >> 3)] = run1; run1 += g; }
+  }
+}
+
+// per tile: every record to its place in the level-1 and the level-2 list, with that level's composite key (root, octants, scan)
+// beside it.  Stable: a record's rank among the tile's records of its cell = cell counts of the earlier rounds + of the earlier
+// wavefronts of this round + the lower lanes of its wavefront with the same cell (ballots over the cell's bits).
+__global__ __launch_bounds__(256) void k_part_scatter(const uint4 *__restrict__ rec, const unsigned int *__restrict__ idx0,
+                                                      const unsigned int *__restrict__ root_start, const unsigned int *__restrict__ tile_base,
+                                                      int NR, const unsigned int *__restrict__ off1, const unsigned int *__restrict__ off2,
+                                                      int fb, int levels, uint4 *__restrict__ rec1, unsigned int *__restrict__ ck1,
+                                                      unsigned int *__restrict__ idx1, uint4 *__restrict__ rec2,
+                                                      unsigned int *__restrict__ ck2, unsigned int *__restrict__ idx2) {
+  __shared__ unsigned int run2[64], run1[8], wc2[4][64], wc1[4][8];
+  const unsigned int t = blockIdx.x;
+  const int r = part_tile_root(tile_base, NR, t);
+  const unsigned int a = root_start[r] + (t - tile_base[r]) * PART_TS, e = min(a + PART_TS, root_start[r + 1]);
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  if (tid < 64) { run2[tid] = off2[(size_t)t * 64 + tid]; wc2[0][tid] = wc2[1][tid] = wc2[2][tid] = wc2[3][tid] = 0; }
+  if (tid < 8) { run1[tid] = off1[(size_t)t * 8 + tid]; wc1[0][tid] = wc1[1][tid] = wc1[2][tid] = wc1[3][tid] = 0; }
+  __syncthreads();
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  for (unsigned int j0 = a; j0 < e; j0 += 256) {
+    const unsigned int j = j0 + tid;
+    const bool act = j < e;
+    uint4 q = make_uint4(0, 0, 0, 0);
+    if (act) q = rec[j];
+    const unsigned int cell = (q.w >> 9) & 63u, child = cell >> 3;
+    unsigned long long m = __ballot(act);
+#pragma unroll
+    for (int b = 5; b >= 3; b--) {
+      const unsigned long long bal = __ballot(act && ((cell >> b) & 1u));
+      m &= ((cell >> b) & 1u) ? bal : ~bal;
+    }
+    const unsigned long long m1 = m;
+#pragma unroll
+    for (int b = 2; b >= 0; b--) {
+      const unsigned long long bal = __ballot(act && ((cell >> b) & 1u));
+      m &= ((cell >> b) & 1u) ? bal : ~bal;
+    }
+    const unsigned int r1 = __popcll(m1 & lt), r2 = __popcll(m & lt);
+    if (act && r1 == 0) wc1[wv][child] = __popcll(m1);
+    if (act && r2 == 0) wc2[wv][cell] = __popcll(m);
+    __syncthreads();
+    unsigned int d1 = 0, d2 = 0;
+    if (act) {
+      d1 = run1[child] + r1; d2 = run2[cell] + r2;
+      for (int w = 0; w < wv; w++) { d1 += wc1[w][child]; d2 += wc2[w][cell]; }
+    }
+    __syncthreads();
+    if (tid < 64) { run2[tid] += wc2[0][tid] + wc2[1][tid] + wc2[2][tid] + wc2[3][tid]; wc2[0][tid] = wc2[1][tid] = wc2[2][tid] = wc2[3][tid] = 0; }
+    if (tid < 8) { run1[tid] += wc1[0][tid] + wc1[1][tid] + wc1[2][tid] + wc1[3][tid]; wc1[0][tid] = wc1[1][tid] = wc1[2][tid] = wc1[3][tid] = 0; }
+    if (act) {
+      const unsigned int fr = q.w & 511u;
+      rec1[d1] = q;
+      ck1[d1] = ((((unsigned int)r << 3) | child) << fb) | fr;
+      if (idx1) idx1[d1] = idx0[j];
+      if (levels > 2) {
+        rec2[d2] = q;
+        ck2[d2] = ((((unsigned int)r << 6) | cell) << fb) | fr;
+        if (idx2) idx2[d2] = idx0[j];
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// k_seg_clusters on the records themselves (no index, no gather): same sums in the same order, as two launches.
+//   k_seg_lane  one lane per segment: segments of up to SEG_LANE_MAX points are summed by their lane (a loop over its contiguous
+//               records, the next one prefetched); longer ones are appended to a work list (the very long ones to a second list that
+//               is served first).  With one WAVEFRONT per segment, as k_seg_clusters has it, level 2 of the shipped window launched
+//               792 000 wavefronts of which nine in ten found a short segment and left: 290 us of launch throughput, not of work.
+//   k_seg_wave  persistent wavefronts take the listed segments in turn: 64 points at a time are expanded into their 18 terms in LDS
+//               (the chunk padded with +0.0: x + 0.0 = x bit for bit for every x these sums can hold), and lanes 0..17 each add one term
+//               column in order -- a fixed, fully unrolled chain of 64 additions whose LDS reads run a batch ahead of the adds
+//               (the rolled loop with its tail paid a full LDS round trip per 8 additions: ~1.5 us per chunk).
+constexpr int SEG_LANE_MAX = 32;
+constexpr unsigned int SEG_VERY_LONG = 2048;
+
+__global__ __launch_bounds__(256) void k_seg_lane(const uint4 *__restrict__ rec, const double *__restrict__ poses,
+                                                  const unsigned int *__restrict__ seg_start, const unsigned long long *__restrict__ seg_ck,
+                                                  long NS, double *__restrict__ seg_body, double *__restrict__ seg_world,
+                                                  unsigned int *__restrict__ counters /* [0] long, [1] very long */,
+                                                  unsigned int *__restrict__ long_list, unsigned int *__restrict__ vlong_list) {
+  const long s = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  unsigned int i0 = 0, i1 = 0;
+  if (s < NS) { i0 = seg_start[s]; i1 = seg_start[s + 1]; }
+  const unsigned int cnt = i1 - i0;
+  // the long ones join their list: one atomic per wavefront and class
+  const bool is_long = cnt > (unsigned int)SEG_LANE_MAX, is_vlong = cnt > SEG_VERY_LONG;
+  {
+    const unsigned long long ml = __ballot(is_long && !is_vlong), mv = __ballot(is_vlong);
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    unsigned int bl = 0, bv = 0;
+    if (lane == 0) {
+      if (ml) bl = atomicAdd(&counters[0], (unsigned int)__popcll(ml));
+      if (mv) bv = atomicAdd(&counters[1], (unsigned int)__popcll(mv));
+    }
+    bl = __shfl(bl, 0, 64); bv = __shfl(bv, 0, 64);
+    if (is_long && !is_vlong) long_list[bl + __popcll(ml & lt)] = (unsigned int)s;
+    if (is_vlong) vlong_list[bv + __popcll(mv & lt)] = (unsigned int)s;
+  }
+  if (s >= NS || is_long) return;
+  const double *pose = poses + 12 * (long)(seg_ck[s] & 511ull);
+  double P[12];
+#pragma unroll
+  for (int c = 0; c < 12; c++) P[c] = pose[c];
+  double acc[SEG_TERMS];
+#pragma unroll
+  for (int c = 0; c < SEG_TERMS; c++) acc[c] = 0.0;
+  uint4 qn = make_uint4(0, 0, 0, 0);
+  if (cnt) qn = rec[i0];
+  for (unsigned int u = 0; u < cnt; u++) {
+    const float x[3] = {__uint_as_float(qn.x), __uint_as_float(qn.y), __uint_as_float(qn.z)};
+    if (u + 1 < cnt) qn = rec[i0 + u + 1];
+    const PointTerms t = point_terms(x, P);
+#pragma unroll
+    for (int c = 0; c < SEG_TERMS; c++) acc[c] = __dadd_rn(acc[c], t.t[c]);
+  }
+#pragma unroll
+  for (int c = 0; c < 9; c++) { seg_body[s * 10 + c] = acc[c]; seg_world[s * 10 + c] = acc[9 + c]; }
+  seg_body[s * 10 + 9] = seg_world[s * 10 + 9] = (double)cnt;
+}
+
+__global__ __launch_bounds__(256) void k_seg_wave(const uint4 *__restrict__ rec, const double *__restrict__ poses,
+                                                  const unsigned int *__restrict__ seg_start, const unsigned long long *__restrict__ seg_ck,
+                                                  double *__restrict__ seg_body, double *__restrict__ seg_world,
+                                                  const unsigned int *__restrict__ counters, const unsigned int *__restrict__ long_list,
+                                                  const unsigned int *__restrict__ vlong_list) {
+  __shared__ double lds[4][SEG_TERMS * SEG_LD];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const unsigned int nl = counters[0], nv = counters[1];
+  const unsigned int nwaves = gridDim.x * 4, me = blockIdx.x * 4 + wv;
+  double *mine = lds[wv];
+  const int col = min(lane, SEG_TERMS - 1);
+  const double *colp = mine + col * SEG_LD;
+  for (unsigned int w = me; w < nv + nl; w += nwaves) {
+    const unsigned int s = w < nv ? vlong_list[w] : long_list[w - nv];      // the longest first: they are the launch's tail ...
+    // ... and their wavefronts win the SIMD's issue arbitration: a chain of thousands of dependent additions that shares its SIMD with
+    // three other wavefronts advances at a quarter of its speed, and the launch ends when the longest chain does
+    if (w < nv) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0);
+    const unsigned int i0 = seg_start[s], i1 = seg_start[s + 1];
+    const double *pose = poses + 12 * (long)(seg_ck[s] & 511ull);
+    double P[12];
+#pragma unroll
+    for (int c = 0; c < 12; c++) P[c] = pose[c];
+    double acc = 0.0;
+    uint4 qn = rec[min(i0 + lane, i1 - 1)];
+    for (unsigned int i = i0; i < i1; i += 64) {
+      const bool live = i + lane < i1;
+      const float x[3] = {__uint_as_float(qn.x), __uint_as_float(qn.y), __uint_as_float(qn.z)};
+      qn = rec[min(i + 64 + lane, i1 - 1)];
+      const PointTerms t = point_terms(x, P);
+#pragma unroll
+      for (int c = 0; c < SEG_TERMS; c++) mine[c * SEG_LD + lane] = live ? t.t[c] : 0.0;
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_s_waitcnt(0xc07f);        // lgkmcnt(0): the wave's LDS writes have landed
+      double va[16], vb[16];
+#pragma unroll
+      for (int u = 0; u < 16; u++) va[u] = colp[u];
+#pragma unroll
+      for (int b = 0; b < 4; b++) {
+        if (b < 3) {
+#pragma unroll
+          for (int u = 0; u < 16; u++) vb[u] = colp[16 * (b + 1) + u];
+        }
+#pragma unroll
+        for (int u = 0; u < 16; u++) acc = __dadd_rn(acc, va[u]);
+#pragma unroll
+        for (int u = 0; u < 16; u++) va[u] = vb[u];
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    if (lane < 9) seg_body[(size_t)s * 10 + lane] = acc;
+    else if (lane < SEG_TERMS) seg_world[(size_t)s * 10 + lane - 9] = acc;
+    else if (lane == SEG_TERMS) seg_body[(size_t)s * 10 + 9] = seg_world[(size_t)s * 10 + 9] = (double)(i1 - i0);
+  }
+}
+
 inline void launch_seg_clusters(hipStream_t st, const float *xyz, const double *poses, const unsigned int *idx, const unsigned int *seg_start,
                                 const unsigned long long *seg_ck, long NS_or_bound, double *seg_body, double *seg_world,
                                 const unsigned int *ns_dev = nullptr) {
   if (NS_or_bound <= 0) return;
   const int sb = (int)((NS_or_bound + 255) / 256), lb = (int)((NS_or_bound + 3) / 4);
   hipLaunchKernelGGL(k_seg_clusters, dim3(sb + lb), dim3(256), 0, st, xyz, poses, idx, seg_start, seg_ck, NS_or_bound, sb, seg_body, seg_world, ns_dev);
+}
+
+// lists: [2] counters, then two lists of NS entries each (scratch of the caller)
+inline void launch_seg_clusters_rec(hipStream_t st, const uint4 *rec, const double *poses, const unsigned int *seg_start,
+                                    const unsigned long long *seg_ck, long NS, double *seg_body, double *seg_world, unsigned int *lists) {
+  if (NS <= 0) return;
+  unsigned int *counters = lists, *long_list = lists + 2, *vlong_list = lists + 2 + NS;
+  hipMemsetAsync(counters, 0, 2 * sizeof(unsigned int), st);
+  hipLaunchKernelGGL(k_seg_lane, dim3((unsigned int)((NS + 255) / 256)), dim3(256), 0, st, rec, poses, seg_start, seg_ck, NS, seg_body, seg_world,
+                     counters, long_list, vlong_list);
+  const long want = (NS + 3) / 4;
+  hipLaunchKernelGGL(k_seg_wave, dim3((unsigned int)(want < 1024 ? want : 1024)), dim3(256), 0, st, rec, poses, seg_start, seg_ck, seg_body, seg_world,
+                     counters, long_list, vlong_list);
 }
 
 // tree links over a level's sorted segment list: node -> first segment, node -> parent node,
@@ -583,13 +909,56 @@ struct Scratch {
   ~Scratch() { for (void *p : extra) hipFree(p); }
 };
 
-unsigned int last_u32(hipStream_t s, const unsigned int *d, long n) {
+unsigned int last_u32_sync(hipStream_t s, const unsigned int *d, long n);
+// a count the host needs before it can size the next step, through a pinned mailbox the host polls (a copy command + a stream
+// synchronise cost 15-25 us on this stack, the mailbox ~5; the association reads eleven such counts)
+__global__ void k_mail_u32(const unsigned int *__restrict__ src, volatile unsigned int *__restrict__ mail, unsigned int seq) {
+  mail[0] = *src;
+  __threadfence_system();
+  mail[1] = seq;
+  __threadfence_system();
+}
+
+unsigned int last_u32(hipStream_t s, const unsigned int *d, long n, AssocMail *mail = nullptr) {
+  if (n > 0 && mail && mail->host && mail->dev) {
+    const unsigned int seq = ++mail->seq;
+    hipLaunchKernelGGL(k_mail_u32, dim3(1), dim3(1), 0, s, d + n - 1, mail->dev, seq);
+    volatile unsigned int *h = mail->host;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int spin = 0;; spin++) {
+      if (h[1] == seq) { std::atomic_thread_fence(std::memory_order_acquire); return h[0]; }
+      if ((spin & 255) == 255 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
+    }
+    if (hipStreamSynchronize(s) == hipSuccess && h[1] == seq) return h[0];
+    return 0;
+  }
+  return last_u32_sync(s, d, n);
+}
+
+unsigned int last_u32_sync(hipStream_t s, const unsigned int *d, long n) {
   unsigned int v = 0;
   if (n > 0) { hipMemcpyAsync(&v, d + n - 1, sizeof(v), hipMemcpyDeviceToHost, s); hipStreamSynchronize(s); }
   return v;
 }
 
 void scan_incl(Scratch &sc, hipStream_t s, const unsigned int *in, unsigned int *out, long n) {
+  size_t tmp = 0;
+  rocprim::inclusive_scan(nullptr, tmp, in, out, (size_t)n, rocprim::plus<unsigned int>(), s);
+  void *d = sc.get<char>(tmp);
+  if (d) rocprim::inclusive_scan(d, tmp, in, out, (size_t)n, rocprim::plus<unsigned int>(), s);
+}
+
+// inclusive scan of the HEAD FLAGS of a sorted key list (position i starts a run: i == 0 or key[i] >> shift differs from its
+// predecessor's) without the flags ever being stored: the scan reads the keys through a transform iterator -- one launch and 4 + 4
+// bytes per element instead of a flag kernel (4 + 4) in front of the scan (4 + 4)
+template <class K>
+struct HeadFlagOf {
+  const K *key; int shift;
+  __device__ unsigned int operator()(long i) const { return (i == 0 || (key[i] >> shift) != (key[i - 1] >> shift)) ? 1u : 0u; }
+};
+template <class K>
+void scan_heads(Scratch &sc, hipStream_t s, const K *key, int shift, unsigned int *out, long n) {
+  auto in = rocprim::make_transform_iterator(rocprim::counting_iterator<long>(0), HeadFlagOf<K>{key, shift});
   size_t tmp = 0;
   rocprim::inclusive_scan(nullptr, tmp, in, out, (size_t)n, rocprim::plus<unsigned int>(), s);
   void *d = sc.get<char>(tmp);
@@ -632,8 +1001,8 @@ struct Level {
 // failure, -2 unsupported size, -3 a scan index outside [0, W) or a non-finite point).
 int associate_device(hipStream_t s, const float *d_xyz, const int *d_frame, const double *d_poses, long n, const AssocOpts &o,
                      void *arena, size_t arena_cap, size_t *arena_need, int *F_out, double **d_out, double **d_coe,
-                     double **d_fix, int **d_layer, int **d_point_feat, long *n_roots) {
-  *F_out = 0; *d_out = nullptr; *d_coe = nullptr; *d_fix = nullptr; *d_layer = nullptr; *n_roots = 0;
+                     double **d_fix, int **d_layer, int **d_point_feat, long *n_roots, AssocMail *mail, bool *outputs_owned) {
+  *F_out = 0; *outputs_owned = true; *d_out = nullptr; *d_coe = nullptr; *d_fix = nullptr; *d_layer = nullptr; *n_roots = 0;
   if (d_point_feat) *d_point_feat = nullptr;
   const int W = o.W;
   if (W > 512 || n <= 0 || n >= (1l << 31) || o.layer_limit < 0 || o.layer_limit > 2 || o.fix_frames < 0 || o.fix_frames >= W)
@@ -647,7 +1016,7 @@ int associate_device(hipStream_t s, const float *d_xyz, const int *d_frame, cons
   auto *k0 = sc.get<unsigned long long>(n), *k0s = sc.get<unsigned long long>(n);   // k0 is reused as the level key
   auto *val = sc.get<unsigned long long>(n), *vals = sc.get<unsigned long long>(n);
   auto *idx1 = sc.get<unsigned int>(n), *idxL = sc.get<unsigned int>(n);
-  auto *flag = sc.get<unsigned int>(n), *rootid = sc.get<unsigned int>(n), *incl = sc.get<unsigned int>(n);
+  auto *rootid = sc.get<unsigned int>(n), *incl = sc.get<unsigned int>(n);
   auto *cks = sc.get<unsigned long long>(n);
   auto *range = sc.get<int>(RANGE_ROW * RANGE_BLOCKS);
   unsigned int *pnode[3] = {nullptr, nullptr, nullptr};
@@ -680,71 +1049,73 @@ int associate_device(hipStream_t s, const float *d_xyz, const int *d_frame, cons
     kp.off[j] = h_range[j]; kp.bits[j] = b; key_bits += b;
   }
 
-  auto root_keys = [&](auto *ka, auto *kb) {     // 32-bit radix keys whenever the packed key fits
-    using K = std::remove_pointer_t<decltype(ka)>;
-    hipLaunchKernelGGL((k_vox_keys<K>), dim3(grid_for(n, B)), dim3(B), 0, s, d_xyz, d_frame, d_poses, n, o.voxel_size, kp, ka, val);
-    sort_pairs(sc, s, ka, kb, val, vals, n, key_bits);
-    hipLaunchKernelGGL((k_head_flags<K>), dim3(grid_for(n, B)), dim3(B), 0, s, kb, n, 0, flag);
-  };
-  if (key_bits <= 32) root_keys((unsigned int *)k0, (unsigned int *)k0s);
-  else root_keys(k0, k0s);
-  scan_incl(sc, s, flag, rootid, n);
-  if (!sc.ok) return -1;
-  const long NR = last_u32(s, rootid, n);
-  int root_bits = 1;
-  while ((1l << root_bits) < NR) root_bits++;
-
   VoxParams pr{o.voxel_size, {o.thr[0], o.thr[1], o.thr[2]}, o.min_ps, W, o.layer_limit, o.min_observers, o.fix_frames,
                o.max_dis, o.ratio21_max, o.lam0_max};
   Level lv[3];
   int fb = 1;                                     // bits of a scan index
   while ((1 << fb) < W) fb++;
-  for (int L = 0; L < levels; L++) {
-    Level &v = lv[L];
-    const int key_bits_L = root_bits + 3 * L + fb;
-    // The keys are built in root-sorted order, which is scan order inside every root voxel when the points arrived scan by
-    // scan (the root sort is stable).  Then (i) the level-0 key (root, scan) is already sorted: no sort at all; (ii) deeper
-    // levels only need the bits ABOVE the scan index sorted -- the stable passes keep the scans in order for free:
-    // 14 / 17 bits instead of 22 / 25 on the shipped window = 5 radix passes instead of 10 over the three levels.
-    auto level_keys = [&](auto *ka, auto *kb) {
-      using K = std::remove_pointer_t<decltype(ka)>;
-      if (scan_ordered && L == 0) {
-        hipLaunchKernelGGL((k_make_ck<K>), dim3(grid_for(n, B)), dim3(B), 0, s, rootid, vals, n, L, fb, kb, idxL);
-      } else {
-        hipLaunchKernelGGL((k_make_ck<K>), dim3(grid_for(n, B)), dim3(B), 0, s, rootid, vals, n, L, fb, ka, idx1);
-        sort_pairs(sc, s, ka, kb, idx1, idxL, n, key_bits_L, scan_ordered ? fb : 0);
-      }
-      hipLaunchKernelGGL((k_head_flags<K>), dim3(grid_for(n, B)), dim3(B), 0, s, kb, n, 0, flag);
-    };
-    const bool narrow = key_bits_L <= 32;
-    if (narrow) level_keys((unsigned int *)k0, (unsigned int *)cks);
-    else level_keys(k0, cks);
-    scan_incl(sc, s, flag, incl, n);
+  // Round 5's path (records in root order, levels 1-2 as stable partitions inside the roots: see k_part_scatter) whenever the points
+  // arrive scan by scan and the packed root key fits 32 bits; BALM_ASSOC=sorted forces the library-sort path (A/B, tests)
+  const char *amode = getenv("BALM_ASSOC");
+  const bool fast_keys = scan_ordered && key_bits <= 32 && !(amode && !strcmp(amode, "sorted"));
+  unsigned short *tag = nullptr, *tags = nullptr;
+  unsigned int *idx0 = (unsigned int *)val, *idx0s = (unsigned int *)vals;       // (the fast path's sort values live in the u64 arrays)
+  if (fast_keys) {
+    tag = sc.get<unsigned short>(n); tags = sc.get<unsigned short>(n);
     if (!sc.ok) return -1;
-    v.NS = last_u32(s, incl, n);
+    hipLaunchKernelGGL((k_vox_keys_tag<unsigned int>), dim3(grid_for(n, B)), dim3(B), 0, s, d_xyz, d_frame, d_poses, n, o.voxel_size, kp,
+                       (unsigned int *)k0, idx0, tag);
+    sort_pairs(sc, s, (unsigned int *)k0, (unsigned int *)k0s, idx0, idx0s, n, key_bits);
+    scan_heads(sc, s, (const unsigned int *)k0s, 0, rootid, n);
+  } else {
+    auto root_keys = [&](auto *ka, auto *kb) {     // 32-bit radix keys whenever the packed key fits
+      using K = std::remove_pointer_t<decltype(ka)>;
+      hipLaunchKernelGGL((k_vox_keys<K>), dim3(grid_for(n, B)), dim3(B), 0, s, d_xyz, d_frame, d_poses, n, o.voxel_size, kp, ka, val);
+      sort_pairs(sc, s, ka, kb, val, vals, n, key_bits);
+      scan_heads(sc, s, (const K *)kb, 0, rootid, n);
+    };
+    if (key_bits <= 32) root_keys((unsigned int *)k0, (unsigned int *)k0s);
+    else root_keys(k0, k0s);
+  }
+  if (!sc.ok) return -1;
+  const long NR = last_u32(s, rootid, n, mail);
+  int root_bits = 1;
+  while ((1l << root_bits) < NR) root_bits++;
+  const bool fast = fast_keys && root_bits + 3 * (levels - 1) + fb <= 32;
+
+  // everything of a level behind its sorted list: cks = the composite keys in list order (32- or 64-bit), idxL = the points' indices
+  // in list order (NULL when nobody needs them), recL = the records in list order (fast path) or NULL (gather through idxL)
+  auto finish_level = [&](int L, bool narrow, const void *cks_, const unsigned int *idxL_, const uint4 *recL) -> int {
+    Level &v = lv[L];
+    if (narrow) scan_heads(sc, s, (const unsigned int *)cks_, 0, incl, n);
+    else scan_heads(sc, s, (const unsigned long long *)cks_, 0, incl, n);
+    if (!sc.ok) return -1;
+    v.NS = last_u32(s, incl, n, mail);
     auto *seg_start = sc.get<unsigned int>(v.NS + 1);
     v.seg_ck = sc.get<unsigned long long>(v.NS);
     v.seg_body = sc.get<double>((size_t)v.NS * 10);
     auto *seg_world = sc.get<double>((size_t)v.NS * 10);
-    auto *sf = sc.get<unsigned int>(v.NS), *nid = sc.get<unsigned int>(v.NS), *pid = sc.get<unsigned int>(v.NS);
+    auto *nid = sc.get<unsigned int>(v.NS), *pid = sc.get<unsigned int>(v.NS);
     v.seg_node = nid;
     if (!sc.ok) return -1;
     if (narrow)
-      hipLaunchKernelGGL((k_seg_heads<unsigned int>), dim3(grid_for(n, B)), dim3(B), 0, s, (const unsigned int *)cks, incl, n, L,
+      hipLaunchKernelGGL((k_seg_heads<unsigned int>), dim3(grid_for(n, B)), dim3(B), 0, s, (const unsigned int *)cks_, incl, n, L,
                          fb, seg_start, v.seg_ck);
     else
-      hipLaunchKernelGGL((k_seg_heads<unsigned long long>), dim3(grid_for(n, B)), dim3(B), 0, s, cks, incl, n, L, fb, seg_start, v.seg_ck);
+      hipLaunchKernelGGL((k_seg_heads<unsigned long long>), dim3(grid_for(n, B)), dim3(B), 0, s, (const unsigned long long *)cks_, incl, n, L, fb,
+                         seg_start, v.seg_ck);
     hipLaunchKernelGGL(k_set_u32, dim3(1), dim3(1), 0, s, seg_start + v.NS, (unsigned int)n);
-    launch_seg_clusters(s, d_xyz, d_poses, idxL, seg_start, v.seg_ck, v.NS, v.seg_body, seg_world);
-    hipLaunchKernelGGL((k_head_flags<unsigned long long>), dim3(grid_for(v.NS, B)), dim3(B), 0, s, v.seg_ck, v.NS, 9, sf);
-    scan_incl(sc, s, sf, nid, v.NS);
-    const int pshift = L == 0 ? 0 : (L == 1 ? 15 : 12);
-    if (L > 0) {
-      hipLaunchKernelGGL((k_head_flags<unsigned long long>), dim3(grid_for(v.NS, B)), dim3(B), 0, s, v.seg_ck, v.NS, pshift, sf);
-      scan_incl(sc, s, sf, pid, v.NS);
+    if (recL) {
+      auto *lists = sc.get<unsigned int>(2 + 2 * (size_t)v.NS);
+      if (!sc.ok) return -1;
+      launch_seg_clusters_rec(s, recL, d_poses, seg_start, v.seg_ck, v.NS, v.seg_body, seg_world, lists);
     }
+    else launch_seg_clusters(s, d_xyz, d_poses, idxL_, seg_start, v.seg_ck, v.NS, v.seg_body, seg_world);
+    scan_heads(sc, s, (const unsigned long long *)v.seg_ck, 9, nid, v.NS);
+    const int pshift = L == 0 ? 0 : (L == 1 ? 15 : 12);
+    if (L > 0) scan_heads(sc, s, (const unsigned long long *)v.seg_ck, pshift, pid, v.NS);
     if (!sc.ok) return -1;
-    v.NN = last_u32(s, nid, v.NS);
+    v.NN = last_u32(s, nid, v.NS, mail);
     v.node_seg = sc.get<unsigned int>(v.NN + 1);
     v.node_parent = sc.get<unsigned int>(v.NN);
     v.tot = sc.get<NodeTot>(v.NN);
@@ -760,10 +1131,66 @@ int associate_device(hipStream_t s, const float *d_xyz, const int *d_frame, cons
                        o.fix_frames, v.tot);
     hipLaunchKernelGGL(k_node_status, dim3(grid_for(v.NN, 128)), dim3(128), 0, s, v.tot, v.NN, pr.thr[L], pr, v.status, plane);
     if (strict && o.max_dis > 0)
-      hipLaunchKernelGGL(k_point_plane_dist, dim3(grid_for(n, B)), dim3(B), 0, s, d_xyz, d_frame, d_poses, idxL, incl, nid, n, plane,
+      hipLaunchKernelGGL(k_point_plane_dist, dim3(grid_for(n, B)), dim3(B), 0, s, d_xyz, d_frame, d_poses, idxL_, incl, nid, n, plane,
                          o.max_dis, v.status);
-    if (want_points) hipLaunchKernelGGL(k_point_nodes, dim3(grid_for(n, B)), dim3(B), 0, s, idxL, incl, nid, n, pnode[L]);
+    if (want_points) hipLaunchKernelGGL(k_point_nodes, dim3(grid_for(n, B)), dim3(B), 0, s, idxL_, incl, nid, n, pnode[L]);
     hipMemsetAsync(v.flag + v.NN, 0, sizeof(unsigned int), s);
+    return 0;
+  };
+
+  if (fast) {
+    const bool need_idx = want_points || (strict && o.max_dis > 0);       // who still wants the points' original indices per level
+    auto *rec0 = sc.get<uint4>(n);
+    auto *ck0 = (unsigned int *)cks;
+    auto *root_start = sc.get<unsigned int>(NR + 1), *tiles = sc.get<unsigned int>(NR + 1), *tile_base = sc.get<unsigned int>(NR + 1);
+    if (!sc.ok) return -1;
+    hipLaunchKernelGGL(k_gather_records, dim3(grid_for(n, B)), dim3(B), 0, s, d_xyz, tag, idx0s, rootid, n, fb, rec0, ck0, tags);
+    uint4 *rec1 = nullptr, *rec2 = nullptr;
+    unsigned int *ck1 = nullptr, *ck2 = nullptr, *idx1 = nullptr, *idx2 = nullptr;
+    if (levels > 1) {
+      hipLaunchKernelGGL(k_root_starts, dim3(grid_for(n, B)), dim3(B), 0, s, (const unsigned int *)k0s, rootid, n, NR, root_start);
+      hipLaunchKernelGGL(k_root_tiles, dim3(grid_for(NR + 1, B)), dim3(B), 0, s, root_start, NR, tiles);
+      scan_excl(sc, s, tiles, tile_base, NR + 1);
+      if (!sc.ok) return -1;
+      const long NT = last_u32(s, tile_base, NR + 1, mail);
+      auto *hist = sc.get<unsigned int>((size_t)NT * 64), *off1 = sc.get<unsigned int>((size_t)NT * 8), *off2 = sc.get<unsigned int>((size_t)NT * 64);
+      rec1 = sc.get<uint4>(n); ck1 = sc.get<unsigned int>(n);
+      if (levels > 2) { rec2 = sc.get<uint4>(n); ck2 = sc.get<unsigned int>(n); }
+      if (need_idx) { idx1 = sc.get<unsigned int>(n); if (levels > 2) idx2 = sc.get<unsigned int>(n); }
+      if (!sc.ok) return -1;
+      hipLaunchKernelGGL(k_part_hist, dim3((unsigned int)NT), dim3(256), 0, s, tags, root_start, tile_base, (int)NR, hist);
+      hipLaunchKernelGGL(k_part_offsets, dim3((unsigned int)NR), dim3(64), 0, s, hist, root_start, tile_base, (int)NR, off1, off2);
+      hipLaunchKernelGGL(k_part_scatter, dim3((unsigned int)NT), dim3(256), 0, s, rec0, idx0s, root_start, tile_base, (int)NR, off1, off2, fb,
+                         levels, rec1, ck1, idx1, rec2, ck2, idx2);
+    }
+    if (finish_level(0, true, ck0, idx0s, rec0)) return -1;
+    if (levels > 1 && finish_level(1, true, ck1, idx1, rec1)) return -1;
+    if (levels > 2 && finish_level(2, true, ck2, idx2, rec2)) return -1;
+  } else {
+    if (fast_keys) {          // the root sort ran on (key, index): the sorted path's 64-bit values from the tags
+      hipLaunchKernelGGL(k_vals_from_tags, dim3(grid_for(n, B)), dim3(B), 0, s, idx0s, tag, n, k0);
+      hipMemcpyAsync(vals, k0, (size_t)n * sizeof(unsigned long long), hipMemcpyDeviceToDevice, s);
+    }
+    for (int L = 0; L < levels; L++) {
+      const int key_bits_L = root_bits + 3 * L + fb;
+      // The keys are built in root-sorted order, which is scan order inside every root voxel when the points arrived scan by
+      // scan (the root sort is stable).  Then (i) the level-0 key (root, scan) is already sorted: no sort at all; (ii) deeper
+      // levels only need the bits ABOVE the scan index sorted -- the stable passes keep the scans in order for free:
+      // 14 / 17 bits instead of 22 / 25 on the shipped window = 5 radix passes instead of 10 over the three levels.
+      auto level_keys = [&](auto *ka, auto *kb) {
+        using K = std::remove_pointer_t<decltype(ka)>;
+        if (scan_ordered && L == 0) {
+          hipLaunchKernelGGL((k_make_ck<K>), dim3(grid_for(n, B)), dim3(B), 0, s, rootid, vals, n, L, fb, kb, idxL);
+        } else {
+          hipLaunchKernelGGL((k_make_ck<K>), dim3(grid_for(n, B)), dim3(B), 0, s, rootid, vals, n, L, fb, ka, idx1);
+          sort_pairs(sc, s, ka, kb, idx1, idxL, n, key_bits_L, scan_ordered ? fb : 0);
+        }
+      };
+      const bool narrow = key_bits_L <= 32;
+      if (narrow) level_keys((unsigned int *)k0, (unsigned int *)cks);
+      else level_keys(k0, cks);
+      if (finish_level(L, narrow, cks, idxL, nullptr)) return -1;
+    }
   }
   if (lv[0].NN != NR) return -1;
   unsigned int FL[3] = {0, 0, 0};
@@ -773,7 +1200,7 @@ int associate_device(hipStream_t s, const float *d_xyz, const int *d_frame, cons
     scan_excl(sc, s, lv[L].flag, lv[L].fid, lv[L].NN + 1);
   }
   if (!sc.ok) return -1;
-  for (int L = 0; L < levels; L++) FL[L] = last_u32(s, lv[L].fid, lv[L].NN + 1);
+  for (int L = 0; L < levels; L++) FL[L] = last_u32(s, lv[L].fid, lv[L].NN + 1, mail);
   const long F = (long)FL[0] + FL[1] + FL[2];
   *n_roots = NR;
   if (hipGetLastError() != hipSuccess) return -1;
@@ -781,13 +1208,25 @@ int associate_device(hipStream_t s, const float *d_xyz, const int *d_frame, cons
   const int Wout = W - o.fix_frames;
   double *out = nullptr, *coe = nullptr, *fixo = nullptr;
   int *lay = nullptr, *pf = nullptr;
-  auto fail = [&]() { if (out) hipFree(out); if (coe) hipFree(coe); if (fixo) hipFree(fixo); if (lay) hipFree(lay); if (pf) hipFree(pf); return -1; };
-  if (hipMalloc((void **)&out, (size_t)F * Wout * 10 * sizeof(double)) != hipSuccess ||
-      hipMalloc((void **)&coe, (size_t)F * sizeof(double)) != hipSuccess ||
-      hipMalloc((void **)&fixo, (size_t)F * 10 * sizeof(double)) != hipSuccess ||
-      hipMalloc((void **)&lay, (size_t)F * sizeof(int)) != hipSuccess ||
-      (want_points && hipMalloc((void **)&pf, (size_t)n * sizeof(int)) != hipSuccess))
-    return fail();
+  // the feature table the caller installs right away: out of the arena when it fits (no hipMalloc / hipFree per call), else the
+  // caller's to free
+  const size_t out_bytes = ((size_t)F * Wout * 10 + (size_t)F + (size_t)F * 10) * sizeof(double) + (size_t)F * sizeof(int) +
+                           (want_points ? (size_t)n * sizeof(int) : 0) + 5 * 256;
+  const bool from_arena = sc.off + out_bytes <= sc.cap;
+  auto fail = [&]() { if (!from_arena) { if (out) hipFree(out); if (coe) hipFree(coe); if (fixo) hipFree(fixo); if (lay) hipFree(lay); if (pf) hipFree(pf); } return -1; };
+  if (from_arena) {
+    out = sc.get<double>((size_t)F * Wout * 10); coe = sc.get<double>((size_t)F); fixo = sc.get<double>((size_t)F * 10);
+    lay = sc.get<int>((size_t)F); if (want_points) pf = sc.get<int>((size_t)n);
+    *outputs_owned = false;
+  } else {
+    sc.need += out_bytes;
+    if (hipMalloc((void **)&out, (size_t)F * Wout * 10 * sizeof(double)) != hipSuccess ||
+        hipMalloc((void **)&coe, (size_t)F * sizeof(double)) != hipSuccess ||
+        hipMalloc((void **)&fixo, (size_t)F * 10 * sizeof(double)) != hipSuccess ||
+        hipMalloc((void **)&lay, (size_t)F * sizeof(int)) != hipSuccess ||
+        (want_points && hipMalloc((void **)&pf, (size_t)n * sizeof(int)) != hipSuccess))
+      return fail();
+  }
   hipMemsetAsync(out, 0, (size_t)F * Wout * 10 * sizeof(double), s);
   unsigned int base[3] = {0, FL[0], FL[0] + FL[1]};
   for (int L = 0; L < levels; L++) {

@@ -47,6 +47,8 @@ struct FakeDma {
   static FakeDma &get() { static FakeDma d; return d; }
 };
 
+inline hipError_t hipDeviceGetPCIBusId(char *, int, int) { return hipErrorInvalidValue; }      // (no device: nobody is pinned)
+inline hipError_t hipSetDevice(int) { return hipSuccess; }
 inline hipError_t hipHostMalloc(void **p, size_t n, unsigned) { *p = std::malloc(n); return *p ? hipSuccess : hipErrorInvalidValue; }
 inline hipError_t hipHostFree(void *p) { std::free(p); return hipSuccess; }
 inline hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { *e = new FakeEvent(); return hipSuccess; }

@@ -14,7 +14,7 @@ static int check(size_t bytes, size_t unit, int rounds) {
     std::vector<std::atomic<unsigned char>> seen((bytes + unit - 1) / unit);
     for (auto &s : seen) s.store(0);
     std::atomic<int> bad{0};
-    hipError_t e = balm::staged_upload(ring, nullptr, dst.data(), bytes, unit, [&](char *d, size_t off, size_t len) {
+    hipError_t e = balm::staged_upload(ring, 0, nullptr, dst.data(), bytes, unit, [&](char *d, size_t off, size_t len) {
       if (off % unit || (len % unit && off + len != bytes)) bad++;
       for (size_t u = off / unit; u < (off + len + unit - 1) / unit; u++)
         if (seen[u].fetch_add(1) != 0) bad++;

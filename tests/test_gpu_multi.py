@@ -152,7 +152,7 @@ def test_a_failing_device_thread_takes_its_peers_out_instead_of_hanging(fault):
 @pytest.mark.parametrize("W,n", [(200, 4), (64, 2), (260, 2)])
 def test_multi_context_keeps_the_persistent_solve_and_exits_cleanly(W, n):
     """The device threads of balm_create_multi launch k_ldl_chain plainly (a cooperative launch from a thread other than the process's
-    first segfaulted ROCm 7.2 at exit: tools/exp_crash.py): the replicas run the SAME factorisation kernel as a plain context (25 / 8
+    first segfaulted ROCm 7.2 at exit): the replicas run the SAME factorisation kernel as a plain context (25 / 8
     panels with identity rows; 33 panels with the back-substitution), reproduce its LM run, and the process exits with code 0."""
     import os
     import subprocess

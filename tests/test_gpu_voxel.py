@@ -287,3 +287,31 @@ def test_device_association_points_not_in_scan_order():
     assert np.array_equal(cl0[..., 9], cl1[..., 9])
     assert np.abs(cl0 - cl1).max() <= 1e-12 * np.abs(cl0).max()
     c.close()
+
+
+@pytest.mark.parametrize("seed,W,voxel,layer_limit,opts", [
+    (1, 8, 1.0, 2, {}), (2, 20, 2.0, 2, {}), (6, 12, 1.0, 1, {}), (7, 6, 2.0, 0, {}),
+    (8, 10, 1.0, 2, dict(fix_frames=2, min_observers=0, want_points=True)),
+    (9, 7, 1.0, 2, dict(strict=(0.05, 25.0, 1e-2), want_points=True)),
+])
+def test_partition_path_is_the_sorted_path_bit_for_bit(seed, W, voxel, layer_limit, opts, monkeypatch):
+    """Round 5's association (records laid down in root order, levels 1-2 as stable partitions inside the root voxels, segment sums
+    streaming the records) against the library-sort path it replaces (BALM_ASSOC=sorted: composite keys + rocPRIM radix sorts per
+    level + gathers): the SAME feature table in the same order, bit for bit -- clusters, weights, layers, fix clusters, and the
+    feature of every point -- with every rule option on the way (layer limits, marginalised scans, the strict plane test)."""
+    poses, frames = cluttered_window(seed, W, 50, 150, 2500)
+    ff = opts.get("fix_frames", 0)
+
+    def run():
+        c = capi.Context(W - ff)
+        out = rw.associate_gpu(c, frames, poses, voxel, layer_limit=layer_limit, **opts)
+        c.close()
+        return out
+
+    F_a, nr_a, feats_a = run()
+    monkeypatch.setenv("BALM_ASSOC", "sorted")
+    F_b, nr_b, feats_b = run()
+    assert F_a == F_b and nr_a == nr_b and F_a > (0 if opts.get("strict") else 5)
+    assert len(feats_a) == len(feats_b)
+    for x, y in zip(feats_a, feats_b):
+        assert (x is None and y is None) or np.array_equal(x, y)

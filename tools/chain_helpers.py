@@ -26,8 +26,7 @@ for W, mode in ((200, "chain"), (300, "chainb"), (400, "chainb"), (500, "chainb"
     t = np.frombuffer(buf, dtype=np.int64)
     off = P * 16 + RB * P * 4
     NH = 256 - 1 - (RB if mode == "chain" else P + 1)
-    me = os.environ.get("BALM_CHAIN_MACRO")          # launch_factor_chain: forced by the switch, else 31..41 and 69..100 panels
-    macro = mode == "chainb" and P >= 31 and ((me != "0") if me is not None else (P <= 41 or P >= 69))
+    macro = mode == "chainb" and P >= 31 and (P <= 41 or P >= 69)       # launch_factor_chain's rule: 2 x 2 macro-tiles at 31..41 and 69..100 panels
     M = sum((P - j0 + 2) // 2 for j0 in range(2, P, 2))
     NH = min(NH, (P - 2) * P if mode == "chain" else (M if macro else P * (P - 1) // 2 - 1))
     st = t[off:off + 4 * NH].reshape(NH, 4)

@@ -107,7 +107,7 @@ int main() {
     for (int rep = 0; rep < 4; rep++) {
       std::vector<char> fresh(total, (char)rep);
       const double t0 = now();
-      CK(balm::staged_copy(ring, s0, dev, fresh.data(), total));
+      CK(balm::staged_copy(ring, 0, s0, dev, fresh.data(), total));
       const double t1 = now();
       CK(hipStreamSynchronize(s0));
       printf("host_stage.h pipeline (%d threads, %d x %d MB), fresh buffer, rep %d: %6.1f GB/s  (host side done after %.2f of %.2f ms)\n",
@@ -115,7 +115,7 @@ int main() {
     }
     for (int rep = 0; rep < 2; rep++) {
       const double t0 = now();
-      CK(balm::staged_copy(ring, s0, dev, page.data(), total));
+      CK(balm::staged_copy(ring, 0, s0, dev, page.data(), total));
       CK(hipStreamSynchronize(s0));
       printf("host_stage.h pipeline, the warm buffer, rep %d: %6.1f GB/s\n", rep, total / (now() - t0) / 1e9);
     }
