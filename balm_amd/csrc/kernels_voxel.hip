@@ -110,7 +110,11 @@ __global__ __launch_bounds__(256) void k_vox_range(const float *__restrict__ xyz
   }
 }
 
-struct KeyPack { long long off[3]; int bits[3]; };
+// root key = mixed-radix number of the three per-axis voxel indices: ((kx - off_x) * n_y + (ky - off_y)) * n_z + (kz - off_z), n = cells
+// per axis.  Any injective map does (the sort only has to bring equal keys together); this one needs ceil(log2(n_x n_y n_z)) bits
+// instead of the sum of the axes' bit counts -- 24 instead of 25 on the shipped window (223 x 389 x 178 cells): three 8-bit radix
+// passes instead of four.
+struct KeyPack { long long off[3]; unsigned long long n[3]; };
 
 // pass B: packed root key + cut_func's octants (bavoxel.hpp:709-720) for both subdivision levels; the sort
 // value carries (point index, octants, frame) so that later passes never gather per-point attributes
@@ -133,7 +137,7 @@ __global__ __launch_bounds__(256) void k_vox_keys(const float *__restrict__ xyz,
     const int b1 = q[j] > (double)c0;
     const float c1 = __fadd_rn(c0, __fmul_rn((float)(2 * b1 - 1), q1));
     const int b2 = q[j] > (double)c1;
-    key = (key << kp.bits[j]) | (unsigned long long)(kj - kp.off[j]);
+    key = key * kp.n[j] + (unsigned long long)(kj - kp.off[j]);
     o1 = (o1 << 1) | b1;
     o2 = (o2 << 1) | b2;
   }
@@ -327,7 +331,7 @@ __global__ __launch_bounds__(256) void k_vox_keys_tag(const float *__restrict__ 
     const int b1 = q[j] > (double)c0;
     const float c1 = __fadd_rn(c0, __fmul_rn((float)(2 * b1 - 1), q1));
     const int b2 = q[j] > (double)c1;
-    key = (key << kp.bits[j]) | (unsigned long long)(kj - kp.off[j]);
+    key = key * kp.n[j] + (unsigned long long)(kj - kp.off[j]);
     o1 = (o1 << 1) | b1;
     o2 = (o2 << 1) | b2;
   }
@@ -509,7 +513,7 @@ __global__ __launch_bounds__(256) void k_seg_lane(const uint4 *__restrict__ rec,
                                                   const unsigned int *__restrict__ seg_start, const unsigned long long *__restrict__ seg_ck,
                                                   long NS, double *__restrict__ seg_body, double *__restrict__ seg_world,
                                                   unsigned int *__restrict__ counters /* [0] long, [1] very long */,
-                                                  unsigned int *__restrict__ long_list, unsigned int *__restrict__ vlong_list) {
+                                                  uint4 *__restrict__ long_list, uint4 *__restrict__ vlong_list /* {segment, first, end, scan} */) {
   const long s = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const int lane = threadIdx.x & 63;
   unsigned int i0 = 0, i1 = 0;
@@ -526,8 +530,10 @@ __global__ __launch_bounds__(256) void k_seg_lane(const uint4 *__restrict__ rec,
       if (mv) bv = atomicAdd(&counters[1], (unsigned int)__popcll(mv));
     }
     bl = __shfl(bl, 0, 64); bv = __shfl(bv, 0, 64);
-    if (is_long && !is_vlong) long_list[bl + __popcll(ml & lt)] = (unsigned int)s;
-    if (is_vlong) vlong_list[bv + __popcll(mv & lt)] = (unsigned int)s;
+    if (is_long) {
+      const uint4 d = make_uint4((unsigned int)s, i0, i1, (unsigned int)(seg_ck[s] & 511ull));
+      if (is_vlong) vlong_list[bv + __popcll(mv & lt)] = d; else long_list[bl + __popcll(ml & lt)] = d;
+    }
   }
   if (s >= NS || is_long) return;
   const double *pose = poses + 12 * (long)(seg_ck[s] & 511ull);
@@ -551,58 +557,101 @@ __global__ __launch_bounds__(256) void k_seg_lane(const uint4 *__restrict__ rec,
   seg_body[s * 10 + 9] = seg_world[s * 10 + 9] = (double)cnt;
 }
 
+// One listed segment per wavefront at a time, four wavefronts per workgroup.  The split is static but not blind: the first
+// min(nv, C) wavefronts take the very long segments (> 2 048 points: each is most of a wavefront's fair share already), with issue
+// priority, and NOTHING else; the long ones are dealt round among the other wavefronts.  (A blind round-robin left the wavefront that
+// drew the 8 255-point segment with its full share of the others as well: 175 chunks against a mean of 50, 234 us per level.  A
+// shared cursor balances perfectly and costs more than it saves: 100 000 atomics on one address serialise in the L2 -- 0.7-1.1 ms
+// per level, whether the answer is prefetched two segments ahead or not.)
+// Nothing in the loop waits for a dependent global load: an entry is a 16-byte descriptor, the next one is loaded while the current
+// segment runs, the next segment's first records during the current one's last chunk, and the pose comes through the scalar cache
+// (its scan index is made wave-uniform).  The add phase runs with lanes 0..17 only.
+// (Also measured, round 5: three segments per wavefront, lanes 18 k .. 18 k + 17 adding slot k's chunk -- one add phase for three chunks,
+// but one wavefront per SIMD and a very long segment that shares its wavefront with two others: 522 / 404 / 192 us per level against
+// 216 / 209 / 138.)
 __global__ __launch_bounds__(256) void k_seg_wave(const uint4 *__restrict__ rec, const double *__restrict__ poses,
-                                                  const unsigned int *__restrict__ seg_start, const unsigned long long *__restrict__ seg_ck,
                                                   double *__restrict__ seg_body, double *__restrict__ seg_world,
-                                                  const unsigned int *__restrict__ counters, const unsigned int *__restrict__ long_list,
-                                                  const unsigned int *__restrict__ vlong_list) {
+                                                  const unsigned int *__restrict__ counters /* [0] long, [1] very long */,
+                                                  const uint4 *__restrict__ long_list, const uint4 *__restrict__ vlong_list) {
   __shared__ double lds[4][SEG_TERMS * SEG_LD];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const unsigned int nl = counters[0], nv = counters[1];
-  const unsigned int nwaves = gridDim.x * 4, me = blockIdx.x * 4 + wv;
+  // consumer number: wavefront (b, w) is number b + B ((w - b) mod 4) -- the first B numbers are ONE wavefront of every workgroup, on a
+  // SIMD that rotates with b.  With the plain b * 4 + w the 914 very long segments of the shipped window's level 0 went to the four
+  // wavefronts of the first 229 workgroups: four 100-chunk chains on one SIMD, each advancing at a quarter of its speed (the PMC
+  // counters: the mean wavefront is resident 60 % of the launch, the VALU 12 % busy per wavefront -- profiles/r05q_association_pmc.csv)
+  const unsigned int NC = gridDim.x * 4, me = blockIdx.x + gridDim.x * ((wv - blockIdx.x) & 3u);
+  // this wavefront's list, first entry and stride
+  const unsigned int heavy = nv < NC ? nv : NC;              // wavefronts that carry very long segments
+  const bool mine_heavy = me < heavy;
+  const bool all_heavy = heavy == NC;                          // (more very long segments than wavefronts: everybody takes both kinds)
+  const uint4 *list = mine_heavy ? vlong_list : long_list;
+  unsigned int total = mine_heavy ? nv : nl;
+  unsigned int ent = mine_heavy ? me : me - heavy;
+  unsigned int stride = mine_heavy ? NC : NC - heavy;
+  bool second_pass = false;                                    // all_heavy: after the very long ones, the long ones dealt round everybody
+  if (!mine_heavy && ent >= total) return;
+  const uint4 none = make_uint4(0, 0, 0, 0);
+  uint4 cur = ent < total ? list[ent] : none, nxt = ent + stride < total ? list[ent + stride] : none;
+  if (mine_heavy) __builtin_amdgcn_s_setprio(3);
+  uint4 qn = rec[min(cur.y + lane, cur.z - 1)];
   double *mine = lds[wv];
-  const int col = min(lane, SEG_TERMS - 1);
-  const double *colp = mine + col * SEG_LD;
-  for (unsigned int w = me; w < nv + nl; w += nwaves) {
-    const unsigned int s = w < nv ? vlong_list[w] : long_list[w - nv];      // the longest first: they are the launch's tail ...
-    // ... and their wavefronts win the SIMD's issue arbitration: a chain of thousands of dependent additions that shares its SIMD with
-    // three other wavefronts advances at a quarter of its speed, and the launch ends when the longest chain does
-    if (w < nv) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0);
-    const unsigned int i0 = seg_start[s], i1 = seg_start[s + 1];
-    const double *pose = poses + 12 * (long)(seg_ck[s] & 511ull);
+  const double *colp = mine + min(lane, SEG_TERMS - 1) * SEG_LD;
+  for (;;) {
+    if (cur.z <= cur.y) {                                      // this list is through
+      if (!(all_heavy && !second_pass)) break;
+      second_pass = true;
+      __builtin_amdgcn_s_setprio(0);
+      list = long_list; total = nl; ent = me; stride = NC;
+      cur = ent < total ? list[ent] : none; nxt = ent + stride < total ? list[ent + stride] : none;
+      if (cur.z <= cur.y) break;
+      qn = rec[min(cur.y + lane, cur.z - 1)];
+    }
+    const double *pose = poses + 12 * (size_t)__builtin_amdgcn_readfirstlane((int)cur.w);
     double P[12];
 #pragma unroll
     for (int c = 0; c < 12; c++) P[c] = pose[c];
     double acc = 0.0;
-    uint4 qn = rec[min(i0 + lane, i1 - 1)];
-    for (unsigned int i = i0; i < i1; i += 64) {
-      const bool live = i + lane < i1;
+    for (unsigned int i = cur.y; i < cur.z; i += 64) {
+      const bool in = i + lane < cur.z;
       const float x[3] = {__uint_as_float(qn.x), __uint_as_float(qn.y), __uint_as_float(qn.z)};
-      qn = rec[min(i + 64 + lane, i1 - 1)];
+      if (i + 64 < cur.z) qn = rec[min(i + 64 + lane, cur.z - 1)];
+      else if (nxt.z > nxt.y) qn = rec[min(nxt.y + lane, nxt.z - 1)];      // the next segment's first chunk
       const PointTerms t = point_terms(x, P);
+      if (i + 64 <= cur.z) {                     // (a full chunk, the common case: no padding selects -- 36 of the loop's ~190 instructions)
 #pragma unroll
-      for (int c = 0; c < SEG_TERMS; c++) mine[c * SEG_LD + lane] = live ? t.t[c] : 0.0;
+        for (int c = 0; c < SEG_TERMS; c++) mine[c * SEG_LD + lane] = t.t[c];
+      } else {
+#pragma unroll
+        for (int c = 0; c < SEG_TERMS; c++) mine[c * SEG_LD + lane] = in ? t.t[c] : 0.0;
+      }
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_s_waitcnt(0xc07f);        // lgkmcnt(0): the wave's LDS writes have landed
-      double va[16], vb[16];
+      if (lane < SEG_TERMS) {
+        double va[16], vb[16];
 #pragma unroll
-      for (int u = 0; u < 16; u++) va[u] = colp[u];
+        for (int u = 0; u < 16; u++) va[u] = colp[u];
 #pragma unroll
-      for (int b = 0; b < 4; b++) {
-        if (b < 3) {
+        for (int b = 0; b < 4; b++) {
+          if (b < 3) {
 #pragma unroll
-          for (int u = 0; u < 16; u++) vb[u] = colp[16 * (b + 1) + u];
+            for (int u = 0; u < 16; u++) vb[u] = colp[16 * (b + 1) + u];
+          }
+#pragma unroll
+          for (int u = 0; u < 16; u++) acc = __dadd_rn(acc, va[u]);
+#pragma unroll
+          for (int u = 0; u < 16; u++) va[u] = vb[u];
         }
-#pragma unroll
-        for (int u = 0; u < 16; u++) acc = __dadd_rn(acc, va[u]);
-#pragma unroll
-        for (int u = 0; u < 16; u++) va[u] = vb[u];
       }
       __builtin_amdgcn_wave_barrier();
     }
-    if (lane < 9) seg_body[(size_t)s * 10 + lane] = acc;
-    else if (lane < SEG_TERMS) seg_world[(size_t)s * 10 + lane - 9] = acc;
-    else if (lane == SEG_TERMS) seg_body[(size_t)s * 10 + 9] = seg_world[(size_t)s * 10 + 9] = (double)(i1 - i0);
+    const size_t s = cur.x;
+    if (lane < 9) seg_body[s * 10 + lane] = acc;
+    else if (lane < SEG_TERMS) seg_world[s * 10 + lane - 9] = acc;
+    else if (lane == SEG_TERMS) seg_body[s * 10 + 9] = seg_world[s * 10 + 9] = (double)(cur.z - cur.y);
+    ent += stride;
+    cur = nxt;
+    nxt = ent + stride < total ? list[ent + stride] : none;
   }
 }
 
@@ -614,16 +663,17 @@ inline void launch_seg_clusters(hipStream_t st, const float *xyz, const double *
   hipLaunchKernelGGL(k_seg_clusters, dim3(sb + lb), dim3(256), 0, st, xyz, poses, idx, seg_start, seg_ck, NS_or_bound, sb, seg_body, seg_world, ns_dev);
 }
 
-// lists: [2] counters, then two lists of NS entries each (scratch of the caller)
+// lists: [4] counters (long, very long), then two descriptor lists of NS entries each (scratch of the caller: 16 + 32 NS bytes)
 inline void launch_seg_clusters_rec(hipStream_t st, const uint4 *rec, const double *poses, const unsigned int *seg_start,
                                     const unsigned long long *seg_ck, long NS, double *seg_body, double *seg_world, unsigned int *lists) {
   if (NS <= 0) return;
-  unsigned int *counters = lists, *long_list = lists + 2, *vlong_list = lists + 2 + NS;
-  hipMemsetAsync(counters, 0, 2 * sizeof(unsigned int), st);
+  unsigned int *counters = lists;
+  uint4 *long_list = reinterpret_cast<uint4 *>(lists + 4), *vlong_list = long_list + NS;
+  hipMemsetAsync(counters, 0, 4 * sizeof(unsigned int), st);
   hipLaunchKernelGGL(k_seg_lane, dim3((unsigned int)((NS + 255) / 256)), dim3(256), 0, st, rec, poses, seg_start, seg_ck, NS, seg_body, seg_world,
                      counters, long_list, vlong_list);
   const long want = (NS + 3) / 4;
-  hipLaunchKernelGGL(k_seg_wave, dim3((unsigned int)(want < 1024 ? want : 1024)), dim3(256), 0, st, rec, poses, seg_start, seg_ck, seg_body, seg_world,
+  hipLaunchKernelGGL(k_seg_wave, dim3((unsigned int)(want < 1024 ? want : 1024)), dim3(256), 0, st, rec, poses, seg_body, seg_world,
                      counters, long_list, vlong_list);
 }
 
@@ -1040,13 +1090,17 @@ int associate_device(hipStream_t s, const float *d_xyz, const int *d_frame, cons
     }
   }
   KeyPack kp;
-  int key_bits = 0;
-  for (int j = 0; j < 3; j++) {
-    if (h_range[j] <= -(1 << 21) || h_range[3 + j] >= (1 << 21)) return -2;   // not a LiDAR map at this voxel size
-    const unsigned long long span = (unsigned long long)((long long)h_range[3 + j] - h_range[j]);
-    int b = 1;
-    while (b < 63 && (span >> b)) b++;
-    kp.off[j] = h_range[j]; kp.bits[j] = b; key_bits += b;
+  int key_bits = 1;
+  {
+    unsigned long long cells = 1;                 // < 2^66 / 8: three spans below 2^22 each
+    for (int j = 0; j < 3; j++) {
+      if (h_range[j] <= -(1 << 21) || h_range[3 + j] >= (1 << 21)) return -2;   // not a LiDAR map at this voxel size
+      kp.off[j] = h_range[j];
+      kp.n[j] = (unsigned long long)((long long)h_range[3 + j] - h_range[j]) + 1ull;
+      if (cells > (~0ull) / kp.n[j]) return -2;
+      cells *= kp.n[j];
+    }
+    while (key_bits < 64 && ((cells - 1) >> key_bits)) key_bits++;
   }
 
   VoxParams pr{o.voxel_size, {o.thr[0], o.thr[1], o.thr[2]}, o.min_ps, W, o.layer_limit, o.min_observers, o.fix_frames,
@@ -1087,6 +1141,8 @@ int associate_device(hipStream_t s, const float *d_xyz, const int *d_frame, cons
   // in list order (NULL when nobody needs them), recL = the records in list order (fast path) or NULL (gather through idxL)
   auto finish_level = [&](int L, bool narrow, const void *cks_, const unsigned int *idxL_, const uint4 *recL) -> int {
     Level &v = lv[L];
+    // (rocprim::select on the head flags -- the run starts compacted in one pass, no ranks -- was measured too: 147 us per level on the
+    //  shipped window against ~100 for this scan + k_seg_heads)
     if (narrow) scan_heads(sc, s, (const unsigned int *)cks_, 0, incl, n);
     else scan_heads(sc, s, (const unsigned long long *)cks_, 0, incl, n);
     if (!sc.ok) return -1;
@@ -1106,7 +1162,7 @@ int associate_device(hipStream_t s, const float *d_xyz, const int *d_frame, cons
                          seg_start, v.seg_ck);
     hipLaunchKernelGGL(k_set_u32, dim3(1), dim3(1), 0, s, seg_start + v.NS, (unsigned int)n);
     if (recL) {
-      auto *lists = sc.get<unsigned int>(2 + 2 * (size_t)v.NS);
+      auto *lists = sc.get<unsigned int>(4 + 8 * (size_t)v.NS);
       if (!sc.ok) return -1;
       launch_seg_clusters_rec(s, recL, d_poses, seg_start, v.seg_ck, v.NS, v.seg_body, seg_world, lists);
     }
