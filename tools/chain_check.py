@@ -67,7 +67,7 @@ if os.environ.get("BALM_SOLVE_TRACE"):
     tr = raw[: P * 16].reshape(-1, 16)
     rw = raw[P * 16: P * 16 + (2 * P + 1) * P * 4].reshape(2 * P + 1, P, 4)
     t0 = tr[0, 0]
-    print("chain workgroup, per panel (us): start | chain wave done | riders done | wave 3: far flags seen, (p+1,p-1) seen, its rows of L[p+1,p-1] in LDS, panel p-1 applied, L[p+1,p] done | all at B1 | B1 -> B3 || panel period")
+    print("chain workgroup, per panel (us): start | chain wave done | riders done | wave 3: far flags seen, (p+1,p-1) seen, [tile loads issued, Minv_p's early tiles seen], its rows of L[p+1,p-1] in LDS, (p+1,p) carries panel p-1, L[p+1,p] done | all at B1 | B1 -> B3 || panel period")
     for p in range(tr.shape[0]):
         r = tr[p]
         nxt = tr[p + 1, 0] - r[0] if p + 1 < tr.shape[0] else float("nan")
