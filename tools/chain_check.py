@@ -67,11 +67,11 @@ if os.environ.get("BALM_SOLVE_TRACE"):
     tr = raw[: P * 16].reshape(-1, 16)
     rw = raw[P * 16: P * 16 + (2 * P + 1) * P * 4].reshape(2 * P + 1, P, 4)
     t0 = tr[0, 0]
-    print("chain workgroup, per panel (us): start | chain wave done | riders done | wave 3: far flags seen, (p+1,p-1) seen, [tile loads issued, Minv_p's early tiles seen], its rows of L[p+1,p-1] in LDS, (p+1,p) carries panel p-1, L[p+1,p] done | all at B1 | B1 -> B3 || panel period")
+    print("chain workgroup, per panel (us): start | chain wave done | riders done | wave 3: far flags seen (x2), L[p+1,p-1] seen, staged, ready | all at B1 | wave 3: product done | B2 | B3 || panel period")
     for p in range(tr.shape[0]):
         r = tr[p]
         nxt = tr[p + 1, 0] - r[0] if p + 1 < tr.shape[0] else float("nan")
-        print("p=%2d  %8.2f | %6.2f | %6.2f | %5.2f %5.2f [%5.2f %5.2f] %5.2f %5.2f %5.2f | %6.2f | %6.2f || %6.2f" % (p, r[0] - t0, r[4] - r[0], r[5] - r[0], r[8] - r[0], r[10] - r[0], r[13] - r[0], r[14] - r[0], r[11] - r[0], r[12] - r[0], r[6] - r[0], r[1] - r[0], r[3] - r[1], nxt))
+        print("p=%2d  %8.2f | %6.2f | %6.2f | %5.2f %5.2f %5.2f %5.2f %5.2f | %6.2f | %6.2f | %6.2f | %6.2f || %6.2f" % (p, r[0] - t0, r[4] - r[0], r[5] - r[0], r[8] - r[0], r[9] - r[0], r[10] - r[0], r[11] - r[0], r[6] - r[0], r[1] - r[0], r[7] - r[1], r[2] - r[1], r[3] - r[2], nxt))
 
     print("row workgroup rb = p + 2 at column p (its L[p+2, p] feeds the chain's sub-diagonal near update of panel p + 1), us relative to the chain's start of panel p:")
     print("   column begun | inputs ready (tile + near update can go) | Minv_p seen | published   [chain: B1 / B3 of panel p at]")
