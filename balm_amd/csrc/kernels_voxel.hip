@@ -188,7 +188,11 @@ __global__ void k_seg_heads(const K *__restrict__ cks, const unsigned int *__res
 //   parallel, parked in LDS, and lanes 0..17 each add one term column in order.
 constexpr int SEG_SHORT = 8;           // (24 until round 3: a lane's gathers are now issued as one batch, which has to fit its registers)
 constexpr int SEG_TERMS = 18;          // 6 + 3 body, 6 + 3 world; N is the segment length
-constexpr int SEG_LD = 65;             // padded LDS row
+// padded LDS row of a term column.  66, not 65: an adding lane reads 16 bytes per instruction (ds_read2_b64) from its own column, i.e.
+// lane j from bank 2 j LD mod 64 on -- with 65 two neighbouring lanes share two banks in every read (a 2-way conflict on the
+// instruction that bounds k_seg_wave), with 66 sixteen lanes take sixteen disjoint bank quads.  Shipped window, association on the
+// device: 2.74-2.82 ms with 65, 2.66 with 66, 2.72 with 67, 3.11 with 64 (profiles/r05u_segment_lds_row.txt).
+constexpr int SEG_LD = 66;
 
 struct PointTerms { double t[SEG_TERMS]; };
 
