@@ -57,6 +57,9 @@ __device__ __forceinline__ void world_point(const float *__restrict__ xyz, const
 }
 
 // cut_voxel's key (bavoxel.hpp:1178-1184): loc = (float)(q / voxel_size), shifted down for negatives, truncated
+// (Measured, round 5: q * (1 / voxel_size) where the voxel size is a power of two -- the same correctly rounded number without the
+// three FP64 divisions per point -- and the pose through the scalar cache: passes A and B of balm_associate did not move, 94 / 83 us;
+// they are bound by their 12-byte-stride point loads, not by instructions.  profiles/r05w_head_scan.txt)
 __device__ __forceinline__ long long voxel_key(double q, double vs) {
   float loc = (float)(q / vs);
   if (loc < 0) loc = (float)((double)loc - 1.0);
@@ -1010,8 +1013,154 @@ struct HeadFlagOf {
   const K *key; int shift;
   __device__ unsigned int operator()(long i) const { return (i == 0 || (key[i] >> shift) != (key[i - 1] >> shift)) ? 1u : 0u; }
 };
+// The same scan as ONE pass of our own for the lists that have an entry per POINT (the root keys and the three levels' composite keys of
+// balm_associate: 13.4 M entries on the shipped window, where the library's scan -- default tuning, no gfx950 entry in its tables --
+// takes 75 us = 1.4 TB/s for 4 + 4 bytes per entry).  Decoupled look-back: workgroup b scans tile b (8 192 entries), publishes its sum
+// {1, sum} as ONE 64-bit word, finds its offset by looking back over its predecessors' words (256 at a time, one per thread) up to the
+// nearest one that already holds an inclusive prefix {2, prefix}, publishes its own, adds, writes.  A thread owns FOUR consecutive entries
+// in each of the tile's eight parts: every load and store is a full 16 (32) bytes per lane, consecutive lanes adjacent.
+//   The tile is the workgroup's INDEX, not a ticket drawn from a counter (the library's way, and this kernel's first form: 3 273 atomics
+// on one address cost 21 of its 72 us).  That is safe where workgroups start in index order -- what a tile waits for then already
+// runs -- which is how the dispatcher of this hardware walks a one-dimensional grid, per XCD; it is not a guarantee, so the wait is
+// bounded: a workgroup that has not seen a predecessor's word after SH_SPIN_LIMIT looks (~tens of ms; a normal wait is microseconds)
+// COUNTS the heads in front of its tile itself (sh_count_before: correct whatever the others do, and it terminates), publishes and goes on.
+constexpr int SH_BLOCK = 256, SH_PARTS = 8, SH_TILE = 4 * SH_PARTS * SH_BLOCK;
+constexpr int SH_SPIN_LIMIT = 1 << 15;
+__device__ __forceinline__ void sh_load4(const unsigned int *p, unsigned int (&k)[4]) {
+  const uint4 v = *reinterpret_cast<const uint4 *>(p);
+  k[0] = v.x; k[1] = v.y; k[2] = v.z; k[3] = v.w;
+}
+__device__ __forceinline__ void sh_load4(const unsigned long long *p, unsigned long long (&k)[4]) {
+  const ulonglong2 a = reinterpret_cast<const ulonglong2 *>(p)[0], b = reinterpret_cast<const ulonglong2 *>(p)[1];
+  k[0] = a.x; k[1] = a.y; k[2] = b.x; k[3] = b.y;
+}
+// heads among the entries [0, end): the whole workgroup, the answer in every thread (s_red: [4])
+template <class K>
+__device__ unsigned int sh_count_before(const K *__restrict__ key, int shift, long end, unsigned int *s_red) {
+  unsigned int c = 0;
+  for (long i = threadIdx.x; i < end; i += SH_BLOCK) c += (i == 0 || (key[i] >> shift) != (key[i - 1] >> shift)) ? 1u : 0u;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d, 64);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = c;
+  __syncthreads();
+  return (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+}
+template <class K>
+__global__ __launch_bounds__(SH_BLOCK) void k_scan_heads(const K *__restrict__ key, int shift, unsigned int *__restrict__ out, long n,
+                                                         unsigned long long *__restrict__ state /* [tiles], zeroed */, int spin_limit) {
+  __shared__ unsigned int s_look[4], s_found[4], s_wsum[SH_PARTS][4];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const unsigned int tile = blockIdx.x;
+  const long t0 = (long)tile * SH_TILE;
+  const bool full = t0 + SH_TILE <= n;
+  unsigned int v[SH_PARTS][4], tsum[SH_PARTS];         // [part][entry]: inclusive within the thread's four; the thread's sum per part
+#pragma unroll
+  for (int q = 0; q < SH_PARTS; q++) {
+    const long i0 = t0 + (long)q * (4 * SH_BLOCK) + 4 * tid;
+    K k[4];
+    if (full) {
+      sh_load4(key + i0, k);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; j++) k[j] = i0 + j < n ? key[i0 + j] : (K)0;
+    }
+    // the entry in front of the thread's four: the left neighbour's last (lane 0: from memory)
+    K kp = (K)__shfl_up(k[3], 1, 64);
+    if (lane == 0) kp = (i0 > 0 && i0 - 1 < n) ? key[i0 - 1] : (K)0;
+    unsigned int run = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const K prev = j == 0 ? kp : k[j - 1];
+      const bool head = i0 + j < n && (i0 + j == 0 || (k[j] >> shift) != (prev >> shift));
+      run += head ? 1u : 0u;
+      v[q][j] = run;
+    }
+    tsum[q] = run;
+  }
+  // exclusive offsets of the thread's parts inside the tile: wave scans, wave sums through LDS
+  unsigned int wex[SH_PARTS];
+#pragma unroll
+  for (int q = 0; q < SH_PARTS; q++) {
+    unsigned int x = tsum[q];
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const unsigned int y = __shfl_up(x, d, 64); if (lane >= d) x += y; }
+    wex[q] = x - tsum[q];
+    if (lane == 63) s_wsum[q][wv] = x;
+  }
+  __syncthreads();
+  unsigned int off[SH_PARTS], total = 0;
+#pragma unroll
+  for (int q = 0; q < SH_PARTS; q++) {
+    unsigned int before = 0, all = 0;
+#pragma unroll
+    for (int w = 0; w < 4; w++) { const unsigned int sw = s_wsum[q][w]; if (w < wv) before += sw; all += sw; }
+    off[q] = total + before + wex[q];
+    total += all;
+  }
+  // the tile's offset.  All 256 threads look back, one predecessor each.
+  unsigned int prefix = 0;
+  if (tile == 0) {
+    if (tid == 0) __hip_atomic_store(state, (2ull << 32) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  } else {
+    if (tid == 0) __hip_atomic_store(state + tile, (1ull << 32) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    long pos = (long)tile - 1;
+    bool gave_up = false;
+    for (;;) {
+      const long t = pos - tid;
+      unsigned long long w = 2ull << 32;                                       // (in front of tile 0: an inclusive prefix of zero)
+      bool late = false;
+      if (t >= 0) {
+        int spins = 0;
+        do { w = __hip_atomic_load(state + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while ((w >> 32) == 0 && ++spins < spin_limit);
+        late = (w >> 32) == 0;
+      }
+      const unsigned long long incl = __ballot((w >> 32) == 2ull);
+      const int upto = incl ? __builtin_ctzll(incl) : 63;                      // this wavefront's nearest predecessor with an inclusive prefix
+      const unsigned long long lates = __ballot(late && lane <= upto);         // (a word behind that one is not needed)
+      unsigned int x = lane <= upto ? (unsigned int)w : 0u;
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) x += __shfl_xor(x, d, 64);
+      if (lane == 0) { s_look[wv] = x; s_found[wv] = (incl ? 1u : 0u) | (lates ? 2u : 0u); }
+      __syncthreads();
+      bool done = false;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        if (!done) { prefix += s_look[k]; done = (s_found[k] & 1u) != 0u; gave_up = gave_up || (s_found[k] & 2u) != 0u; }
+      }
+      __syncthreads();
+      if (done || gave_up) break;
+      pos -= SH_BLOCK;
+    }
+    if (gave_up) prefix = sh_count_before(key, shift, t0, s_look);
+    if (tid == 0) __hip_atomic_store(state + tile, (2ull << 32) | (unsigned long long)(prefix + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+#pragma unroll
+  for (int q = 0; q < SH_PARTS; q++) {
+    const long i0 = t0 + (long)q * (4 * SH_BLOCK) + 4 * tid;
+    const unsigned int b = prefix + off[q];
+    if (full) {
+      *reinterpret_cast<uint4 *>(out + i0) = make_uint4(b + v[q][0], b + v[q][1], b + v[q][2], b + v[q][3]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; j++) if (i0 + j < n) out[i0 + j] = b + v[q][j];
+    }
+  }
+}
+
 template <class K>
 void scan_heads(Scratch &sc, hipStream_t s, const K *key, int shift, unsigned int *out, long n) {
+  if (n >= SH_TILE && n < (1l << 32)) {                // (the counts fit 32 bits; key and out come from the arena: 256-byte aligned)
+    const long tiles = (n + SH_TILE - 1) / SH_TILE;
+    auto *state = sc.get<unsigned long long>((size_t)tiles);
+    if (state && (((uintptr_t)key | (uintptr_t)out) & 15) == 0) {
+      const char *e = getenv("BALM_SCAN_SPIN");        // (tests: 1 = every workgroup gives up at its first look and counts for itself)
+      const int spin_limit = e && atoi(e) > 0 ? atoi(e) : SH_SPIN_LIMIT;
+      hipMemsetAsync(state, 0, (size_t)tiles * sizeof(unsigned long long), s);
+      hipLaunchKernelGGL((k_scan_heads<K>), dim3((unsigned int)tiles), dim3(SH_BLOCK), 0, s, key, shift, out, n, state, spin_limit);
+      return;
+    }
+  }
   auto in = rocprim::make_transform_iterator(rocprim::counting_iterator<long>(0), HeadFlagOf<K>{key, shift});
   size_t tmp = 0;
   rocprim::inclusive_scan(nullptr, tmp, in, out, (size_t)n, rocprim::plus<unsigned int>(), s);

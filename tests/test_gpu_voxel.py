@@ -58,7 +58,8 @@ def check_same_features(ctx, frames, poses, voxel, thr=(1.0 / 16, 1.0 / 16, 1.0 
     return cl_g, layer_g
 
 
-@pytest.mark.parametrize("seed,W,voxel", [(1, 8, 1.0), (2, 20, 2.0), (3, 5, 4.0), (4, 33, 0.5)])
+# (voxel sizes that are powers of two take the exact-multiply form of cut_voxel's key, the others its division: voxel_key)
+@pytest.mark.parametrize("seed,W,voxel", [(1, 8, 1.0), (2, 20, 2.0), (3, 5, 4.0), (4, 33, 0.5), (5, 9, 0.7), (6, 12, 1.3)])
 def test_device_association_matches_host_on_cluttered_scans(seed, W, voxel):
     poses, frames = cluttered_window(seed, W, 60, 120, 3000)
     c = capi.Context(W)
@@ -315,3 +316,28 @@ def test_partition_path_is_the_sorted_path_bit_for_bit(seed, W, voxel, layer_lim
     assert len(feats_a) == len(feats_b)
     for x, y in zip(feats_a, feats_b):
         assert (x is None and y is None) or np.array_equal(x, y)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("assoc", ["", "sorted"])
+def test_head_scan_that_gives_up_waiting_counts_for_itself(assoc, monkeypatch):
+    """k_scan_heads (the one-pass scan of the per-point key lists) takes a workgroup's INDEX as its tile and bounds the wait for its
+    predecessors' words; a workgroup that gives up counts the heads in front of its tile itself.  BALM_SCAN_SPIN=1 makes every workgroup
+    give up at its first look: the same feature table, bit for bit (several tiles per list: 150 000+ points, and a ragged last tile)."""
+    poses, frames = cluttered_window(21, 12, 50, 150, 14000)
+    if assoc:
+        monkeypatch.setenv("BALM_ASSOC", assoc)
+
+    def run():
+        c = capi.Context(12)
+        out = rw.associate_gpu(c, frames, poses, 1.0, layer_limit=2, want_points=True)
+        c.close()
+        return out
+
+    F_a, nr_a, feats_a = run()
+    monkeypatch.setenv("BALM_SCAN_SPIN", "1")
+    F_b, nr_b, feats_b = run()
+    assert sum(len(f) for f in frames) > 8 * 8192 and F_a == F_b and nr_a == nr_b and F_a > 5
+    for x, y in zip(feats_a, feats_b):
+        assert (x is None and y is None) or np.array_equal(x, y)
+
