@@ -266,6 +266,9 @@ __global__ __launch_bounds__(256) void k_feature_eigen(const double *__restrict_
   }
   if (threadIdx.x == 0) rpart[blockIdx.x] = sred[0];
   if (!mail.host) return;                                         // (only ever set on a ONE-workgroup launch: sred[0] is the whole sum)
+  // What the stamp promises the host is the sixteen scalars, nothing else: the feature records and rpart this kernel wrote above are
+  // fenced by the sixteen mailing lanes only, so whatever reads THEM must be ordered behind this kernel on ctx->stream (every reader in
+  // the library is: the next kernels of the iteration) -- a host action taken on seeing the stamp must not read them off-stream.
   if (threadIdx.x == 0) mail.scal[mail.slot] = sred[0];
   __syncthreads();
   volatile double *host = mail.host;
