@@ -506,6 +506,7 @@ static void one_destroy(balm_ctx *ctx) {
   if (ctx->h_scal) hipHostFree(ctx->h_scal);
   ctx->ring.release();
   if (ctx->amail.host) hipHostFree((void *)ctx->amail.host);
+  if (ctx->amail.scan_state) hipFree(ctx->amail.scan_state);
   for (auto &sp : ctx->timer.pending) { hipEventDestroy(sp.a); hipEventDestroy(sp.b); }
   for (auto e : ctx->timer.pool) hipEventDestroy(e);
   if (ctx->stream) hipStreamDestroy(ctx->stream);
@@ -878,6 +879,13 @@ static int one_associate(balm_ctx *ctx, const balm_voxel_opts *opts, const float
           hipHostGetDevicePointer((void **)&d, h, 0) == hipSuccess) {
         h[0] = h[1] = 0; ctx->amail.host = h; ctx->amail.dev = d;
       } else { if (h) hipHostFree(h); hipGetLastError(); }
+    }
+    if (!ctx->amail.scan_state) {                        // (without it the scans clear a scratch buffer per call)
+      void *st = nullptr;
+      if (hipMalloc(&st, SCAN_TILES_CAP * sizeof(unsigned long long)) == hipSuccess &&
+          hipMemsetAsync(st, 0, SCAN_TILES_CAP * sizeof(unsigned long long), ctx->stream) == hipSuccess) {
+        ctx->amail.scan_state = (unsigned long long *)st; ctx->amail.scan_gen = 0;
+      } else { if (st) hipFree(st); hipGetLastError(); }
     }
     arc = associate_device(ctx->stream, d_xyz, d_f, d_pos, n_pts, ao, ctx->d_arena, ctx->arena_cap, &need, &F, &d_out, &d_coe,
                            &d_fix, &d_lay, opts->want_point_features ? &d_pf : nullptr, &nroots, &ctx->amail, &owned);

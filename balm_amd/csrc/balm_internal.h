@@ -46,7 +46,14 @@ struct Timer {
 
 namespace balm {
 struct WindowSession;
-struct AssocMail { volatile unsigned int *host = nullptr; unsigned int *dev = nullptr; unsigned int seq = 0; };   // pinned mailbox for the counts the host reads between kernels
+struct AssocMail {                                      // a context's persistent small state for balm_associate
+  volatile unsigned int *host = nullptr; unsigned int *dev = nullptr; unsigned int seq = 0;   // pinned mailbox for the counts the host reads between kernels
+  // k_scan_heads' tile words: SCAN_TILES_CAP 64-bit words that persist between scans, each tagged with the scan's generation -- a word of
+  // an older scan reads "not there yet", so no scan has to clear them first (a fill launch in front of each of the nine scans of an
+  // association is ~4 us of launch and gap)
+  unsigned long long *scan_state = nullptr; unsigned int scan_gen = 0;
+};
+constexpr long SCAN_TILES_CAP = 8192;
 }
 
 struct balm_ctx {

@@ -78,15 +78,18 @@ __global__ __launch_bounds__(256) void k_vox_range(const float *__restrict__ xyz
   __shared__ int red[4][RANGE_ROW];
   int lo[3] = {1 << 30, 1 << 30, 1 << 30}, hi[3] = {-(1 << 30), -(1 << 30), -(1 << 30)};
   int bad = 0;
-  // Two points per trip, their loads issued together, on up to 2 048 blocks (a full complement of resident wavefronts): with one point per
-  // trip on 1 024 blocks the pass had 5 MB in flight and ran at 2.3 TB/s -- latency-bound (94 us for the shipped window's 215 MB).
+  // RANGE_U points per trip, their loads issued together, on up to 2 048 blocks (a full complement of resident wavefronts): with one point
+  // per trip on 1 024 blocks the pass had 5 MB in flight and ran at 2.3 TB/s -- latency-bound (94 us for the shipped window's 215 MB).
+  constexpr int RANGE_U = 4;
   const long stride = (long)gridDim.x * blockDim.x;
-  for (long p0 = (long)blockIdx.x * blockDim.x + threadIdx.x; p0 < n; p0 += 2 * stride) {
-    const long pp[2] = {p0, p0 + stride};
-    int frv[2], frp[2];
-    float xv[2][3];
+  for (long p0 = (long)blockIdx.x * blockDim.x + threadIdx.x; p0 < n; p0 += RANGE_U * stride) {
+    long pp[RANGE_U];
+    int frv[RANGE_U], frp[RANGE_U];
+    float xv[RANGE_U][3];
 #pragma unroll
-    for (int u = 0; u < 2; u++) {
+    for (int u = 0; u < RANGE_U; u++) pp[u] = p0 + u * stride;
+#pragma unroll
+    for (int u = 0; u < RANGE_U; u++) {
       const bool in = pp[u] < n;
       const long p = in ? pp[u] : p0;
       frv[u] = frame[p];
@@ -94,7 +97,7 @@ __global__ __launch_bounds__(256) void k_vox_range(const float *__restrict__ xyz
       xv[u][0] = xyz[3 * p]; xv[u][1] = xyz[3 * p + 1]; xv[u][2] = xyz[3 * p + 2];
     }
 #pragma unroll
-    for (int u = 0; u < 2; u++) {
+    for (int u = 0; u < RANGE_U; u++) {
       if (pp[u] >= n) continue;
       const int fr = frv[u];
       if (frp[u] > fr) bad |= 2;                              // not in scan order: the level sorts must sort the scan bits too
@@ -976,6 +979,7 @@ struct Scratch {
   char *base; size_t cap, off = 0, need = 0;
   std::vector<void *> extra;
   bool ok = true;
+  AssocMail *persist = nullptr;          // the context's persistent small state (k_scan_heads' tile words), where the caller has one
   Scratch(void *b, size_t c) : base((char *)b), cap(c) {}
   template <class T> T *get(size_t n) {
     const size_t bytes = ((n ? n : 1) * sizeof(T) + 255) & ~(size_t)255;
@@ -1071,7 +1075,8 @@ __device__ unsigned int sh_count_before(const K *__restrict__ key, int shift, lo
 }
 template <class K>
 __global__ __launch_bounds__(SH_BLOCK) void k_scan_heads(const K *__restrict__ key, int shift, unsigned int *__restrict__ out, long n,
-                                                         unsigned long long *__restrict__ state /* [tiles], zeroed */, int spin_limit) {
+                                                         unsigned long long *__restrict__ state /* [tiles]: {generation : 30, kind : 2, value : 32} */,
+                                                         unsigned long long gen /* this scan's generation << 34 */, int spin_limit) {
   __shared__ unsigned int s_look[4], s_found[4], s_wsum[SH_PARTS][4];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const unsigned int tile = blockIdx.x;
@@ -1124,18 +1129,21 @@ __global__ __launch_bounds__(SH_BLOCK) void k_scan_heads(const K *__restrict__ k
   // the tile's offset.  All 256 threads look back, one predecessor each.
   unsigned int prefix = 0;
   if (tile == 0) {
-    if (tid == 0) __hip_atomic_store(state, (2ull << 32) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) __hip_atomic_store(state, gen | (2ull << 32) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   } else {
-    if (tid == 0) __hip_atomic_store(state + tile, (1ull << 32) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) __hip_atomic_store(state + tile, gen | (1ull << 32) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     long pos = (long)tile - 1;
     bool gave_up = false;
     for (;;) {
       const long t = pos - tid;
       unsigned long long w = 2ull << 32;                                       // (in front of tile 0: an inclusive prefix of zero)
       bool late = false;
-      if (t >= 0) {
+      if (t >= 0) {                                                            // a word of another generation is an older scan's: not there yet
         int spins = 0;
-        do { w = __hip_atomic_load(state + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while ((w >> 32) == 0 && ++spins < spin_limit);
+        do {
+          w = __hip_atomic_load(state + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          w = (w >> 34) == (gen >> 34) ? w & ((1ull << 34) - 1ull) : 0ull;
+        } while ((w >> 32) == 0 && ++spins < spin_limit);
         late = (w >> 32) == 0;
       }
       const unsigned long long incl = __ballot((w >> 32) == 2ull);
@@ -1156,7 +1164,7 @@ __global__ __launch_bounds__(SH_BLOCK) void k_scan_heads(const K *__restrict__ k
       pos -= SH_BLOCK;
     }
     if (gave_up) prefix = sh_count_before(key, shift, t0, s_look);
-    if (tid == 0) __hip_atomic_store(state + tile, (2ull << 32) | (unsigned long long)(prefix + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) __hip_atomic_store(state + tile, gen | (2ull << 32) | (unsigned long long)(prefix + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 #pragma unroll
   for (int q = 0; q < SH_PARTS; q++) {
@@ -1175,13 +1183,22 @@ template <class K>
 void scan_heads(Scratch &sc, hipStream_t s, const K *key, int shift, unsigned int *out, long n) {
   if (n >= SH_TILE && n < (1l << 32)) {                // (the counts fit 32 bits; key and out come from the arena: 256-byte aligned)
     const long tiles = (n + SH_TILE - 1) / SH_TILE;
-    auto *state = sc.get<unsigned long long>((size_t)tiles);
-    if (state && (((uintptr_t)key | (uintptr_t)out) & 15) == 0) {
+    if ((((uintptr_t)key | (uintptr_t)out) & 15) == 0) {
       const char *e = getenv("BALM_SCAN_SPIN");        // (tests: 1 = every workgroup gives up at its first look and counts for itself)
       const int spin_limit = e && atoi(e) > 0 ? atoi(e) : SH_SPIN_LIMIT;
-      hipMemsetAsync(state, 0, (size_t)tiles * sizeof(unsigned long long), s);
-      hipLaunchKernelGGL((k_scan_heads<K>), dim3((unsigned int)tiles), dim3(SH_BLOCK), 0, s, key, shift, out, n, state, spin_limit);
-      return;
+      unsigned long long *state = nullptr, gen = 1;
+      if (sc.persist && sc.persist->scan_state && tiles <= SCAN_TILES_CAP) {
+        // the context's persistent words, told apart by the scan's generation: nothing to clear (30 bits: cleared once per 2^30 scans)
+        state = sc.persist->scan_state;
+        if (++sc.persist->scan_gen >= (1u << 30)) { hipMemsetAsync(state, 0, SCAN_TILES_CAP * sizeof(unsigned long long), s); sc.persist->scan_gen = 1; }
+        gen = sc.persist->scan_gen;
+      } else if ((state = sc.get<unsigned long long>((size_t)tiles)) != nullptr) {
+        hipMemsetAsync(state, 0, (size_t)tiles * sizeof(unsigned long long), s);
+      }
+      if (state) {
+        hipLaunchKernelGGL((k_scan_heads<K>), dim3((unsigned int)tiles), dim3(SH_BLOCK), 0, s, key, shift, out, n, state, gen << 34, spin_limit);
+        return;
+      }
     }
   }
   auto in = rocprim::make_transform_iterator(rocprim::counting_iterator<long>(0), HeadFlagOf<K>{key, shift});
@@ -1237,6 +1254,7 @@ int associate_device(hipStream_t s, const float *d_xyz, const int *d_frame, cons
   const bool want_points = d_point_feat != nullptr;
   const int levels = o.layer_limit + 1;
   Scratch sc(arena, arena_cap);
+  sc.persist = mail;
   struct NeedOut { Scratch &sc; size_t *out; ~NeedOut() { *out = sc.need; } } need_out{sc, arena_need};
   const int B = 256;
   auto *k0 = sc.get<unsigned long long>(n), *k0s = sc.get<unsigned long long>(n);   // k0 is reused as the level key
