@@ -122,3 +122,22 @@ def test_macro_tile_ownership_plan_is_a_balanced_partition(P, NH):
     assert max(loads) <= sum(loads) / NH + heaviest          # longest-processing-time-first's bound
     if P == 63:
         assert max(loads) <= 1.12 * sum(loads) / NH
+
+
+def test_every_environment_switch_is_documented_and_exercised():
+    """a switch of the library that no test executes selects unrun code.  Every getenv("BALM_...") in
+    balm_amd/csrc has a row in INTEGRATION.md's table and a hit in tests/ -- and there are no more of them than the review allowed (18)."""
+    import glob
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    names = set()
+    for f in glob.glob(os.path.join(root, "balm_amd", "csrc", "*")):
+        if os.path.isfile(f):
+            names |= set(re.findall(r'getenv\("(BALM_[A-Z0-9_]+)"\)', open(f, errors="ignore").read()))
+    assert 10 <= len(names) <= 18, sorted(names)
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    tests = "".join(open(f).read() for f in glob.glob(os.path.join(root, "tests", "*.py")) if not f.endswith("test_capi_cpu.py"))
+    for n in sorted(names):
+        assert n in doc, "%s is not in INTEGRATION.md's switch table" % n
+        assert n in tests, "%s is not exercised by any test" % n
+
