@@ -540,43 +540,71 @@ __global__ __launch_bounds__(256) void k_sym_scale(double *__restrict__ T, int n
   }
 }
 
-// C (nA x nA, ld nA) = A B with A(i,k) = a[i sai + k sak], B(k,j) = b[k sbk + j sbj]; one of the operands is the
-// triangular M or its transpose: tri = 1: A non-zero for k <= i, 2: B non-zero for k <= j, 3: A non-zero for
-// k >= i, 4: B non-zero for k >= j.  Workgroup = 3 waves = a 48 x 48 tile of C, wave w = rows 16 w .. 16 w + 15.
+// C (nA x nA, ld nA) = A B with A(i,k) = a[i sai + k sak], B(k,j) = b[k sbk + j sbj] (one stride of each operand is 1); one of the operands
+// is the triangular M or its transpose: tri = 1: A non-zero for k <= i, 2: B non-zero for k <= j, 3: A non-zero for k >= i, 4: B non-zero
+// for k >= j.  Workgroup = 3 waves = a 48 x 48 tile of C, wave w = rows 16 w .. 16 w + 15.
 // MFMA f64 16x16x4: A operand lane l = A(row l & 15, k + (l >> 4)), B operand lane l = B(k + (l >> 4), col l & 15),
 // C/D: col = l & 15, row = (l >> 4) + 4 reg.
+// Round 5: both operand blocks of a 48-wide k block go through LDS.  Until then every wavefront loaded its operands straight from memory in
+// MFMA layout -- sixteen separate 32-byte pieces per load instruction (strides ldA / nA) and the same B block three times per tile: 576 MB of
+// requests per product, 160 us for 25 us of MFMA work, and issuing the next block's loads ahead of the MFMAs changed nothing
+// (profiles/r05t_tri_gemm_prefetch.txt: request-bound, not latency-bound).  Now the 192 threads fetch the two 48 x 48 blocks once, along the
+// operand's unit stride (48 consecutive doubles per row: whole 128-byte lines), the next block's 24 values per thread in flight under this
+// block's 36 MFMAs per wavefront, and the MFMA operands are LDS reads: As[k][i], Bs[k][j], rows of 49 doubles (an odd row keeps the
+// transposing stores of a k-contiguous operand at two lanes per bank; the reads -- sixteen consecutive doubles per k -- are conflict-free
+// but for one bank pair).
+constexpr int TG_LD = NB + 1;
 __global__ __launch_bounds__(192) void k_tri_gemm(const double *__restrict__ a, long sai, long sak, const double *__restrict__ b,
                                                   long sbk, long sbj, int nA, int tri, double *__restrict__ C) {
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int i0 = blockIdx.x * NB + 16 * wv, j0 = blockIdx.y * NB;
+  __shared__ double As[NB * TG_LD], Bs[NB * TG_LD];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int l15 = lane & 15, l4 = lane >> 4;
+  const int i0 = blockIdx.x * NB, j0 = blockIdx.y * NB;
   int k0 = 0, k1 = nA;
-  if (tri == 1) k1 = min(nA, blockIdx.x * NB + NB);
+  if (tri == 1) k1 = min(nA, i0 + NB);
   else if (tri == 2) k1 = min(nA, j0 + NB);
-  else if (tri == 3) k0 = blockIdx.x * NB;
+  else if (tri == 3) k0 = i0;
   else if (tri == 4) k0 = j0;
-  const double *pa = a + (size_t)(i0 + (lane & 15)) * sai + (size_t)(lane >> 4) * sak;
-  const double *pb = b + (size_t)(lane >> 4) * sbk + (size_t)(j0 + (lane & 15)) * sbj;
+  // this thread's twelve elements of a 48 x 48 block: one index along the unit stride (f), the other g0, g0 + 4, ..
+  const int f = tid % NB, g0 = tid / NB;
+  const bool a_i_fast = sai == 1, b_k_fast = sbk == 1;
+  // A block: (i, k) = (f, g) or (g, f); B block: (k, j) = (f, g) or (g, f)
+  const double *pa = a_i_fast ? a + (size_t)(i0 + f) + (size_t)g0 * sak : a + (size_t)(i0 + g0) * sai + (size_t)f;
+  const long sa_m = a_i_fast ? 4 * sak : 4 * sai, sa_k = a_i_fast ? sak : 1;          // per m (g += 4), per unit of k
+  const double *pb = b_k_fast ? b + (size_t)f + (size_t)(j0 + g0) * sbj : b + (size_t)g0 * sbk + (size_t)(j0 + f);
+  const long sb_m = b_k_fast ? 4 * sbj : 4 * sbk, sb_k = b_k_fast ? 1 : sbk;
+  const int la = a_i_fast ? g0 * TG_LD + f : f * TG_LD + g0, la_m = a_i_fast ? 4 * TG_LD : 4;      // As[k][i]
+  const int lb = b_k_fast ? f * TG_LD + g0 : g0 * TG_LD + f, lb_m = b_k_fast ? 4 : 4 * TG_LD;      // Bs[k][j]
   d4 acc[3];
 #pragma unroll
   for (int y = 0; y < 3; y++) acc[y] = (d4){0.0, 0.0, 0.0, 0.0};
-  for (int k = k0; k < k1; k += 16) {           // k ranges are multiples of 48: four k-steps per trip, loads first
-    double av[4], bv[4][3];
+  double ra[12], rb[12];
+  if (k0 < k1) {
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
-      av[u] = pa[(size_t)(k + 4 * u) * sak];
+    for (int m = 0; m < 12; m++) { ra[m] = pa[(size_t)k0 * sa_k + m * sa_m]; rb[m] = pb[(size_t)k0 * sb_k + m * sb_m]; }
+  }
+  for (int kb = k0; kb < k1; kb += NB) {
+    __syncthreads();                               // the last block's operand reads are done
 #pragma unroll
-      for (int y = 0; y < 3; y++) bv[u][y] = pb[(size_t)(k + 4 * u) * sbk + (size_t)(16 * y) * sbj];
+    for (int m = 0; m < 12; m++) { As[la + m * la_m] = ra[m]; Bs[lb + m * lb_m] = rb[m]; }
+    __syncthreads();
+    if (kb + NB < k1) {                            // the next block: in flight under this one's MFMAs
+#pragma unroll
+      for (int m = 0; m < 12; m++) { ra[m] = pa[(size_t)(kb + NB) * sa_k + m * sa_m]; rb[m] = pb[(size_t)(kb + NB) * sb_k + m * sb_m]; }
     }
 #pragma unroll
-    for (int u = 0; u < 4; u++)
+    for (int u = 0; u < 12; u++) {
+      const double av = As[(4 * u + l4) * TG_LD + 16 * wv + l15];
 #pragma unroll
-      for (int y = 0; y < 3; y++) acc[y] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u][y], acc[y], 0, 0, 0);
+      for (int y = 0; y < 3; y++)
+        acc[y] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Bs[(4 * u + l4) * TG_LD + 16 * y + l15], acc[y], 0, 0, 0);
+    }
   }
 #pragma unroll
   for (int y = 0; y < 3; y++)
 #pragma unroll
     for (int e = 0; e < 4; e++)
-      C[(size_t)(j0 + 16 * y + (lane & 15)) * nA + i0 + (lane >> 4) + 4 * e] = acc[y][e];
+      C[(size_t)(j0 + 16 * y + l15) * nA + i0 + 16 * wv + l4 + 4 * e] = acc[y][e];
 }
 
 inline int grid1(long total, int bs, int cap) {
