@@ -141,3 +141,12 @@ def test_every_environment_switch_is_documented_and_exercised():
         assert n in doc, "%s is not in INTEGRATION.md's switch table" % n
         assert n in tests, "%s is not exercised by any test" % n
 
+
+def test_tri_gemm_index_arithmetic_on_the_numpy_replay():
+    """k_tri_gemm (the covariance congruence's triangular products through LDS) was written from a numpy replay of its data movement --
+    thread -> block element -> LDS -> MFMA operand -> accumulator -> C; the replay must reproduce the plain product for the four stride
+    patterns and triangular modes it is launched with (the GPU tests then compare the kernel itself with the reference's covariance)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import emulate_tri_gemm
+    assert max(emulate_tri_gemm.all_patterns(96)) < 1e-12
+
