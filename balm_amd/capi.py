@@ -13,16 +13,16 @@ LIB_PATH = os.environ.get("BALM_HIP_LIB") or os.path.join(_HERE, "lib", "libbalm
 
 FORM_LEFT, FORM_RIGHT = 0, 1
 OK, ERR_ARG, ERR_HIP, ERR_STATE, ERR_TOO_FEW_PLANES, ERR_NUMERIC = range(6)
-ABI_VERSION = 5            # include/balm_hip.h: BALM_ABI_VERSION
+ABI_VERSION = 6            # include/balm_hip.h: BALM_ABI_VERSION
 FLAG_TIMING = 1
 FLAG_LOOPBACK_SHARDS = 2
 T_MOMENTS, T_FACTORS, T_SYRK, T_ASSEMBLE, T_SOLVE, T_UPDATE, T_BUILD, T_VOXEL, T_COV, T_COMM, T_UPLOAD, T_COUNT = range(12)
 TIMING_NAMES = ["moments", "factors", "syrk", "assemble", "solve", "update", "build", "voxel", "cov", "comm", "upload"]
 
 # every symbol include/balm_hip.h declares
-EXPORTS = ["balm_create", "balm_create_multi", "balm_destroy", "balm_set_features", "balm_set_features_cb", "balm_evaluate", "balm_only_residual",
-           "balm_solve_damped", "balm_damping_iter", "balm_build_clusters", "balm_voxel_defaults", "balm_associate", "balm_get_features", "balm_get_association", "balm_pose_covariance",
-           "balm_window_open", "balm_window_add_scan", "balm_window_recut", "balm_window_get_points", "balm_window_features", "balm_window_marginalize", "balm_window_info", "balm_window_close",
+EXPORTS = ["balm_create", "balm_prewarm", "balm_create_multi", "balm_destroy", "balm_set_features", "balm_set_features_cb", "balm_evaluate", "balm_only_residual",
+           "balm_solve_damped", "balm_damping_iter", "balm_build_clusters", "balm_build_clusters_planes", "balm_voxel_defaults", "balm_associate", "balm_associate_scans", "balm_get_features", "balm_get_association", "balm_pose_covariance",
+           "balm_window_open", "balm_window_add_scan", "balm_window_add_scan_strided", "balm_window_recut", "balm_window_get_points", "balm_window_features", "balm_window_marginalize", "balm_window_info", "balm_window_close",
            "balm_set_allreduce", "balm_comm_unique_id", "balm_comm_init_rank", "balm_comm_info",
            "balm_get_timing", "balm_get_solve_trace", "balm_chain_macro_plan", "balm_reset_timing", "balm_work_model", "balm_last_error", "balm_version", "balm_abi_version"]
 
@@ -73,6 +73,7 @@ def lib():
         L.balm_create.argtypes = [C.c_int, C.c_int, C.c_int]
         L.balm_create_multi.restype = C.c_void_p
         L.balm_create_multi.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int]
+        L.balm_prewarm.argtypes = [C.c_int]
         L.balm_destroy.restype = None
         L.balm_destroy.argtypes = [C.c_void_p]
         L.balm_set_features.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -86,6 +87,11 @@ def lib():
                                         C.POINTER(C.c_int)]
         L.balm_build_clusters.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long,
                                           C.c_void_p, C.c_void_p, C.c_void_p]
+        L.balm_build_clusters_planes.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p,
+                                                 C.c_void_p, C.c_void_p]
+        L.balm_associate_scans.argtypes = [C.c_void_p, C.POINTER(VoxelOpts), C.c_int, C.c_void_p, C.c_void_p, C.c_size_t,
+                                           C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_long)]
+        L.balm_window_add_scan_strided.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_size_t, C.c_void_p]
         L.balm_window_open.argtypes = [C.c_void_p, C.POINTER(VoxelOpts)]
         L.balm_window_add_scan.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_void_p]
         L.balm_window_recut.argtypes = [C.c_void_p]
@@ -187,13 +193,25 @@ class Context:
         fix, coeffs = _c(fix), _c(coeffs)
         row = self.W * 10
 
+        failed = []
+
         def fill(_user, f0, f1, dst):
+            # ctypes prints and swallows an exception raised in a callback: the chunk would leave with stale bytes and the
+            # call would still answer BALM_OK.  Zero the range (an all-zero cluster = "not observed"), remember, re-raise after.
             out = np.ctypeslib.as_array(dst, shape=((f1 - f0) * row,))
-            for a in range(f0, f1):
-                out[(a - f0) * row:(a - f0 + 1) * row] = tabs[a].reshape(-1)
+            try:
+                for a in range(f0, f1):
+                    out[(a - f0) * row:(a - f0 + 1) * row] = tabs[a].reshape(-1)
+            except BaseException as exc:       # noqa: BLE001
+                out[:] = 0.0
+                failed.append(exc)
 
         cb = FILL_CLUSTERS_FN(fill)
-        self._check(self.L.balm_set_features_cb(self.h, F, cb, None, _p(fix), _p(coeffs)))
+        rc = self.L.balm_set_features_cb(self.h, F, cb, None, _p(fix), _p(coeffs))
+        if failed:
+            self.F = 0
+            raise failed[0]
+        self._check(rc)
         self.F = F
 
     def build_clusters(self, F, xyz, feat_id, pose_id, fix, coeffs, want_clusters=True):
@@ -206,6 +224,67 @@ class Context:
         self.F = F
         return out
 
+    @staticmethod
+    def _containers(arrays):
+        """list of C-contiguous float32 [n_k, c] arrays (c >= 3: x, y, z lead each row, like the 12 floats of a
+        pcl::PointXYZINormal) -> (pointer array, count array, stride in bytes, the arrays kept alive)"""
+        keep = [np.ascontiguousarray(a, dtype=np.float32) for a in arrays]
+        keep = [a.reshape(-1, 3) if a.ndim == 1 else a for a in keep]
+        cols = {a.shape[1] for a in keep}
+        assert len(cols) == 1 and min(cols) >= 3, "every container: [n, c] float32 with the same c >= 3"
+        ptrs = (C.c_void_p * len(keep))(*[a.ctypes.data if a.shape[0] else None for a in keep])
+        cnt = (C.c_long * len(keep))(*[a.shape[0] for a in keep])
+        return ptrs, cnt, 4 * cols.pop(), keep
+
+    def build_clusters_planes(self, planes, pose_col, fix, coeffs, want_clusters=True):
+        """balm_build_clusters_planes: `planes` = F separate [n_a, c] float32 arrays (one per plane, as benchmark_virtual.cpp
+        holds its clouds), column `pose_col` of each row = the observing pose stored as a float (`intensity`)"""
+        ptrs, cnt, stride, keep = self._containers(planes)
+        F = len(keep)
+        fix, coeffs = _c(fix), _c(coeffs)
+        out = np.zeros((F, self.W, 10)) if want_clusters else None
+        self._check(self.L.balm_build_clusters_planes(self.h, F, ptrs, cnt, stride, 4 * int(pose_col), _p(fix), _p(coeffs), _p(out)))
+        self.F = F
+        return out
+
+    def associate_scans(self, scans, poses, voxel_size=2.0, eigen_thresholds=(1.0 / 16, 1.0 / 16, 1.0 / 9), min_ps=15,
+                        want_features=True, layer_limit=2, min_observers=2, fix_frames=0, strict=None, want_points=False):
+        """balm_associate_scans: `scans` = one [n_i, c] float32 array per scan (c = 3: packed xyz; c = 12: 48-byte elements
+        like pcl::PointXYZINormal), read by the library where they lie.  Returns what associate() returns."""
+        ptrs, cnt, stride, keep = self._containers(scans)
+        poses = _c(poses)
+        assert poses.shape[0] == self.W + fix_frames == len(keep), "one scan and one pose per window slot"
+        o = self._voxel_opts(voxel_size, eigen_thresholds, min_ps, layer_limit, min_observers, fix_frames, strict, want_points)
+        F, nr = C.c_int(0), C.c_long(0)
+        self._check(self.L.balm_associate_scans(self.h, C.byref(o), len(keep), ptrs, cnt, stride, _p(poses), C.byref(F), C.byref(nr)))
+        self.F = F.value
+        return self.F, nr.value, self._association_result(want_features, fix_frames, want_points, sum(a.shape[0] for a in keep))
+
+    def _voxel_opts(self, voxel_size, eigen_thresholds, min_ps, layer_limit, min_observers, fix_frames, strict, want_points):
+        o = VoxelOpts()
+        self.L.balm_voxel_defaults(C.byref(o))
+        o.voxel_size = voxel_size
+        o.eigen_thr = (C.c_float * 3)(*[float(t) for t in eigen_thresholds])
+        o.min_ps, o.layer_limit, o.min_observers, o.fix_frames = min_ps, layer_limit, min_observers, fix_frames
+        if strict is not None:
+            o.max_plane_dist, o.max_lambda21, o.max_lambda0 = strict
+        o.want_point_features = int(want_points)
+        return o
+
+    def _association_result(self, want_features, fix_frames, want_points, n_pts):
+        feats = None
+        if want_features and self.F > 0:
+            cl, co = np.zeros((self.F, self.W, 10)), np.zeros(self.F)
+            layer = np.zeros(self.F, dtype=np.int32)
+            self._check(self.L.balm_get_features(self.h, _p(cl), _p(co), _p(layer)))
+            feats = (cl, co, layer)
+            if fix_frames or want_points:
+                fix = np.zeros((self.F, 10))
+                pf = np.zeros(n_pts, dtype=np.int32) if want_points else None
+                self._check(self.L.balm_get_association(self.h, _p(fix), _p(pf)))
+                feats = (cl, co, layer, fix, pf)
+        return feats
+
     def associate(self, xyz, frame_id, poses, voxel_size=2.0, eigen_thresholds=(1.0 / 16, 1.0 / 16, 1.0 / 9),
                   min_ps=15, want_features=True, layer_limit=2, min_observers=2, fix_frames=0, strict=None,
                   want_points=False):
@@ -215,30 +294,12 @@ class Context:
         xyz = _c(xyz, np.float32).reshape(-1, 3)
         frame_id, poses = _c(frame_id, np.int32), _c(poses)
         assert poses.shape[0] == self.W + fix_frames, "poses for the marginalised scans too"
-        o = VoxelOpts()
-        self.L.balm_voxel_defaults(C.byref(o))
-        o.voxel_size = voxel_size
-        o.eigen_thr = (C.c_float * 3)(*[float(t) for t in eigen_thresholds])
-        o.min_ps, o.layer_limit, o.min_observers, o.fix_frames = min_ps, layer_limit, min_observers, fix_frames
-        if strict is not None:
-            o.max_plane_dist, o.max_lambda21, o.max_lambda0 = strict
-        o.want_point_features = int(want_points)
+        o = self._voxel_opts(voxel_size, eigen_thresholds, min_ps, layer_limit, min_observers, fix_frames, strict, want_points)
         F, nr = C.c_int(0), C.c_long(0)
         self._check(self.L.balm_associate(self.h, C.byref(o), _p(xyz), _p(frame_id), xyz.shape[0], _p(poses),
                                           C.byref(F), C.byref(nr)))
         self.F = F.value
-        feats = None
-        if want_features and self.F > 0:
-            cl, co = np.zeros((self.F, self.W, 10)), np.zeros(self.F)
-            layer = np.zeros(self.F, dtype=np.int32)
-            self._check(self.L.balm_get_features(self.h, _p(cl), _p(co), _p(layer)))
-            feats = (cl, co, layer)
-            if fix_frames or want_points:
-                fix = np.zeros((self.F, 10))
-                pf = np.zeros(xyz.shape[0], dtype=np.int32) if want_points else None
-                self._check(self.L.balm_get_association(self.h, _p(fix), _p(pf)))
-                feats = (cl, co, layer, fix, pf)
-        return self.F, nr.value, feats
+        return self.F, nr.value, self._association_result(want_features, fix_frames, want_points, xyz.shape[0])
 
     # ---- sliding-window map (the incremental use of the reference's octree) ----
     def window_open(self, voxel_size=2.0, eigen_thresholds=(1.0 / 16, 1.0 / 16, 1.0 / 9), min_ps=15, layer_limit=2,
@@ -270,6 +331,12 @@ class Context:
         """cut_voxel + recut: body-frame points of one scan, its pose [12]"""
         xyz, pose12 = _c(xyz, np.float32).reshape(-1, 3), _c(pose12).reshape(12)
         self._check(self.L.balm_window_add_scan(self.h, _p(xyz), xyz.shape[0], _p(pose12)))
+
+    def window_add_scan_strided(self, points, pose12):
+        """the same for a [n, c] float32 container whose rows start with x, y, z (c = 12: pcl::PointXYZINormal elements)"""
+        ptrs, cnt, stride, keep = self._containers([points])
+        pose12 = _c(pose12).reshape(12)
+        self._check(self.L.balm_window_add_scan_strided(self.h, keep[0].ctypes.data, keep[0].shape[0], stride, _p(pose12)))
 
     def window_marginalize(self, mg_size, poses=None):
         """OCTO_TREE_ROOT::marginalize of every root; poses [scans_in_window, 12] (re-transform) or None"""

@@ -180,6 +180,9 @@ namespace balm {
 // launchers (kernels_accum.hip)
 hipError_t prepare_device_accum();     // per-device kernel attributes (dynamic LDS limits); once per context
 hipError_t prepare_device_cov();
+hipError_t preload_solve();            // load a translation unit's code object on the current device (balm_prewarm)
+hipError_t preload_build();
+hipError_t preload_voxel();
 void launch_transpose_clusters(hipStream_t s, const double *aos, double *soa, int F, int W);
 void launch_world_moments(hipStream_t s, const double *cl, const double *poses, int W, int f0, int f1, double *C);
 struct EigenMail { double *scal; double *host; double stamp; int slot; };      // a ONE-workgroup k_feature_eigen sends the LM iteration's scalars itself (host == NULL: no)
@@ -314,6 +317,8 @@ void launch_build_clusters(hipStream_t s, const float *xyz, const int *feat_id, 
 void launch_build_clusters_any(hipStream_t s, const float *xyz, const int *feat_id, const int *pose_id, long n_pts,
                                int F, int W, double *soa);                       // any order: atomics
 void launch_soa_to_aos(hipStream_t s, const double *soa, double *aos, int F, int W);
+void launch_expand_ids(hipStream_t s, const long *d_first, int m, long n, int *d_id);            // container index of every point from the containers' prefix counts
+void launch_unpack_xyzw(hipStream_t s, const float *d_rec, long n, float *d_xyz, int *d_aux);    // (x, y, z, w) records -> xyz + (int)w
 void launch_obs_mask(hipStream_t s, const double *soa, int F, int W, unsigned char *mask);      // N != 0 per (feature, pose)
 
 }  // namespace balm

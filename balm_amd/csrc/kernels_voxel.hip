@@ -1496,4 +1496,11 @@ int associate_device(hipStream_t s, const float *d_xyz, const int *d_frame, cons
 
 #include "kernels_window.inc"
 
+// the code object of this translation unit, loaded on the current device now (the runtime loads it on the first use of any of its
+// kernels otherwise: balm_prewarm does it on a background thread while the caller is still busy elsewhere)
+hipError_t preload_voxel() {
+  hipFuncAttributes a;
+  return hipFuncGetAttributes(&a, (const void *)k_set_u32);
+}
+
 }  // namespace balm

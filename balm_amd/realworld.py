@@ -97,7 +97,7 @@ SHIPPED_WINDOW_NPZ = os.path.join(os.path.dirname(os.path.dirname(os.path.abspat
 
 def end_to_end(npz_path=SHIPPED_WINDOW_NPZ, device=0, reps=5):
     """benchmark_realworld.cpp:183-218 on the shipped window, from HOST memory to optimised poses, through the C ABI: scans in
-    pageable numpy arrays -> balm_associate (pinned-ring upload + device association) -> balm_damping_iter with the driver's
+    pageable numpy arrays, one per scan -> balm_associate_scans (pinned-ring upload + device association) -> balm_damping_iter with the driver's
     constants.  `npz_path`: xyz [n,3] float32 in scan order, counts [W], poses [W,12] (tools/make_realworld_fixture.py writes it
     from datas/benchmark_realworld with this module's readers), optionally ref_poses / ref_log = the reference's own result.
     First repetition = cold (arena, pinned ring, code objects); the figures are the median of the others.  -> dict."""
@@ -107,7 +107,8 @@ def end_to_end(npz_path=SHIPPED_WINDOW_NPZ, device=0, reps=5):
     counts = np.asarray(d["counts"]).astype(np.int64)
     poses = np.ascontiguousarray(d["poses"], dtype=np.float64)
     W = int(counts.shape[0])
-    fid = np.repeat(np.arange(W, dtype=np.int32), counts)
+    offs = np.concatenate([[0], np.cumsum(counts)])
+    scans = [xyz[offs[i]:offs[i + 1]] for i in range(W)]          # one container per scan, as the driver holds them (here: packed xyz)
     ctx = capi.Context(W, device, capi.FLAG_TIMING)
     rows = []
     out = lg = None
@@ -115,7 +116,7 @@ def end_to_end(npz_path=SHIPPED_WINDOW_NPZ, device=0, reps=5):
     for rep in range(reps + 1):
         ctx.reset_timing()
         t0 = time.perf_counter()
-        F, nroots, _ = ctx.associate(xyz, fid, poses, 2.0, want_features=False)
+        F, nroots, _ = ctx.associate_scans(scans, poses, 2.0, want_features=False)
         t1 = time.perf_counter()
         out, lg = ctx.damping_iter(poses, form=capi.FORM_LEFT, u0=0.01, max_iter=10, min_planes=20)
         t2 = time.perf_counter()
@@ -124,9 +125,9 @@ def end_to_end(npz_path=SHIPPED_WINDOW_NPZ, device=0, reps=5):
                          assoc_device=tm["voxel"][0]))
     ctx.close()
     med = {k: float(np.median([r[k] for r in rows[1:]])) for k in rows[0]}
-    up_bytes = xyz.nbytes + fid.nbytes
+    up_bytes = xyz.nbytes                                          # (no per-point scan index on this route: 177 counts)
     res = {
-        "what": "BASELINE configs[4] as shipped (datas/benchmark_realworld: %d scans, %d points): host scans -> balm_associate -> "
+        "what": "BASELINE configs[4] as shipped (datas/benchmark_realworld: %d scans, %d points): host scans -> balm_associate_scans -> "
                 "balm_damping_iter (u0=0.01, <=10 it., >=20 planes/pose) -> poses, wall clock through the C ABI from pageable host "
                 "memory; median of %d warm repetitions" % (W, xyz.shape[0], reps),
         "scans": W, "points": int(xyz.shape[0]), "root_voxels": int(nroots), "features": int(F), "lm_iterations": int(len(lg)),
@@ -150,6 +151,62 @@ def end_to_end(npz_path=SHIPPED_WINDOW_NPZ, device=0, reps=5):
     return res
 
 
+CPP_E2E_EXE = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "bin", "shim_realworld_e2e")
+
+
+def write_window_bin(npz_path, out_path):
+    """the window file tests/cpp/shim_realworld_e2e.cpp reads: int32 W, int32 has_ref, int64 n | int64 counts[W] | double poses[W*12]
+    | double ref_poses[W*12] (if has_ref) | float32 xyz[n*3]"""
+    d = np.load(npz_path)
+    xyz = np.ascontiguousarray(d["xyz"], dtype=np.float32).reshape(-1, 3)
+    counts = np.asarray(d["counts"]).astype(np.int64)
+    has_ref = "ref_poses" in d.files
+    with open(out_path, "wb") as f:
+        f.write(np.array([counts.shape[0], int(has_ref)], dtype=np.int32).tobytes())
+        f.write(np.array([xyz.shape[0]], dtype=np.int64).tobytes())
+        f.write(counts.tobytes())
+        f.write(np.ascontiguousarray(d["poses"], dtype=np.float64).tobytes())
+        if has_ref:
+            f.write(np.ascontiguousarray(d["ref_poses"], dtype=np.float64).tobytes())
+        f.write(xyz.tobytes())
+    return out_path
+
+
+def end_to_end_cpp(npz_path=SHIPPED_WINDOW_NPZ, reps=5, exe=CPP_E2E_EXE, features_out=None, env=None, late=False):
+    """The same window through the C++ side of the boundary: tests/cpp/shim_realworld_e2e.cpp = the reference's translation unit
+    (tools.hpp, bavoxel.hpp) + include/balm_shim.hpp, scans held as vector<pcl::PointCloud<PointXYZINormal>::Ptr> (48-byte
+    elements), `BALM2_HIP::associate(pl_fulls, x_buf); damping_iter(x_buf)` timed on the caller's thread, cold (first use in a fresh
+    process, context creation apart) and warm (median).  `late`: the optimizer object is declared after the scans are read (where the
+    reference declares `BALM2 opt;`), not first thing in main -- nothing of the device's start-up overlaps.  The binary is built where the reference's headers are
+    (tests/cpp/build_shim_driver.sh -> tools/bin/, travels); -> dict, or None when it is not there."""
+    import subprocess
+    import tempfile
+    if not os.path.exists(exe):
+        return None
+    with tempfile.TemporaryDirectory() as td:
+        win = write_window_bin(npz_path, os.path.join(td, "window.bin"))
+        cmd = [exe, win, str(int(reps)), features_out or "-"] + (["late"] if late else [])
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("SHIM_E2E ")]
+    if not line:
+        raise RuntimeError("shim_realworld_e2e failed (rc %d): %s %s" % (out.returncode, out.stdout[-500:], out.stderr[-500:]))
+    kv = dict(t.split("=", 1) for t in line[0].split()[1:])
+    return {
+        "what": "the same window through include/balm_shim.hpp from C++: %s scans as pcl::PointCloud<PointXYZINormal> (%s-byte elements) -> "
+                "BALM2_HIP::associate(pl_fulls, x_buf) -> BALM2_HIP::damping_iter(x_buf), steady_clock on the caller's thread; "
+                "cold = first use in a fresh process, warm = median of %s further calls" % (kv["scans"], kv["point_bytes"], kv["reps"]),
+        "optimizer_object_declared": kv["declared"] + (" in main: the device start-up runs behind the reading of the scans" if kv["declared"] == "first"
+                                                         else " (after the scans are read, benchmark_realworld.cpp:217: no overlap)"),
+        "features": int(kv["features"]), "lm_iterations": int(kv["lm_iterations"]),
+        "ms_total": float(kv["total"]), "ms_associate_call": float(kv["associate"]), "ms_lm_call": float(kv["lm"]),
+        "ms_upload": float(kv["upload"]), "ms_associate_device": float(kv["assoc_device"]),
+        "ms_cold_create": float(kv["cold_create"]), "ms_cold_associate": float(kv["cold_associate"]), "ms_cold_lm": float(kv["cold_lm"]),
+        "ms_cold_first_call": float(kv["cold_associate"]) + float(kv["cold_lm"]),
+        "vs_reference": {"max_rot_rad": float(kv["max_rot"]), "max_trans_m": float(kv["max_trans"]),
+                         "ok": bool(out.returncode == 0 and 0 <= float(kv["max_rot"]) <= 1e-5 and 0 <= float(kv["max_trans"]) <= 1e-4)},
+    }
+
+
 def main(argv=None):
     import argparse
     ap = argparse.ArgumentParser()
@@ -163,7 +220,9 @@ def main(argv=None):
     from . import capi
     if a.npz:
         import json
-        print(json.dumps(end_to_end(a.data_dir, a.device)))
+        res = end_to_end(a.data_dir, a.device)
+        res["cpp_shim"] = end_to_end_cpp(a.data_dir)
+        print(json.dumps(res))
         return 0
     t = time.time()
     poses, frames = load_window(a.data_dir)

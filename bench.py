@@ -602,6 +602,17 @@ def main(argv=None):
             try:
                 ctx.close()
                 out["realworld_end_to_end"] = rw.end_to_end(rw.SHIPPED_WINDOW_NPZ, local_rank)
+                # ... and what the reference's C++ drivers get through include/balm_shim.hpp, scans held as pcl clouds (a fresh
+                # process: its first call is the cold figure a one-shot driver pays)
+                try:
+                    cpp = rw.end_to_end_cpp(rw.SHIPPED_WINDOW_NPZ)
+                    if cpp is not None:
+                        late = rw.end_to_end_cpp(rw.SHIPPED_WINDOW_NPZ, reps=1, late=True)
+                        cpp["declared_late"] = {k: late[k] for k in ("optimizer_object_declared", "ms_cold_create", "ms_cold_associate", "ms_cold_lm", "ms_cold_first_call")}
+                    out["realworld_end_to_end"]["cpp_shim"] = cpp if cpp is not None else {
+                        "skipped": "tools/bin/shim_realworld_e2e not built (tests/cpp/build_shim_driver.sh needs the reference's headers)"}
+                except Exception as e:
+                    out["realworld_end_to_end"]["cpp_shim"] = {"error": repr(e)}
                 ctx = capi.Context(W, local_rank, capi.FLAG_TIMING)
                 ctx.set_features(sc.clusters, None, sc.coeffs)
             except Exception as e:

@@ -20,6 +20,8 @@
 #ifndef BALM_HIP_H
 #define BALM_HIP_H
 
+#include <stddef.h>
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -74,6 +76,13 @@ typedef struct balm_lm_opts {
 balm_ctx *balm_create(int win_size, int device, int flags);
 void balm_destroy(balm_ctx *ctx);
 
+/* Starts, on a background thread of the library, what the first use of `device` costs a process and needs no window size: the
+ * runtime's own start, the pinned staging ring of the uploads and the code objects of the association / cluster-build / solve
+ * kernels (60-100 ms together, profiles/r06_cold_call.txt).  Returns at once; idempotent; balm_create calls it too.  The reference's
+ * drivers are one-shot programs (benchmark_realworld.cpp:179): a caller that declares its optimizer object FIRST -- the shim's
+ * constructor calls this -- has the device ready by the time its scans are read.  BALM_ERR_ARG: no such device. */
+int balm_prewarm(int device);
+
 /* SURVEY 8(b)'s `n_devices`: one context that shards its features over the n_devices GPUs
  * first_device .. first_device+n_devices-1 of this process (one host thread, one stream and one
  * replica of the small per-window state per device) and sums the per-device Hessian/gradient/residual
@@ -113,7 +122,8 @@ int balm_set_features(balm_ctx *ctx, int F, const double *clusters, const double
  * a pinned staging chunk of the library that leaves for the device as soon as it is full, so the table is
  * never flattened into a second host copy.  fill is called from several host threads of the library at
  * once, on disjoint feature ranges, every feature exactly once, before the call returns; it must only read
- * the caller's data.  balm_set_features is this call with a memcpy as fill. */
+ * the caller's data and must NOT call back into this library (the library's host pool runs one job at a time: an
+ * upload or any other entry point called from inside fill deadlocks).  balm_set_features is this call with a memcpy as fill. */
 typedef void (*balm_fill_clusters_fn)(void *user, int f0, int f1, double *dst);
 int balm_set_features_cb(balm_ctx *ctx, int F, balm_fill_clusters_fn fill, void *user, const double *fix,
                          const double *coeffs);
@@ -150,6 +160,17 @@ int balm_damping_iter(balm_ctx *ctx, const balm_lm_opts *opts, double *poses_ino
 int balm_build_clusters(balm_ctx *ctx, int F, const float *xyz, const int *feat_id,
                         const int *pose_id, long n_pts, const double *fix, const double *coeffs,
                         double *clusters_out);
+
+/* The same for a caller that holds its points the way the reference does -- one pcl::PointCloud<PointType> per plane with the
+ * observing pose in `intensity` (benchmark_virtual.cpp:375,392-403,586; PointType = pcl::PointXYZINormal, 48-byte elements,
+ * include/tools.hpp:22): plane_points[a] -> plane_count[a] elements `stride_bytes` apart, float x, y, z at byte offset 0 of each
+ * element and the pose index as a FLOAT at byte `pose_offset_bytes` (converted like the reference's `(int)ap.intensity`, :396).
+ * The library's host threads read the containers where they lie and pack 16 bytes per point straight into the pinned upload
+ * chunks; the plane index of every point is expanded on the device from the counts.  Nothing is flattened on the caller's thread.
+ * stride_bytes >= 12, a multiple of 4; pose_offset_bytes + 4 <= stride_bytes; empty planes are legal (NULL pointer allowed). */
+int balm_build_clusters_planes(balm_ctx *ctx, int F, const void *const *plane_points, const long *plane_count,
+                               size_t stride_bytes, size_t pose_offset_bytes, const double *fix, const double *coeffs,
+                               double *clusters_out);
 
 /* Replaces the caller's association stage: cut_voxel over every scan, OCTO_TREE_NODE::recut and
  * ::tras_opt over every root voxel (bavoxel.hpp:1170-1223, 654-776, 908-929;
@@ -189,6 +210,17 @@ void balm_voxel_defaults(balm_voxel_opts *opts);
 int balm_associate(balm_ctx *ctx, const balm_voxel_opts *opts, const float *xyz, const int *frame_id,
                    long n_pts, const double *poses, int *F_out, long *n_root_voxels);
 
+/* The same for the reference's own scan containers -- `vector<pcl::PointCloud<PointType>::Ptr> pl_fulls`
+ * (benchmark_realworld.cpp:155,183-184): scan_points[i] -> scan_count[i] elements `stride_bytes` apart (48 for PointXYZINormal),
+ * float x, y, z at byte offset 0 of each.  n_scans = win_size + opts->fix_frames, scans in window order.  The library's host
+ * threads pack 12 bytes per point from the caller's clouds straight into the pinned upload chunks (no flattened copy, nothing on
+ * the caller's thread) and the scan index of every point is expanded on the device from the n_scans counts: the per-point frame_id
+ * array of balm_associate -- a quarter of its upload -- does not exist on this route.  stride_bytes >= 12, a multiple of 4; empty
+ * scans are legal.  Same results as balm_associate on the flattened arrays, bit for bit. */
+int balm_associate_scans(balm_ctx *ctx, const balm_voxel_opts *opts, int n_scans, const void *const *scan_points,
+                         const long *scan_count, size_t stride_bytes, const double *poses, int *F_out,
+                         long *n_root_voxels);
+
 /* Sliding-window map: the INCREMENTAL use of the reference's adaptive voxel map, kept on the device between calls
  * (OCTO_TREE_ROOT / OCTO_TREE_NODE, src/benchmark/bavoxel.hpp:625-963; balm_associate above is the batch form).
  *   balm_window_open         an empty unordered_map<VOXEL_LOC, OCTO_TREE_ROOT*>; window size = the context's `win`, plus
@@ -214,6 +246,9 @@ int balm_associate(balm_ctx *ctx, const balm_voxel_opts *opts, const float *xyz,
 int balm_window_open(balm_ctx *ctx, const balm_voxel_opts *opts);
 int balm_window_recut(balm_ctx *ctx);
 int balm_window_add_scan(balm_ctx *ctx, const float *xyz, long n_pts, const double *pose12);
+/* balm_window_add_scan for a scan in the caller's own container (`pcl::PointCloud<PointType> &pl`, bavoxel.hpp:1170): n_pts
+ * elements `stride_bytes` apart, float x, y, z at byte offset 0 of each. */
+int balm_window_add_scan_strided(balm_ctx *ctx, const void *points, long n_pts, size_t stride_bytes, const double *pose12);
 int balm_window_features(balm_ctx *ctx, int *F_out);
 int balm_window_marginalize(balm_ctx *ctx, int mg_size, const double *poses);
 int balm_window_info(balm_ctx *ctx, int *scans_in_window, long *points, long *nodes);
@@ -296,9 +331,9 @@ const char *balm_version(void);
 
 /* ABI revision of this header.  It changes whenever a struct above grows, an enum gains a member that sizes a caller's array
  * (BALM_T_COUNT) or an entry point changes its meaning: 3 = round 3 (balm_voxel_opts gained fix_point_limit / defer_recut,
- * BALM_T_COUNT went from 9 to 10), 4 = round 4 (balm_abi_version itself), 5 = this header (balm_set_features_cb, BALM_T_UPLOAD: BALM_T_COUNT 11).  A caller built against another revision must not call anything else:
+ * BALM_T_COUNT went from 9 to 10), 4 = round 4 (balm_abi_version itself), 5 = round 5 (balm_set_features_cb, BALM_T_UPLOAD: BALM_T_COUNT 11), 6 = this header (the strided point-container entries balm_associate_scans / balm_build_clusters_planes / balm_window_add_scan_strided, balm_prewarm).  A caller built against another revision must not call anything else:
  *     if (balm_abi_version() != BALM_ABI_VERSION) { refuse }                                                              */
-#define BALM_ABI_VERSION 5
+#define BALM_ABI_VERSION 6
 int balm_abi_version(void);
 
 #ifdef __cplusplus

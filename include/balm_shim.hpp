@@ -13,8 +13,10 @@
 #ifndef BALM_SHIM_HPP
 #define BALM_SHIM_HPP
 
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 #include <vector>
 
 #include "balm_hip.h"
@@ -30,12 +32,15 @@ class BALM2_HIP {
   int device = 0;
   int n_devices = 0;           // >= 1: balm_create_multi over devices device..device+n_devices-1 (features sharded, one RCCL
                                // all-reduce per evaluation inside the library; replaces the thread sum at bavoxel.hpp:1049-1056)
+  bool timing = false;         // BALM_FLAG_TIMING: HIP-event spans per kernel class (balm_get_timing on context())
   bool verbose = true;         // the reference always prints its per-iteration line (:1132)
   bool reanchor = true;        // bavoxel.hpp:1159-1164 (the consistency driver does not: BAs_left.hpp:1087)
   double abs_tol = 0;          // > 0: the consistency driver's stop rule |r1-r2| < 1e-9 (BAs_left.hpp:1083)
   std::vector<balm_iter_log> last_log;
 
-  BALM2_HIP() {}
+  // The device's one-off start-up (runtime, pinned upload ring, code objects) begins in the background here: declare the object
+  // before the scans are read and the first associate() / damping_iter() finds a warm device.  `dev`: as the `device` member.
+  explicit BALM2_HIP(int dev = 0) : device(dev) { balm_prewarm(dev); }
   ~BALM2_HIP() { if (ctx_) balm_destroy(ctx_); }
   BALM2_HIP(const BALM2_HIP &) = delete;
   BALM2_HIP &operator=(const BALM2_HIP &) = delete;
@@ -67,9 +72,10 @@ class BALM2_HIP {
   // Replaces the association block of the reference's drivers (benchmark_realworld.cpp:183-200: cut_voxel per
   // scan into the surf_map, OCTO_TREE_ROOT::recut, ::tras_opt -> VOX_HESS::push_voxel) with one device call.
   // Reads the same globals the reference's code reads: win_size, voxel_size, eigen_value_array, min_ps
-  // (bavoxel.hpp:8-17; layer_limit 0..2).  `Cloud` is pcl::PointCloud<PointType>::Ptr (any
-  // pointer to a container of points with float x, y, z).  Returns the number of plane features, which are
-  // installed on the device: follow with damping_iter(x_stats).
+  // (bavoxel.hpp:8-17; layer_limit 0..2).  `CloudPtr` is pcl::PointCloud<PointType>::Ptr (any pointer to a
+  // container whose `points` is a contiguous vector of elements that start with float x, y, z).  The clouds are read
+  // where they lie by the library's host threads.  Returns the number of plane features, which are installed on the
+  // device: follow with damping_iter(x_stats).
   template <class CloudPtr>
   int associate(const std::vector<CloudPtr> &pl_fulls, const std::vector<IMUST> &x_buf) {
     ensure_ctx();
@@ -77,16 +83,16 @@ class BALM2_HIP {
       fprintf(stderr, "balm_hip: associate needs layer_limit in 0..2 and win_size scans and poses\n");
       abort();
     }
-    size_t n = 0;
-    for (const CloudPtr &pl : pl_fulls) n += pl->size();
-    std::vector<float> xyz(3 * n);
-    std::vector<int> frame(n);
-    size_t k = 0;
-    for (int i = 0; i < win_size; i++)
-      for (const auto &pt : *pl_fulls[(size_t)i]) {
-        xyz[3 * k] = pt.x; xyz[3 * k + 1] = pt.y; xyz[3 * k + 2] = pt.z;
-        frame[k++] = i;
-      }
+    // the clouds stay where they are: the library's host threads pack x, y, z out of the 48-byte PointType elements straight into
+    // its pinned upload chunks (balm_associate_scans); the caller's thread only lists W pointers and counts
+    std::vector<const void *> base((size_t)win_size);
+    std::vector<long> count((size_t)win_size);
+    for (int i = 0; i < win_size; i++) {
+      const auto &pts = pl_fulls[(size_t)i]->points;
+      static_assert(offsetof(typename std::decay<decltype(pts[0])>::type, x) == 0, "PointType: x, y, z lead the element");
+      base[(size_t)i] = pts.empty() ? nullptr : (const void *)&pts[0];
+      count[(size_t)i] = (long)pts.size();
+    }
     std::vector<double> poses = flatten_poses(x_buf);
     balm_voxel_opts o;
     balm_voxel_defaults(&o);
@@ -96,7 +102,7 @@ class BALM2_HIP {
     o.layer_limit = layer_limit;
     int F = 0;
     long roots = 0;
-    check(balm_associate(ctx_, &o, xyz.data(), frame.data(), (long)n, poses.data(), &F, &roots));
+    check(balm_associate_scans(ctx_, &o, win_size, base.data(), count.data(), sizeof(pl_fulls[0]->points[0]), poses.data(), &F, &roots));
     loaded_ = (const void *)this;        // the device features no longer mirror a VOX_HESS
     loaded_F_ = (size_t)F;
     return F;
@@ -122,11 +128,9 @@ class BALM2_HIP {
   }
   template <class Cloud>
   void window_add_scan(const Cloud &pl, const IMUST &x) {
-    std::vector<float> xyz(3 * pl.size());
-    size_t k = 0;
-    for (const auto &pt : pl) { xyz[3 * k] = pt.x; xyz[3 * k + 1] = pt.y; xyz[3 * k + 2] = pt.z; k++; }
     std::vector<double> pose = flatten_poses(std::vector<IMUST>(1, x));
-    check(balm_window_add_scan(ctx_, xyz.data(), (long)pl.size(), pose.data()));
+    if (pl.points.empty()) { fprintf(stderr, "balm_hip: window_add_scan: empty scan\n"); abort(); }
+    check(balm_window_add_scan_strided(ctx_, &pl.points[0], (long)pl.points.size(), sizeof(pl.points[0]), pose.data()));
   }
   int window_features() {
     int F = 0;
@@ -222,7 +226,8 @@ class BALM2_HIP {
   void ensure_ctx() {
     if (ctx_ && ctx_win_ == win_size) return;
     if (ctx_) balm_destroy(ctx_);
-    ctx_ = n_devices >= 1 ? balm_create_multi(win_size, device, n_devices, 0) : balm_create(win_size, device, 0);
+    const int flags = timing ? BALM_FLAG_TIMING : 0;
+    ctx_ = n_devices >= 1 ? balm_create_multi(win_size, device, n_devices, flags) : balm_create(win_size, device, flags);
     ctx_win_ = win_size;
     loaded_ = nullptr;
     if (!ctx_) {

@@ -19,8 +19,10 @@
 #define BALM_SHIM_VIRTUAL_HPP
 
 #include <chrono>
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 #include <vector>
 
 #include "balm_hip.h"
@@ -39,7 +41,7 @@ class BALM2_HIP {
   int winSize = 0;             // public member of the reference's class (:109), set by dampingIter (:381)
   std::vector<balm_iter_log> last_log;
 
-  BALM2_HIP() {}
+  explicit BALM2_HIP(int dev = 0) : device(dev) { balm_prewarm(dev); }     // the device's one-off start-up begins in the background
   ~BALM2_HIP() { if (ctx_) balm_destroy(ctx_); }
   BALM2_HIP(const BALM2_HIP &) = delete;
   BALM2_HIP &operator=(const BALM2_HIP &) = delete;
@@ -61,18 +63,19 @@ class BALM2_HIP {
       }
     }
     // :391-403: weights winSize*ptsSize; one PointCluster per (plane, pose), pushed point by point
-    size_t n = 0;
-    for (const CloudPtr &pl : plSurfs) n += pl->size();
-    std::vector<float> xyz(3 * n);
-    std::vector<int> feat(n), pose(n);
-    size_t k = 0;
-    for (int a = 0; a < F; a++)
-      for (const auto &ap : plSurfs[(size_t)a]->points) {
-        xyz[3 * k] = ap.x; xyz[3 * k + 1] = ap.y; xyz[3 * k + 2] = ap.z;
-        feat[k] = a; pose[k] = (int)ap.intensity; k++;
-      }
+    // The per-plane clouds stay where they are: the library's host threads read x, y, z and `intensity` out of the 48-byte
+    // PointType elements into its pinned upload chunks (balm_build_clusters_planes); this thread lists F pointers and counts.
+    std::vector<const void *> base((size_t)F);
+    std::vector<long> count((size_t)F);
+    for (int a = 0; a < F; a++) {
+      const auto &pts = plSurfs[(size_t)a]->points;
+      base[(size_t)a] = pts.empty() ? nullptr : (const void *)&pts[0];
+      count[(size_t)a] = (long)pts.size();
+    }
+    typedef typename std::decay<decltype(plSurfs[0]->points[0])>::type Pt;
+    static_assert(offsetof(Pt, x) == 0, "PointType: x, y, z lead the element");
     std::vector<double> coeffs((size_t)F, (double)(W * ptsSize));
-    check(balm_build_clusters(ctx_, F, xyz.data(), feat.data(), pose.data(), (long)n, nullptr, coeffs.data(), nullptr));
+    check(balm_build_clusters_planes(ctx_, F, base.data(), count.data(), sizeof(Pt), offsetof(Pt, intensity), nullptr, coeffs.data(), nullptr));
     std::vector<double> poses(12 * (size_t)W);
     for (int i = 0; i < W; i++) {
       double *q = poses.data() + 12 * i;

@@ -20,3 +20,10 @@ g++ -std=c++14 -O3 -w -pthread -I"$ROOT/oracle/compat" -I"$REF/include" -I"$REF/
     -o "$ROOT/oracle/_ref/shim_virtual_driver" "$ROOT/tests/cpp/shim_virtual_driver.cpp" \
     -L"$ROOT/balm_amd/lib" -lbalm_hip -ldl -Wl,-rpath,'$ORIGIN/../../balm_amd/lib'
 echo "built $ROOT/oracle/_ref/shim_virtual_driver"
+# the shipped window through BALM2_HIP::associate + damping_iter, timed (bench.py's realworld_end_to_end.cpp_shim leg): a driver of
+# the PRODUCT path, so it does not live under oracle/ -- tools/bin/ is git-ignored and travels like the other built files
+mkdir -p "$ROOT/tools/bin"
+g++ -std=c++14 -O2 -w -pthread -I"$ROOT/oracle/compat" -I"$REF/include" -I"$REF/src/benchmark" -I"$ROOT/include" \
+    -o "$ROOT/tools/bin/shim_realworld_e2e" "$ROOT/tests/cpp/shim_realworld_e2e.cpp" \
+    -L"$ROOT/balm_amd/lib" -lbalm_hip -ldl -Wl,-rpath,'$ORIGIN/../../balm_amd/lib'
+echo "built $ROOT/tools/bin/shim_realworld_e2e"

@@ -32,8 +32,57 @@ static int check(size_t bytes, size_t unit, int rounds) {
   return 0;
 }
 
+// strided point containers (48-byte PointXYZINormal-like elements, ragged and empty scans) -> packed xyz / xyz+aux records
+struct Pt48 { float x, y, z, pad; float n[4]; float intensity, curvature, c2, c3; };
+static int check_points(const std::vector<long> &counts, bool aux, size_t stride) {
+  std::vector<std::vector<char>> clouds(counts.size());
+  std::vector<const void *> base(counts.size());
+  std::vector<float> want;
+  unsigned v = 12345;
+  auto next = [&] { v = v * 1664525u + 1013904223u; return (float)(v >> 8) * (1.0f / 65536.0f); };
+  for (size_t k = 0; k < counts.size(); k++) {
+    clouds[k].assign((size_t)counts[k] * stride + 16, (char)0x5a);
+    base[k] = counts[k] ? clouds[k].data() : nullptr;
+    for (long i = 0; i < counts[k]; i++) {
+      float *p = reinterpret_cast<float *>(clouds[k].data() + (size_t)i * stride);
+      for (int c = 0; c < 3; c++) { p[c] = next(); want.push_back(p[c]); }
+      if (aux) { float *w = reinterpret_cast<float *>(clouds[k].data() + (size_t)i * stride + 32); *w = (float)(i % 7); want.push_back(*w); }
+    }
+  }
+  balm::StridedPoints sp;
+  if (!sp.set((int)counts.size(), base.data(), counts.data(), stride, aux ? 32 : balm::StridedPoints::NO_AUX)) { printf("FAIL StridedPoints::set\n"); return 1; }
+  std::vector<float> got(want.size() + 4, -1.0f);
+  balm::PinnedRing ring;
+  hipError_t e = balm::staged_points(ring, 0, nullptr, got.data(), sp);
+  hipStreamSynchronize(nullptr);
+  ring.release();
+  if (e != hipSuccess || (size_t)sp.total() * sp.rec() != want.size() * 4 || std::memcmp(got.data(), want.data(), want.size() * 4) || got[want.size()] != -1.0f) {
+    printf("FAIL points scans=%zu aux=%d stride=%zu\n", counts.size(), (int)aux, stride);
+    return 1;
+  }
+  // any sub-range, from any (misaligned) destination
+  std::vector<float> part(3000 * 4 + 8);
+  const long n = sp.total();
+  for (long p0 : {0l, 1l, 5l, n / 2, n - 7}) {
+    if (p0 < 0 || p0 >= n) continue;
+    const long np = std::min<long>(3000, n - p0);
+    for (int mis = 0; mis < 4; mis++) {
+      sp.gather(reinterpret_cast<char *>(part.data() + mis), p0, np);
+      if (std::memcmp(part.data() + mis, want.data() + (size_t)p0 * (sp.rec() / 4), (size_t)np * sp.rec())) { printf("FAIL gather p0=%ld mis=%d\n", p0, mis); return 1; }
+    }
+  }
+  return 0;
+}
+
 int main() {
   int rc = 0;
+  rc |= check_points({5, 0, 1, 100003, 0, 7, 250001, 3}, false, 48);
+  rc |= check_points({5, 0, 1, 100003, 0, 7, 250001, 3}, true, 48);
+  rc |= check_points({1000, 999, 40001}, false, 12);          // already packed
+  rc |= check_points({1000, 999, 40001}, false, 16);
+  rc |= check_points({17}, false, 48);
+  { balm::StridedPoints bad; const long c1[1] = {4}; const void *b1[1] = {nullptr};
+    if (bad.set(1, b1, c1, 48) || bad.set(0, nullptr, nullptr, 10)) { printf("FAIL StridedPoints accepted a bad container\n"); rc = 1; } }
   rc |= check(1000, 8, 2);                                   // the small path
   rc |= check(((size_t)1 << 20) + 64, 64, 2);                // just above it: one chunk
   rc |= check((size_t)5 * (16 << 20) + 12345 * 12, 12, 2);   // 5+ chunks, 12-byte units (points), ring reused across calls
