@@ -952,7 +952,6 @@ static int one_associate(balm_ctx *ctx, const balm_voxel_opts *opts, const float
 #endif
   if (scans) {
     e = hipMemcpyAsync(d_first, scans->first.data(), ((size_t)WT + 1) * sizeof(long), hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) launch_expand_ids(ctx->stream, d_first, WT, n_pts, d_f);      // (ahead of the points: runs while the pool fills the first chunk)
     if (e == hipSuccess) {
       Span sp(ctx, BALM_T_UPLOAD);
       e = staged_points(ctx->ring, ctx->device, ctx->stream, d_xyz, *scans);
@@ -991,7 +990,7 @@ static int one_associate(balm_ctx *ctx, const balm_voxel_opts *opts, const float
         ctx->amail.scan_state = (unsigned long long *)st; ctx->amail.scan_gen = 0;
       } else { if (st) hipFree(st); hipGetLastError(); }
     }
-    arc = associate_device(ctx->stream, d_xyz, d_f, d_pos, n_pts, ao, ctx->d_arena, ctx->arena_cap, &need, &F, &d_out, &d_coe,
+    arc = associate_device(ctx->stream, d_xyz, scans ? nullptr : d_f, scans ? d_first : nullptr, d_pos, n_pts, ao, ctx->d_arena, ctx->arena_cap, &need, &F, &d_out, &d_coe,
                            &d_fix, &d_lay, opts->want_point_features ? &d_pf : nullptr, &nroots, &ctx->amail, &owned);
   }
   cold_mark("associate: associate_device returned");

@@ -283,7 +283,7 @@ struct AssocOpts {
   int defer_recut = 0;      // window map: add_scan is cut_voxel only
 };
 // *outputs_owned: the output arrays were hipMalloc'ed for the caller (true) or live in the arena until the next call (false)
-int associate_device(hipStream_t s, const float *d_xyz, const int *d_frame, const double *d_poses, long n, const AssocOpts &o,
+int associate_device(hipStream_t s, const float *d_xyz, const int *d_frame, const long *d_first, const double *d_poses, long n, const AssocOpts &o,
                      void *arena, size_t arena_cap, size_t *arena_need, int *F_out, double **d_out, double **d_coe,
                      double **d_fix, int **d_layer, int **d_point_feat, long *n_roots, AssocMail *mail, bool *outputs_owned);
 

@@ -56,6 +56,37 @@ __device__ __forceinline__ void world_point(const float *__restrict__ xyz, const
                                __dmul_rn(pose[6 + r], po[2])), pose[9 + r]);
 }
 
+// The scan a point belongs to: the caller's per-point array (balm_associate), or -- balm_associate_scans, where the scans arrive as
+// containers -- the offsets of the scans in the packed point list: first[k] <= p < first[k + 1] (m scans, empty ones allowed).  The
+// per-point array then never exists: 4 bytes per point not uploaded, not expanded (53 us for the shipped window), not read by passes A, B.
+struct ScanOf {
+  const int *frame;
+  const long *first;
+  int m;
+  static constexpr int MAX_SCANS = 512;                         // (associate_device refuses more)
+  // the offsets into LDS: the searches below are chains of dependent loads (from HBM: k_vox_range 78 -> 125 us)
+  __device__ __forceinline__ void stage(long *tbl) const {
+    if (frame) return;
+    for (int t = threadIdx.x; t <= m; t += blockDim.x) tbl[t] = first[t];
+    __syncthreads();
+  }
+  __device__ __forceinline__ int find(long p, const long *tbl) const {           // p < first[m]; tbl = first, or its LDS copy
+    if (frame) return frame[p];
+    int lo = 0, hi = m;
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (tbl[mid] <= p) lo = mid; else hi = mid;
+    }
+    return lo;
+  }
+  // the scan of p, given the scan `fr` of an earlier point (a kernel's points ascend: almost always no step)
+  __device__ __forceinline__ int advance(int fr, long p, const long *tbl) const {
+    if (frame) return frame[p];
+    while (fr + 1 < m && p >= tbl[fr + 1]) fr++;
+    return fr;
+  }
+};
+
 // cut_voxel's key (bavoxel.hpp:1178-1184): loc = (float)(q / voxel_size), shifted down for negatives, truncated
 // (Measured, round 5: q * (1 / voxel_size) where the voxel size is a power of two -- the same correctly rounded number without the
 // three FP64 divisions per point -- and the pose through the scalar cache: passes A and B of balm_associate did not move, 94 / 83 us;
@@ -72,9 +103,12 @@ __device__ __forceinline__ long long voxel_key(double q, double vs) {
 // non-finite coordinate (input validation rides along instead of a host pass over the points).
 constexpr int RANGE_BLOCKS = 2048;
 constexpr int RANGE_ROW = 7;
-__global__ __launch_bounds__(256) void k_vox_range(const float *__restrict__ xyz, const int *__restrict__ frame,
+__global__ __launch_bounds__(256) void k_vox_range(const float *__restrict__ xyz, const ScanOf scan,
                                                    const double *__restrict__ poses, long n, int W, double vs,
                                                    int *__restrict__ range /* [gridDim.x][RANGE_ROW] */) {
+  const int *__restrict__ frame = scan.frame;
+  __shared__ long s_first[ScanOf::MAX_SCANS + 1];
+  scan.stage(s_first);
   __shared__ int red[4][RANGE_ROW];
   int lo[3] = {1 << 30, 1 << 30, 1 << 30}, hi[3] = {-(1 << 30), -(1 << 30), -(1 << 30)};
   int bad = 0;
@@ -82,6 +116,8 @@ __global__ __launch_bounds__(256) void k_vox_range(const float *__restrict__ xyz
   // per trip on 1 024 blocks the pass had 5 MB in flight and ran at 2.3 TB/s -- latency-bound (94 us for the shipped window's 215 MB).
   constexpr int RANGE_U = 4;
   const long stride = (long)gridDim.x * blockDim.x;
+  int fcur = 0;                  // (offsets: the thread's points ascend, so does their scan)
+  if (!frame && (long)blockIdx.x * blockDim.x + threadIdx.x < n) fcur = scan.find((long)blockIdx.x * blockDim.x + threadIdx.x, s_first);
   for (long p0 = (long)blockIdx.x * blockDim.x + threadIdx.x; p0 < n; p0 += RANGE_U * stride) {
     long pp[RANGE_U];
     int frv[RANGE_U], frp[RANGE_U];
@@ -92,8 +128,8 @@ __global__ __launch_bounds__(256) void k_vox_range(const float *__restrict__ xyz
     for (int u = 0; u < RANGE_U; u++) {
       const bool in = pp[u] < n;
       const long p = in ? pp[u] : p0;
-      frv[u] = frame[p];
-      frp[u] = p > 0 ? frame[p - 1] : frv[u];
+      if (frame) { frv[u] = frame[p]; frp[u] = p > 0 ? frame[p - 1] : frv[u]; }
+      else { fcur = scan.advance(fcur, p, s_first); frv[u] = frp[u] = fcur; }
       xv[u][0] = xyz[3 * p]; xv[u][1] = xyz[3 * p + 1]; xv[u][2] = xyz[3 * p + 2];
     }
 #pragma unroll
@@ -148,13 +184,13 @@ struct KeyPack { long long off[3]; unsigned long long n[3]; };
 // pass B: packed root key + cut_func's octants (bavoxel.hpp:709-720) for both subdivision levels; the sort
 // value carries (point index, octants, frame) so that later passes never gather per-point attributes
 template <class K>
-__global__ __launch_bounds__(256) void k_vox_keys(const float *__restrict__ xyz, const int *__restrict__ frame,
+__global__ __launch_bounds__(256) void k_vox_keys(const float *__restrict__ xyz, const ScanOf scan,
                                                   const double *__restrict__ poses, long n, double vs, KeyPack kp,
                                                   K *__restrict__ k0, unsigned long long *__restrict__ val) {
   const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= n) return;
   double q[3], po[3];
-  const int fr = frame[p];
+  const int fr = scan.find(p, scan.first);
   world_point(xyz, poses + 12 * (long)fr, p, q, po);
   const float q1 = (float)(vs / 4.0);
   unsigned long long key = 0;
@@ -346,13 +382,20 @@ constexpr int PART_TS = 2048;          // records per partition tile (a tile nev
 
 // pass B of the fast path: root key + the record's tag (o1 << 12 | o2 << 9 | scan); the sort value is the point's index
 template <class K>
-__global__ __launch_bounds__(256) void k_vox_keys_tag(const float *__restrict__ xyz, const int *__restrict__ frame,
+__global__ __launch_bounds__(256) void k_vox_keys_tag(const float *__restrict__ xyz, const ScanOf scan,
                                                       const double *__restrict__ poses, long n, double vs, KeyPack kp,
                                                       K *__restrict__ k0, unsigned int *__restrict__ idx, unsigned short *__restrict__ tag) {
+  // offsets: the scan of the workgroup's first point is found once (one thread, nine dependent loads that hit the cache: every
+  // workgroup reads the same 1.4 KB); the others step on from it -- a point's scan is almost always its workgroup's first point's
+  __shared__ int s_f0;
+  if (!scan.frame) {
+    if (threadIdx.x == 0) s_f0 = scan.find(min((long)blockIdx.x * blockDim.x, n - 1), scan.first);
+    __syncthreads();
+  }
   const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= n) return;
   double q[3], po[3];
-  const int fr = frame[p];
+  const int fr = scan.frame ? scan.frame[p] : scan.advance(s_f0, p, scan.first);
   world_point(xyz, poses + 12 * (long)fr, p, q, po);
   const float q1 = (float)(vs / 4.0);
   unsigned long long key = 0;
@@ -410,6 +453,40 @@ __global__ void k_root_tiles(const unsigned int *__restrict__ root_start, long N
   else if (r == NR) tiles[r] = 0;
 }
 
+// recut (bavoxel.hpp:737-776) subdivides a root voxel only when it holds more than min_ps points and is NOT a plane: levels 1 and 2
+// exist for the points of those roots alone.  On the shipped window 77.5 % of the points sit in root voxels that ARE planes
+// (profiles/r06_assoc_levels.txt): their records are neither partitioned nor summed again.  One workgroup walks the roots (thousands,
+// not millions): tile_base[r] = partition tiles in front of root r, live_start[r] = records of split roots in front of it (the root's
+// place in the compact level lists); plan = {tiles, live records}.
+__global__ __launch_bounds__(1024) void k_live_plan(const unsigned int *__restrict__ root_start, const unsigned char *__restrict__ status0, long NR,
+                                                    unsigned int *__restrict__ tile_base, unsigned int *__restrict__ live_start,
+                                                    unsigned int *__restrict__ plan) {
+  __shared__ unsigned int wsum[2][16], carry[2];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  if (tid == 0) carry[0] = carry[1] = 0;
+  __syncthreads();
+  for (long r0 = 0; r0 <= NR; r0 += 1024) {
+    const long r = r0 + tid;
+    unsigned int cnt = 0, til = 0;
+    if (r < NR && status0[r] == 2 /* NODE_SPLIT */) { cnt = root_start[r + 1] - root_start[r]; til = (cnt + PART_TS - 1) / PART_TS; }
+    unsigned int xc = cnt, xt = til;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const unsigned int yc = __shfl_up(xc, d, 64), yt = __shfl_up(xt, d, 64);
+      if (lane >= d) { xc += yc; xt += yt; }
+    }
+    if (lane == 63) { wsum[0][wv] = xc; wsum[1][wv] = xt; }
+    __syncthreads();
+    unsigned int bc = carry[0], bt = carry[1];
+    for (int w = 0; w < wv; w++) { bc += wsum[0][w]; bt += wsum[1][w]; }
+    if (r <= NR) { live_start[r] = bc + xc - cnt; tile_base[r] = bt + xt - til; }
+    __syncthreads();
+    if (tid == 1023) { carry[0] = bc + xc; carry[1] = bt + xt; }
+    __syncthreads();
+  }
+  if (tid == 0) { plan[0] = carry[1]; plan[1] = carry[0]; }
+}
+
 // the root of tile t: the last r with tile_base[r] <= t
 __device__ __forceinline__ int part_tile_root(const unsigned int *__restrict__ tile_base, int NR, unsigned int t) {
   int lo = 0, hi = NR - 1;
@@ -436,7 +513,7 @@ __global__ __launch_bounds__(256) void k_part_hist(const unsigned short *__restr
 
 // per root (one wavefront, lane = cell): where each tile's records of each cell go, for the 64-way (level 2) and the 8-way (level 1)
 // partition -- cell-major inside the root, tile order inside a cell (= the stable order)
-__global__ __launch_bounds__(64) void k_part_offsets(const unsigned int *__restrict__ hist, const unsigned int *__restrict__ root_start,
+__global__ __launch_bounds__(64) void k_part_offsets(const unsigned int *__restrict__ hist, const unsigned int *__restrict__ root_start /* the roots' first places in the OUTPUT lists (k_live_plan's live_start) */,
                                                      const unsigned int *__restrict__ tile_base, int NR, unsigned int *__restrict__ off1,
                                                      unsigned int *__restrict__ off2) {
   const int r = blockIdx.x, lane = threadIdx.x;
@@ -879,7 +956,7 @@ __global__ __launch_bounds__(128) void k_node_status(const NodeTot *__restrict__
 
 // strict mode: a candidate plane with a point farther than max_dis from it is not a plane (BAs_left.hpp:658-674).
 // One lane per point of the level's sorted list; a node is demoted by whichever of its points finds the violation.
-__global__ __launch_bounds__(256) void k_point_plane_dist(const float *__restrict__ xyz, const int *__restrict__ frame,
+__global__ __launch_bounds__(256) void k_point_plane_dist(const float *__restrict__ xyz, const ScanOf scan,
                                                           const double *__restrict__ poses, const unsigned int *__restrict__ idx,
                                                           const unsigned int *__restrict__ segid_incl,
                                                           const unsigned int *__restrict__ nid_incl, long n,
@@ -891,7 +968,7 @@ __global__ __launch_bounds__(256) void k_point_plane_dist(const float *__restric
   if (status[j] != NODE_PLANE) return;
   const long p = idx[i];
   double q[3], po[3];
-  world_point(xyz, poses + 12 * (long)frame[p], p, q, po);
+  world_point(xyz, poses + 12 * (long)scan.find(p, scan.first), p, q, po);
   const double *pl = plane + (size_t)j * 6;
   const double d = fabs(pl[0] * (q[0] - pl[3]) + pl[1] * (q[1] - pl[4]) + pl[2] * (q[2] - pl[5]));
   if (!(d < max_dis)) status[j] = NODE_SPLIT;       // benign race: every writer stores the same value
@@ -935,8 +1012,9 @@ __global__ void k_point_features(long n, int levels, const unsigned int *__restr
   int f = -1;
   unsigned int j = node0[p];
   if (flag0[j]) f = (int)fid0[j];
-  if (f < 0 && levels > 1) { j = node1[p]; if (flag1[j]) f = (int)(base1 + fid1[j]); }
-  if (f < 0 && levels > 2) { j = node2[p]; if (flag2[j]) f = (int)(base2 + fid2[j]); }
+  // (0xffffffff: the point's root voxel was not split -- it has no node at that level)
+  if (f < 0 && levels > 1 && flag1) { j = node1[p]; if (j != 0xffffffffu && flag1[j]) f = (int)(base1 + fid1[j]); }
+  if (f < 0 && levels > 2 && flag2) { j = node2[p]; if (j != 0xffffffffu && flag2[j]) f = (int)(base2 + fid2[j]); }
   feat_of_point[p] = f;
 }
 
@@ -1001,6 +1079,31 @@ __global__ void k_mail_u32(const unsigned int *__restrict__ src, volatile unsign
   __threadfence_system();
   mail[1] = seq;
   __threadfence_system();
+}
+
+// up to four counts in one round trip (mail[4..7]); src pointers may repeat
+__global__ void k_mail_u32x4(const unsigned int *__restrict__ a, const unsigned int *__restrict__ b, const unsigned int *__restrict__ c,
+                             const unsigned int *__restrict__ d, volatile unsigned int *__restrict__ mail, unsigned int seq) {
+  mail[4] = *a; mail[5] = *b; mail[6] = *c; mail[7] = *d;
+  __threadfence_system();
+  mail[1] = seq;
+  __threadfence_system();
+}
+bool mail_u32x4(hipStream_t s, AssocMail *mail, const unsigned int *const src[4], unsigned int out[4]) {
+  if (mail && mail->host && mail->dev) {
+    const unsigned int seq = ++mail->seq;
+    hipLaunchKernelGGL(k_mail_u32x4, dim3(1), dim3(1), 0, s, src[0], src[1], src[2], src[3], mail->dev, seq);
+    volatile unsigned int *h = mail->host;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int spin = 0;; spin++) {
+      if (h[1] == seq) { std::atomic_thread_fence(std::memory_order_acquire); for (int k = 0; k < 4; k++) out[k] = h[4 + k]; return true; }
+      if ((spin & 255) == 255 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
+    }
+    if (hipStreamSynchronize(s) == hipSuccess && h[1] == seq) { for (int k = 0; k < 4; k++) out[k] = h[4 + k]; return true; }
+    return false;
+  }
+  for (int k = 0; k < 4; k++) if (hipMemcpyAsync(&out[k], src[k], sizeof(unsigned int), hipMemcpyDeviceToHost, s) != hipSuccess) return false;
+  return hipStreamSynchronize(s) == hipSuccess;
 }
 
 unsigned int last_u32(hipStream_t s, const unsigned int *d, long n, AssocMail *mail = nullptr) {
@@ -1236,13 +1339,14 @@ struct Level {
 
 }  // namespace
 
-// Device-side association.  d_xyz [n][3], d_frame [n] (0..W-1, points of a frame in scan order), d_poses [W][12],
+// Device-side association.  d_xyz [n][3]; the scan of every point either as d_frame [n] (0..W-1) or -- d_first != NULL -- as the offsets
+// of the W scans in the point list (W + 1 entries, points scan by scan); d_poses [W][12],
 // W = scans including the `fix_frames` marginalised ones.  `arena` / `arena_cap`: caller-owned scratch (may be NULL / 0);
 // *arena_need receives the bytes this call wanted.  On success *F_out features; *d_out = hipMalloc'ed
 // [F][W - fix_frames][10] (caller frees), *d_coe = [F], *d_fix = [F][10], *d_layer = [F], and, when want_points,
 // *d_point_feat = [n] feature of every point (-1: none).  Returns 0, or a negative code (-1 allocation / HIP
 // failure, -2 unsupported size, -3 a scan index outside [0, W) or a non-finite point).
-int associate_device(hipStream_t s, const float *d_xyz, const int *d_frame, const double *d_poses, long n, const AssocOpts &o,
+int associate_device(hipStream_t s, const float *d_xyz, const int *d_frame, const long *d_first, const double *d_poses, long n, const AssocOpts &o,
                      void *arena, size_t arena_cap, size_t *arena_need, int *F_out, double **d_out, double **d_coe,
                      double **d_fix, int **d_layer, int **d_point_feat, long *n_roots, AssocMail *mail, bool *outputs_owned) {
   *F_out = 0; *outputs_owned = true; *d_out = nullptr; *d_coe = nullptr; *d_fix = nullptr; *d_layer = nullptr; *n_roots = 0;
@@ -1253,6 +1357,8 @@ int associate_device(hipStream_t s, const float *d_xyz, const int *d_frame, cons
   const bool strict = o.max_dis > 0 || o.ratio21_max > 0 || o.lam0_max > 0;
   const bool want_points = d_point_feat != nullptr;
   const int levels = o.layer_limit + 1;
+  if (!d_frame && !d_first) return -1;
+  const ScanOf scan{d_first ? nullptr : d_frame, d_first, W};      // (d_first: the offsets of the W scans in the point list, W + 1 entries)
   Scratch sc(arena, arena_cap);
   sc.persist = mail;
   struct NeedOut { Scratch &sc; size_t *out; ~NeedOut() { *out = sc.need; } } need_out{sc, arena_need};
@@ -1270,7 +1376,7 @@ int associate_device(hipStream_t s, const float *d_xyz, const int *d_frame, cons
   // pass A: key range -> digits needed per axis
   const int rblocks = std::min(grid_for(n, B), RANGE_BLOCKS);
   std::vector<int> h_rows((size_t)RANGE_ROW * rblocks);
-  hipLaunchKernelGGL(k_vox_range, dim3(rblocks), dim3(B), 0, s, d_xyz, d_frame, d_poses, n, W, o.voxel_size, range);
+  hipLaunchKernelGGL(k_vox_range, dim3(rblocks), dim3(B), 0, s, d_xyz, scan, d_poses, n, W, o.voxel_size, range);
   hipMemcpyAsync(h_rows.data(), range, h_rows.size() * sizeof(int), hipMemcpyDeviceToHost, s);
   if (hipStreamSynchronize(s) != hipSuccess) return -1;
   int h_range[6] = {1 << 30, 1 << 30, 1 << 30, -(1 << 30), -(1 << 30), -(1 << 30)};
@@ -1311,14 +1417,14 @@ int associate_device(hipStream_t s, const float *d_xyz, const int *d_frame, cons
   if (fast_keys) {
     tag = sc.get<unsigned short>(n); tags = sc.get<unsigned short>(n);
     if (!sc.ok) return -1;
-    hipLaunchKernelGGL((k_vox_keys_tag<unsigned int>), dim3(grid_for(n, B)), dim3(B), 0, s, d_xyz, d_frame, d_poses, n, o.voxel_size, kp,
+    hipLaunchKernelGGL((k_vox_keys_tag<unsigned int>), dim3(grid_for(n, B)), dim3(B), 0, s, d_xyz, scan, d_poses, n, o.voxel_size, kp,
                        (unsigned int *)k0, idx0, tag);
     sort_pairs(sc, s, (unsigned int *)k0, (unsigned int *)k0s, idx0, idx0s, n, key_bits);
     scan_heads(sc, s, (const unsigned int *)k0s, 0, rootid, n);
   } else {
     auto root_keys = [&](auto *ka, auto *kb) {     // 32-bit radix keys whenever the packed key fits
       using K = std::remove_pointer_t<decltype(ka)>;
-      hipLaunchKernelGGL((k_vox_keys<K>), dim3(grid_for(n, B)), dim3(B), 0, s, d_xyz, d_frame, d_poses, n, o.voxel_size, kp, ka, val);
+      hipLaunchKernelGGL((k_vox_keys<K>), dim3(grid_for(n, B)), dim3(B), 0, s, d_xyz, scan, d_poses, n, o.voxel_size, kp, ka, val);
       sort_pairs(sc, s, ka, kb, val, vals, n, key_bits);
       scan_heads(sc, s, (const K *)kb, 0, rootid, n);
     };
@@ -1333,39 +1439,61 @@ int associate_device(hipStream_t s, const float *d_xyz, const int *d_frame, cons
 
   // everything of a level behind its sorted list: cks = the composite keys in list order (32- or 64-bit), idxL = the points' indices
   // in list order (NULL when nobody needs them), recL = the records in list order (fast path) or NULL (gather through idxL)
-  auto finish_level = [&](int L, bool narrow, const void *cks_, const unsigned int *idxL_, const uint4 *recL) -> int {
-    Level &v = lv[L];
+  // nL = entries of the level's list: all n points, or (fast path, levels 1 and 2) the points of the split roots only
+  // Three phases, so that levels whose lists exist together (the fast path's levels 1 and 2) can share the two counts the host has to
+  // read per level -- segments, then nodes -- in ONE mailbox round trip each:
+  //   level_scan      segment ranks of the list's entries (inclusive scan of the head flags) -> st.incl; the count is its last entry
+  //   level_segments  the segments' keys, starts and clusters; node ranks of the segments -> st.nid (the node count is its last entry)
+  //   level_nodes     node tables, totals, plane tests
+  struct LevelStage {
+    long nL = 0; bool narrow = true; const void *cks = nullptr; const unsigned int *idx = nullptr; const uint4 *rec = nullptr;
+    unsigned int *incl = nullptr, *seg_start = nullptr, *nid = nullptr, *pid = nullptr; double *seg_world = nullptr;
+  } stage[3];
+  auto level_scan = [&](int L, long nL, bool narrow, const void *cks_, const unsigned int *idxL_, const uint4 *recL, unsigned int *incl_) -> int {
+    LevelStage &st = stage[L];
+    st.nL = nL; st.narrow = narrow; st.cks = cks_; st.idx = idxL_; st.rec = recL; st.incl = incl_;
     // (rocprim::select on the head flags -- the run starts compacted in one pass, no ranks -- was measured too: 147 us per level on the
     //  shipped window against ~100 for this scan + k_seg_heads)
-    if (narrow) scan_heads(sc, s, (const unsigned int *)cks_, 0, incl, n);
-    else scan_heads(sc, s, (const unsigned long long *)cks_, 0, incl, n);
-    if (!sc.ok) return -1;
-    v.NS = last_u32(s, incl, n, mail);
-    auto *seg_start = sc.get<unsigned int>(v.NS + 1);
+    if (narrow) scan_heads(sc, s, (const unsigned int *)cks_, 0, st.incl, nL);
+    else scan_heads(sc, s, (const unsigned long long *)cks_, 0, st.incl, nL);
+    return sc.ok ? 0 : -1;
+  };
+  auto level_segments = [&](int L, long NS) -> int {
+    Level &v = lv[L];
+    LevelStage &st = stage[L];
+    const long nL = st.nL;
+    v.NS = NS;
+    st.seg_start = sc.get<unsigned int>(v.NS + 1);
     v.seg_ck = sc.get<unsigned long long>(v.NS);
     v.seg_body = sc.get<double>((size_t)v.NS * 10);
-    auto *seg_world = sc.get<double>((size_t)v.NS * 10);
-    auto *nid = sc.get<unsigned int>(v.NS), *pid = sc.get<unsigned int>(v.NS);
-    v.seg_node = nid;
+    st.seg_world = sc.get<double>((size_t)v.NS * 10);
+    st.nid = sc.get<unsigned int>(v.NS); st.pid = sc.get<unsigned int>(v.NS);
+    v.seg_node = st.nid;
     if (!sc.ok) return -1;
-    if (narrow)
-      hipLaunchKernelGGL((k_seg_heads<unsigned int>), dim3(grid_for(n, B)), dim3(B), 0, s, (const unsigned int *)cks_, incl, n, L,
-                         fb, seg_start, v.seg_ck);
+    if (st.narrow)
+      hipLaunchKernelGGL((k_seg_heads<unsigned int>), dim3(grid_for(nL, B)), dim3(B), 0, s, (const unsigned int *)st.cks, st.incl, nL, L,
+                         fb, st.seg_start, v.seg_ck);
     else
-      hipLaunchKernelGGL((k_seg_heads<unsigned long long>), dim3(grid_for(n, B)), dim3(B), 0, s, (const unsigned long long *)cks_, incl, n, L, fb,
-                         seg_start, v.seg_ck);
-    hipLaunchKernelGGL(k_set_u32, dim3(1), dim3(1), 0, s, seg_start + v.NS, (unsigned int)n);
-    if (recL) {
+      hipLaunchKernelGGL((k_seg_heads<unsigned long long>), dim3(grid_for(nL, B)), dim3(B), 0, s, (const unsigned long long *)st.cks, st.incl, nL, L, fb,
+                         st.seg_start, v.seg_ck);
+    hipLaunchKernelGGL(k_set_u32, dim3(1), dim3(1), 0, s, st.seg_start + v.NS, (unsigned int)nL);
+    if (st.rec) {
       auto *lists = sc.get<unsigned int>(4 + 8 * (size_t)v.NS);
       if (!sc.ok) return -1;
-      launch_seg_clusters_rec(s, recL, d_poses, seg_start, v.seg_ck, v.NS, v.seg_body, seg_world, lists);
+      launch_seg_clusters_rec(s, st.rec, d_poses, st.seg_start, v.seg_ck, v.NS, v.seg_body, st.seg_world, lists);
     }
-    else launch_seg_clusters(s, d_xyz, d_poses, idxL_, seg_start, v.seg_ck, v.NS, v.seg_body, seg_world);
-    scan_heads(sc, s, (const unsigned long long *)v.seg_ck, 9, nid, v.NS);
-    const int pshift = L == 0 ? 0 : (L == 1 ? 15 : 12);
-    if (L > 0) scan_heads(sc, s, (const unsigned long long *)v.seg_ck, pshift, pid, v.NS);
-    if (!sc.ok) return -1;
-    v.NN = last_u32(s, nid, v.NS, mail);
+    else launch_seg_clusters(s, d_xyz, d_poses, st.idx, st.seg_start, v.seg_ck, v.NS, v.seg_body, st.seg_world);
+    scan_heads(sc, s, (const unsigned long long *)v.seg_ck, 9, st.nid, v.NS);
+    // a node's parent: level 1 -> its root voxel, whose index the key carries (the compact level lists hold the split roots only:
+    // a rank among THEM is not a root index); level 2 -> the level-1 node = the rank of its (root, octant) prefix, which both lists share
+    if (L == 2) scan_heads(sc, s, (const unsigned long long *)v.seg_ck, 12, st.pid, v.NS);
+    return sc.ok ? 0 : -1;
+  };
+  auto level_nodes = [&](int L, long NN) -> int {
+    Level &v = lv[L];
+    LevelStage &st = stage[L];
+    const int pshift = L == 2 ? 12 : 0;
+    v.NN = NN;
     v.node_seg = sc.get<unsigned int>(v.NN + 1);
     v.node_parent = sc.get<unsigned int>(v.NN);
     v.tot = sc.get<NodeTot>(v.NN);
@@ -1374,48 +1502,72 @@ int associate_device(hipStream_t s, const float *d_xyz, const int *d_frame, cons
     v.fid = sc.get<unsigned int>(v.NN + 1);
     double *plane = strict ? sc.get<double>((size_t)v.NN * 6) : nullptr;
     if (!sc.ok) return -1;
-    hipLaunchKernelGGL(k_level_heads, dim3(grid_for(v.NS, B)), dim3(B), 0, s, v.seg_ck, nid, pid, v.NS, pshift, v.node_seg,
+    hipLaunchKernelGGL(k_level_heads, dim3(grid_for(v.NS, B)), dim3(B), 0, s, v.seg_ck, st.nid, st.pid, v.NS, pshift, v.node_seg,
                        v.node_parent);
     hipLaunchKernelGGL(k_set_u32, dim3(1), dim3(1), 0, s, v.node_seg + v.NN, (unsigned int)v.NS);
-    hipLaunchKernelGGL(k_node_totals, dim3(grid_for(v.NN * 16, B)), dim3(B), 0, s, seg_world, v.seg_ck, v.node_seg, v.NN,
+    hipLaunchKernelGGL(k_node_totals, dim3(grid_for(v.NN * 16, B)), dim3(B), 0, s, st.seg_world, v.seg_ck, v.node_seg, v.NN,
                        o.fix_frames, v.tot);
     hipLaunchKernelGGL(k_node_status, dim3(grid_for(v.NN, 128)), dim3(128), 0, s, v.tot, v.NN, pr.thr[L], pr, v.status, plane);
     if (strict && o.max_dis > 0)
-      hipLaunchKernelGGL(k_point_plane_dist, dim3(grid_for(n, B)), dim3(B), 0, s, d_xyz, d_frame, d_poses, idxL_, incl, nid, n, plane,
+      hipLaunchKernelGGL(k_point_plane_dist, dim3(grid_for(st.nL, B)), dim3(B), 0, s, d_xyz, scan, d_poses, st.idx, st.incl, st.nid, st.nL, plane,
                          o.max_dis, v.status);
-    if (want_points) hipLaunchKernelGGL(k_point_nodes, dim3(grid_for(n, B)), dim3(B), 0, s, idxL_, incl, nid, n, pnode[L]);
+    if (want_points) hipLaunchKernelGGL(k_point_nodes, dim3(grid_for(st.nL, B)), dim3(B), 0, s, st.idx, st.incl, st.nid, st.nL, pnode[L]);
     hipMemsetAsync(v.flag + v.NN, 0, sizeof(unsigned int), s);
     return 0;
+  };
+  // one level on its own: scan, count, segments, count, nodes (nn_known > 0: the node count is known -- level 0's nodes ARE the roots)
+  auto finish_level = [&](int L, long nL, bool narrow, const void *cks_, const unsigned int *idxL_, const uint4 *recL, long nn_known = 0) -> int {
+    if (level_scan(L, nL, narrow, cks_, idxL_, recL, incl)) return -1;
+    if (level_segments(L, last_u32(s, incl, nL, mail))) return -1;
+    return level_nodes(L, nn_known > 0 ? nn_known : (long)last_u32(s, stage[L].nid, lv[L].NS, mail));
   };
 
   if (fast) {
     const bool need_idx = want_points || (strict && o.max_dis > 0);       // who still wants the points' original indices per level
     auto *rec0 = sc.get<uint4>(n);
     auto *ck0 = (unsigned int *)cks;
-    auto *root_start = sc.get<unsigned int>(NR + 1), *tiles = sc.get<unsigned int>(NR + 1), *tile_base = sc.get<unsigned int>(NR + 1);
+    auto *root_start = sc.get<unsigned int>(NR + 1), *live_start = sc.get<unsigned int>(NR + 1), *tile_base = sc.get<unsigned int>(NR + 1);
+    auto *plan = sc.get<unsigned int>(4);
     if (!sc.ok) return -1;
     hipLaunchKernelGGL(k_gather_records, dim3(grid_for(n, B)), dim3(B), 0, s, d_xyz, tag, idx0s, rootid, n, fb, rec0, ck0, tags);
-    uint4 *rec1 = nullptr, *rec2 = nullptr;
-    unsigned int *ck1 = nullptr, *ck2 = nullptr, *idx1 = nullptr, *idx2 = nullptr;
+    if (levels > 1) hipLaunchKernelGGL(k_root_starts, dim3(grid_for(n, B)), dim3(B), 0, s, (const unsigned int *)k0s, rootid, n, NR, root_start);
+    if (finish_level(0, n, true, ck0, idx0s, rec0, NR)) return -1;          // (ck0 numbers the roots 0 .. NR - 1: level 0 has NR nodes)
     if (levels > 1) {
-      hipLaunchKernelGGL(k_root_starts, dim3(grid_for(n, B)), dim3(B), 0, s, (const unsigned int *)k0s, rootid, n, NR, root_start);
-      hipLaunchKernelGGL(k_root_tiles, dim3(grid_for(NR + 1, B)), dim3(B), 0, s, root_start, NR, tiles);
-      scan_excl(sc, s, tiles, tile_base, NR + 1);
-      if (!sc.ok) return -1;
-      const long NT = last_u32(s, tile_base, NR + 1, mail);
-      auto *hist = sc.get<unsigned int>((size_t)NT * 64), *off1 = sc.get<unsigned int>((size_t)NT * 8), *off2 = sc.get<unsigned int>((size_t)NT * 64);
-      rec1 = sc.get<uint4>(n); ck1 = sc.get<unsigned int>(n);
-      if (levels > 2) { rec2 = sc.get<uint4>(n); ck2 = sc.get<unsigned int>(n); }
-      if (need_idx) { idx1 = sc.get<unsigned int>(n); if (levels > 2) idx2 = sc.get<unsigned int>(n); }
-      if (!sc.ok) return -1;
-      hipLaunchKernelGGL(k_part_hist, dim3((unsigned int)NT), dim3(256), 0, s, tags, root_start, tile_base, (int)NR, hist);
-      hipLaunchKernelGGL(k_part_offsets, dim3((unsigned int)NR), dim3(64), 0, s, hist, root_start, tile_base, (int)NR, off1, off2);
-      hipLaunchKernelGGL(k_part_scatter, dim3((unsigned int)NT), dim3(256), 0, s, rec0, idx0s, root_start, tile_base, (int)NR, off1, off2, fb,
-                         levels, rec1, ck1, idx1, rec2, ck2, idx2);
+      // levels 1 and 2 for the points of the roots recut splits (status NODE_SPLIT, known now), in compact lists
+      if (want_points) for (int L = 1; L < levels; L++) hipMemsetAsync(pnode[L], 0xff, (size_t)n * sizeof(unsigned int), s);
+      hipLaunchKernelGGL(k_live_plan, dim3(1), dim3(1024), 0, s, root_start, lv[0].status, NR, tile_base, live_start, plan);
+      const unsigned int *src[4] = {plan, plan + 1, plan, plan};
+      unsigned int got[4] = {0, 0, 0, 0};
+      if (!mail_u32x4(s, mail, src, got)) return -1;
+      const long NT = got[0], n_live = got[1];
+      if (n_live > 0) {
+        auto *hist = sc.get<unsigned int>((size_t)NT * 64), *off1 = sc.get<unsigned int>((size_t)NT * 8), *off2 = sc.get<unsigned int>((size_t)NT * 64);
+        uint4 *rec1 = sc.get<uint4>(n_live), *rec2 = nullptr;
+        unsigned int *ck1 = sc.get<unsigned int>(n_live), *ck2 = nullptr, *idx1 = nullptr, *idx2 = nullptr;
+        if (levels > 2) { rec2 = sc.get<uint4>(n_live); ck2 = sc.get<unsigned int>(n_live); }
+        if (need_idx) { idx1 = sc.get<unsigned int>(n_live); if (levels > 2) idx2 = sc.get<unsigned int>(n_live); }
+        if (!sc.ok) return -1;
+        hipLaunchKernelGGL(k_part_hist, dim3((unsigned int)NT), dim3(256), 0, s, tags, root_start, tile_base, (int)NR, hist);
+        hipLaunchKernelGGL(k_part_offsets, dim3((unsigned int)NR), dim3(64), 0, s, hist, live_start, tile_base, (int)NR, off1, off2);
+        hipLaunchKernelGGL(k_part_scatter, dim3((unsigned int)NT), dim3(256), 0, s, rec0, idx0s, root_start, tile_base, (int)NR, off1, off2, fb,
+                           levels, rec1, ck1, idx1, rec2, ck2, idx2);
+        if (levels == 2) {
+          if (finish_level(1, n_live, true, ck1, idx1, rec1)) return -1;
+        } else {                                   // both lists exist: their counts travel together
+          auto *incl2 = sc.get<unsigned int>(n_live);
+          if (!sc.ok) return -1;
+          if (level_scan(1, n_live, true, ck1, idx1, rec1, incl) || level_scan(2, n_live, true, ck2, idx2, rec2, incl2)) return -1;
+          const unsigned int *ns_src[4] = {incl + n_live - 1, incl2 + n_live - 1, incl, incl};
+          unsigned int ns[4] = {0, 0, 0, 0};
+          if (!mail_u32x4(s, mail, ns_src, ns)) return -1;
+          if (level_segments(1, ns[0]) || level_segments(2, ns[1])) return -1;
+          const unsigned int *nn_src[4] = {stage[1].nid + ns[0] - 1, stage[2].nid + ns[1] - 1, incl, incl};
+          unsigned int nn[4] = {0, 0, 0, 0};
+          if (!mail_u32x4(s, mail, nn_src, nn)) return -1;
+          if (level_nodes(1, nn[0]) || level_nodes(2, nn[1])) return -1;
+        }
+      }
     }
-    if (finish_level(0, true, ck0, idx0s, rec0)) return -1;
-    if (levels > 1 && finish_level(1, true, ck1, idx1, rec1)) return -1;
-    if (levels > 2 && finish_level(2, true, ck2, idx2, rec2)) return -1;
   } else {
     if (fast_keys) {          // the root sort ran on (key, index): the sorted path's 64-bit values from the tags
       hipLaunchKernelGGL(k_vals_from_tags, dim3(grid_for(n, B)), dim3(B), 0, s, idx0s, tag, n, k0);
@@ -1439,18 +1591,30 @@ int associate_device(hipStream_t s, const float *d_xyz, const int *d_frame, cons
       const bool narrow = key_bits_L <= 32;
       if (narrow) level_keys((unsigned int *)k0, (unsigned int *)cks);
       else level_keys(k0, cks);
-      if (finish_level(L, narrow, cks, idxL, nullptr)) return -1;
+      if (finish_level(L, n, narrow, cks, idxL, nullptr)) return -1;
     }
   }
   if (lv[0].NN != NR) return -1;
   unsigned int FL[3] = {0, 0, 0};
   for (int L = 0; L < levels; L++) {
+    if (lv[L].NN == 0) continue;                  // (the fast path's levels 1 and 2 when no root was split)
     hipLaunchKernelGGL(k_feature_flags, dim3(grid_for(lv[L].NN, B)), dim3(B), 0, s, L, lv[L].NN, lv[L].tot, lv[0].status,
                        lv[1].status, lv[2].status, lv[1].node_parent, lv[2].node_parent, pr, lv[L].flag);
     scan_excl(sc, s, lv[L].flag, lv[L].fid, lv[L].NN + 1);
   }
   if (!sc.ok) return -1;
-  for (int L = 0; L < levels; L++) FL[L] = last_u32(s, lv[L].fid, lv[L].NN + 1, mail);
+  {
+    const unsigned int *src[4] = {nullptr, nullptr, nullptr, nullptr};
+    int live_levels = 0;
+    for (int L = 0; L < levels; L++) if (lv[L].NN > 0) { src[L] = lv[L].fid + lv[L].NN; live_levels++; }
+    if (live_levels > 0) {
+      const unsigned int *any = src[0] ? src[0] : (src[1] ? src[1] : src[2]);
+      for (int k = 0; k < 4; k++) if (!src[k]) src[k] = any;
+      unsigned int got[4] = {0, 0, 0, 0};
+      if (!mail_u32x4(s, mail, src, got)) return -1;
+      for (int L = 0; L < levels; L++) if (lv[L].NN > 0) FL[L] = got[L];
+    }
+  }
   const long F = (long)FL[0] + FL[1] + FL[2];
   *n_roots = NR;
   if (hipGetLastError() != hipSuccess) return -1;
@@ -1480,6 +1644,7 @@ int associate_device(hipStream_t s, const float *d_xyz, const int *d_frame, cons
   hipMemsetAsync(out, 0, (size_t)F * Wout * 10 * sizeof(double), s);
   unsigned int base[3] = {0, FL[0], FL[0] + FL[1]};
   for (int L = 0; L < levels; L++) {
+    if (lv[L].NN == 0 || FL[L] == 0) continue;
     hipLaunchKernelGGL(k_emit_segments, dim3(grid_for(lv[L].NS * 16, B)), dim3(B), 0, s, lv[L].NS, lv[L].seg_node, lv[L].flag,
                        lv[L].fid, base[L], lv[L].seg_ck, lv[L].seg_body, Wout, o.fix_frames, out);
     hipLaunchKernelGGL(k_emit_nodes, dim3(grid_for(lv[L].NN * 16, B)), dim3(B), 0, s, lv[L].NN, lv[L].flag, lv[L].fid, base[L],
