@@ -63,13 +63,6 @@ struct ScanOf {
   const int *frame;
   const long *first;
   int m;
-  static constexpr int MAX_SCANS = 512;                         // (associate_device refuses more)
-  // the offsets into LDS: the searches below are chains of dependent loads (from HBM: k_vox_range 78 -> 125 us)
-  __device__ __forceinline__ void stage(long *tbl) const {
-    if (frame) return;
-    for (int t = threadIdx.x; t <= m; t += blockDim.x) tbl[t] = first[t];
-    __syncthreads();
-  }
   __device__ __forceinline__ int find(long p, const long *tbl) const {           // p < first[m]; tbl = first, or its LDS copy
     if (frame) return frame[p];
     int lo = 0, hi = m;
@@ -107,34 +100,50 @@ __global__ __launch_bounds__(256) void k_vox_range(const float *__restrict__ xyz
                                                    const double *__restrict__ poses, long n, int W, double vs,
                                                    int *__restrict__ range /* [gridDim.x][RANGE_ROW] */) {
   const int *__restrict__ frame = scan.frame;
-  __shared__ long s_first[ScanOf::MAX_SCANS + 1];
-  scan.stage(s_first);
   __shared__ int red[4][RANGE_ROW];
   int lo[3] = {1 << 30, 1 << 30, 1 << 30}, hi[3] = {-(1 << 30), -(1 << 30), -(1 << 30)};
   int bad = 0;
   // RANGE_U points per trip, their loads issued together, on up to 2 048 blocks (a full complement of resident wavefronts): with one point
   // per trip on 1 024 blocks the pass had 5 MB in flight and ran at 2.3 TB/s -- latency-bound (94 us for the shipped window's 215 MB).
+  // A workgroup walks ONE contiguous stretch of the points (round 6): with the scans given by their offsets the scan of the stretch's first
+  // point is searched once and the next four scan boundaries sit in LDS -- a point's scan is four compares, no dependent load.
   constexpr int RANGE_U = 4;
-  const long stride = (long)gridDim.x * blockDim.x;
-  int fcur = 0;                  // (offsets: the thread's points ascend, so does their scan)
-  if (!frame && (long)blockIdx.x * blockDim.x + threadIdx.x < n) fcur = scan.find((long)blockIdx.x * blockDim.x + threadIdx.x, s_first);
-  for (long p0 = (long)blockIdx.x * blockDim.x + threadIdx.x; p0 < n; p0 += RANGE_U * stride) {
+  const long per = (n + gridDim.x - 1) / gridDim.x, beg = (long)blockIdx.x * per, end = min(n, beg + per);
+  __shared__ int s_f0;
+  __shared__ long s_b[4];
+  if (!frame) {
+    if (threadIdx.x == 0 && beg < end) {
+      const int f0 = scan.find(beg, scan.first);
+      s_f0 = f0;
+      for (int j = 0; j < 4; j++) s_b[j] = scan.first[min(f0 + 1 + j, scan.m)];
+    }
+    __syncthreads();
+  }
+  for (long p0 = beg + threadIdx.x; p0 < end; p0 += RANGE_U * (long)blockDim.x) {
     long pp[RANGE_U];
     int frv[RANGE_U], frp[RANGE_U];
     float xv[RANGE_U][3];
 #pragma unroll
-    for (int u = 0; u < RANGE_U; u++) pp[u] = p0 + u * stride;
+    for (int u = 0; u < RANGE_U; u++) pp[u] = p0 + u * (long)blockDim.x;
 #pragma unroll
     for (int u = 0; u < RANGE_U; u++) {
-      const bool in = pp[u] < n;
+      const bool in = pp[u] < end;
       const long p = in ? pp[u] : p0;
       if (frame) { frv[u] = frame[p]; frp[u] = p > 0 ? frame[p - 1] : frv[u]; }
-      else { fcur = scan.advance(fcur, p, s_first); frv[u] = frp[u] = fcur; }
       xv[u][0] = xyz[3 * p]; xv[u][1] = xyz[3 * p + 1]; xv[u][2] = xyz[3 * p + 2];
+    }
+    if (!frame) {
+#pragma unroll
+      for (int u = 0; u < RANGE_U; u++) {
+        const long p = pp[u] < end ? pp[u] : p0;
+        int fr = s_f0 + (p >= s_b[0] ? 1 : 0) + (p >= s_b[1] ? 1 : 0) + (p >= s_b[2] ? 1 : 0) + (p >= s_b[3] ? 1 : 0);
+        if (p >= s_b[3]) fr = scan.advance(fr, p, scan.first);      // (empty or tiny scans: walk on)
+        frv[u] = frp[u] = min(fr, scan.m - 1);
+      }
     }
 #pragma unroll
     for (int u = 0; u < RANGE_U; u++) {
-      if (pp[u] >= n) continue;
+      if (pp[u] >= end) continue;
       const int fr = frv[u];
       if (frp[u] > fr) bad |= 2;                              // not in scan order: the level sorts must sort the scan bits too
       if (fr < 0 || fr >= W) { bad |= 1; continue; }
@@ -388,14 +397,25 @@ __global__ __launch_bounds__(256) void k_vox_keys_tag(const float *__restrict__ 
   // offsets: the scan of the workgroup's first point is found once (one thread, nine dependent loads that hit the cache: every
   // workgroup reads the same 1.4 KB); the others step on from it -- a point's scan is almost always its workgroup's first point's
   __shared__ int s_f0;
+  __shared__ long s_b[2];        // where the next two scans begin: a workgroup's 256 points rarely reach past them
   if (!scan.frame) {
-    if (threadIdx.x == 0) s_f0 = scan.find(min((long)blockIdx.x * blockDim.x, n - 1), scan.first);
+    if (threadIdx.x == 0) {
+      const int f0 = scan.find(min((long)blockIdx.x * blockDim.x, n - 1), scan.first);
+      s_f0 = f0;
+      s_b[0] = scan.first[min(f0 + 1, scan.m)]; s_b[1] = scan.first[min(f0 + 2, scan.m)];
+    }
     __syncthreads();
   }
   const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= n) return;
   double q[3], po[3];
-  const int fr = scan.frame ? scan.frame[p] : scan.advance(s_f0, p, scan.first);
+  int fr;
+  if (scan.frame) fr = scan.frame[p];
+  else {
+    fr = s_f0 + (p >= s_b[0] ? 1 : 0) + (p >= s_b[1] ? 1 : 0);
+    if (p >= s_b[1]) fr = scan.advance(fr, p, scan.first);       // (empty or tiny scans: walk on)
+    fr = min(fr, scan.m - 1);
+  }
   world_point(xyz, poses + 12 * (long)fr, p, q, po);
   const float q1 = (float)(vs / 4.0);
   unsigned long long key = 0;
