@@ -24,7 +24,7 @@ EXPORTS = ["balm_create", "balm_prewarm", "balm_create_multi", "balm_destroy", "
            "balm_solve_damped", "balm_damping_iter", "balm_build_clusters", "balm_build_clusters_planes", "balm_voxel_defaults", "balm_associate", "balm_associate_scans", "balm_get_features", "balm_get_association", "balm_pose_covariance",
            "balm_window_open", "balm_window_add_scan", "balm_window_add_scan_strided", "balm_window_recut", "balm_window_get_points", "balm_window_features", "balm_window_marginalize", "balm_window_info", "balm_window_close",
            "balm_set_allreduce", "balm_comm_unique_id", "balm_comm_init_rank", "balm_comm_info",
-           "balm_get_timing", "balm_get_solve_trace", "balm_chain_macro_plan", "balm_reset_timing", "balm_work_model", "balm_last_error", "balm_version", "balm_abi_version"]
+           "balm_get_timing", "balm_get_shard_timing", "balm_get_solve_trace", "balm_chain_macro_plan", "balm_reset_timing", "balm_work_model", "balm_last_error", "balm_version", "balm_abi_version"]
 
 
 class IterLog(C.Structure):
@@ -112,6 +112,7 @@ def lib():
         L.balm_comm_init_rank.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.balm_comm_info.argtypes = [C.c_void_p, C.c_void_p]
         L.balm_get_timing.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.balm_get_shard_timing.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.balm_get_solve_trace.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_void_p]
         L.balm_chain_macro_plan.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_long]
         L.balm_reset_timing.argtypes = [C.c_void_p]
@@ -460,6 +461,13 @@ class Context:
         ms = np.zeros(T_COUNT)
         cnt = np.zeros(T_COUNT, dtype=np.int64)
         self._check(self.L.balm_get_timing(self.h, _p(ms), _p(cnt)))
+        return {TIMING_NAMES[k]: (float(ms[k]), int(cnt[k])) for k in range(T_COUNT)}
+
+    def shard_timing(self, shard):
+        """balm_get_shard_timing: the timers of ONE device of a multi-device context"""
+        ms = np.zeros(T_COUNT)
+        cnt = np.zeros(T_COUNT, dtype=np.int64)
+        self._check(self.L.balm_get_shard_timing(self.h, int(shard), _p(ms), _p(cnt)))
         return {TIMING_NAMES[k]: (float(ms[k]), int(cnt[k])) for k in range(T_COUNT)}
 
     def solve_trace(self):

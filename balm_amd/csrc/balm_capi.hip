@@ -84,7 +84,11 @@ static void adopt_warm_ring(balm_ctx *ctx) {
   std::lock_guard<std::mutex> lk(w.mu);
   if (!w.started) return;
   if (w.th.joinable()) w.th.join();
-  if (w.ring_ready.load(std::memory_order_acquire)) { ctx->ring = w.ring; w.ring = PinnedRing(); w.ring_ready.store(false); }
+  if (w.ring_ready.load(std::memory_order_acquire)) {
+    const int key = ctx->ring.pool_key;
+    ctx->ring = w.ring; ctx->ring.pool_key = key;
+    w.ring = PinnedRing(); w.ring_ready.store(false);
+  }
 }
 
 // ---- timing ------------------------------------------------------------------------------------
@@ -704,9 +708,11 @@ static int assoc_clusters_host(balm_ctx *ctx);
 // while it is hot in the filling thread's cache.
 using FillClusters = std::function<void(int, int, double *, unsigned char *)>;      // (f0, f1, dst, obs of those features: W bytes each)
 
-static int one_set_features_fn(balm_ctx *ctx, int F, const FillClusters &fill, const double *fix, const double *coeffs) {
+// shard_books: a device of a multi context keeps ITS share of the bookkeeping (planes per pose, work model) -- the shards were cut
+// before any table existed on the host (balm_set_features_cb, balm_build_clusters*); the LM loop's precheck sums the shares
+static int one_set_features_fn(balm_ctx *ctx, int F, const FillClusters &fill, const double *fix, const double *coeffs, bool shard_books = false) {
   if (!ctx) return BALM_ERR_ARG;
-  if (ctx->multi && F == 0) { ctx->F = 0; ctx->feat_cur_valid = false; ctx->gt_cur_valid = false; return BALM_OK; }      // a shard without features
+  if (ctx->multi && F == 0) { ctx->F = 0; ctx->feat_cur_valid = false; ctx->gt_cur_valid = false; ctx->planes_per_pose.clear(); ctx->work_S = ctx->work_B = 0; return BALM_OK; }      // a shard without features
   if (F < 1 || !fill || !coeffs) { ctx->err = "balm_set_features: bad argument"; return BALM_ERR_ARG; }
   HIP_TRY(hipSetDevice(ctx->device));
   const int W = ctx->W;
@@ -731,7 +737,7 @@ static int one_set_features_fn(balm_ctx *ctx, int F, const FillClusters &fill, c
   if (e == hipSuccess) launch_transpose_clusters(ctx->stream, d_aos, ctx->d_cl, F, W);
   HIP_TRY(e);
   // (the host's bookkeeping runs beside the last DMAs and the transpose)
-  if (!ctx->multi && (rc = feature_bookkeeping(ctx, F, obs.data(), fix, coeffs))) { hipStreamSynchronize(ctx->stream); return rc; }    // sharded: done once on the whole table
+  if ((!ctx->multi || shard_books) && (rc = feature_bookkeeping(ctx, F, obs.data(), fix, coeffs))) { hipStreamSynchronize(ctx->stream); return rc; }    // (balm_set_features on a sharded context: done once on the whole table)
   if ((rc = build_sparse_plan(ctx, F, obs.data()))) { hipStreamSynchronize(ctx->stream); return rc; }
   if ((rc = install_feature_buffers(ctx, F, fix, coeffs))) { hipStreamSynchronize(ctx->stream); return rc; }
   return sync_stream(ctx);
@@ -751,8 +757,10 @@ static int one_set_features(balm_ctx *ctx, int F, const double *clusters, const 
 // The caller's points of balm_build_clusters: flat arrays (xyz, feat_id, pose_id), or `planes` = its own per-plane containers
 // (balm_build_clusters_planes: element stride + the byte offset of the float that holds the observing pose), which the pool
 // packs into 16-byte records and the device expands.
+// feat_base: the caller's feature index of this context's feature 0 (a shard of a multi context builds ITS features from its stretch
+// of the caller's points: the ids are rebased on the device).
 static int one_build_clusters(balm_ctx *ctx, int F, const float *xyz, const int *feat_id, const int *pose_id, long n_pts,
-                        const double *fix, const double *coeffs, double *clusters_out, const StridedPoints *planes = nullptr) {
+                        const double *fix, const double *coeffs, double *clusters_out, const StridedPoints *planes = nullptr, int feat_base = 0) {
   if (!ctx) return BALM_ERR_ARG;
   if (planes) n_pts = planes->total();
   if (F < 1 || n_pts < 0 || (!planes && (!xyz || !feat_id || !pose_id)) || !coeffs || (planes && planes->n != F)) {
@@ -791,6 +799,7 @@ static int one_build_clusters(balm_ctx *ctx, int F, const float *xyz, const int 
     if (e == hipSuccess) e = staged_copy(ctx->ring, ctx->device, ctx->stream, d_xyz, xyz, (size_t)n_pts * 3 * sizeof(float));
     if (e == hipSuccess) e = staged_copy(ctx->ring, ctx->device, ctx->stream, d_f, feat_id, (size_t)n_pts * sizeof(int));
     if (e == hipSuccess) e = staged_copy(ctx->ring, ctx->device, ctx->stream, d_p, pose_id, (size_t)n_pts * sizeof(int));
+    if (e == hipSuccess && feat_base != 0) launch_rebase_ids(ctx->stream, d_f, n_pts, feat_base);
   }
   if (e == hipSuccess) e = hipMemsetAsync(ctx->d_cl, 0, count * sizeof(double), ctx->stream);
   int *d_flag = reinterpret_cast<int *>(ctx->d_scal + 8);           // a spare device scalar slot
@@ -1526,10 +1535,12 @@ int balm_prewarm(int device) {
 balm_ctx *balm_create_multi(int win_size, int first_device, int n_devices, int flags) {
   if (n_devices < 1 || n_devices > MAX_SHARDS) return nullptr;
   const bool loopback = (flags & BALM_FLAG_LOOPBACK_SHARDS) != 0;
+  HostPool::shard_pool_threads() = n_devices > 4 ? 8 : 0;          // (pools that exist already keep their size)
   std::vector<balm_ctx *> subs;
   for (int k = 0; k < n_devices; k++) {
     balm_ctx *c = balm_create(win_size, loopback ? first_device : first_device + k, flags);
     if (!c) { for (auto *q : subs) one_destroy(q); return nullptr; }
+    c->ring.pool_key = k;            // the device threads' uploads run side by side, each with its own host pool (0 = the process's)
     subs.push_back(c);
   }
   std::string err;
@@ -1571,6 +1582,8 @@ int balm_comm_init_rank(balm_ctx *ctx, int n_ranks, int rank, const void *id128)
 static int multi_set_features(balm_ctx *ctx, balm_multi *m, int F, const double *clusters, const double *fix, const double *coeffs) {
   if (F < 1 || !clusters || !coeffs) { ctx->err = "balm_set_features: bad argument"; return BALM_ERR_ARG; }
   m->F = 0;
+  m->books_per_shard = false;
+  for (size_t k = 1; k < m->sub.size(); k++) { m->sub[k]->planes_per_pose.clear(); m->sub[k]->work_S = m->sub[k]->work_B = 0; }     // (shares of an earlier sharded install)
   const std::vector<unsigned char> obs = obs_of(clusters, F, ctx->W);
   int rc = feature_bookkeeping(ctx, F, obs.data(), fix, coeffs);
   if (rc) return rc;
@@ -1614,16 +1627,62 @@ int balm_set_features(balm_ctx *ctx, int F, const double *clusters, const double
   return one_set_features(ctx, F, clusters, fix, coeffs);
 }
 
+// contiguous shards of (about) equal cost: fbeg[k] = the first feature whose cumulated cost reaches k / n of the total
+static void multi_cut(balm_multi *m, int F, const std::vector<double> &cum /* [F + 1], cum[0] = 0 */) {
+  m->fbeg[0] = 0;
+  for (int k = 1; k < m->n; k++) {
+    const double target = cum[(size_t)F] * k / m->n;
+    int f = (int)(std::lower_bound(cum.begin(), cum.end(), target) - cum.begin());
+    if (f < m->fbeg[(size_t)k - 1]) f = m->fbeg[(size_t)k - 1];
+    if (f > F) f = F;
+    m->fbeg[(size_t)k] = f;
+  }
+  m->fbeg[(size_t)m->n] = F;
+}
+
+static int multi_done(balm_ctx *ctx, balm_multi *m, int F, int rc, const char *who) {
+  if (rc) { if (ctx->err.empty()) ctx->err = std::string(who) + ": a device failed"; for (auto *q : m->sub) if (!q->err.empty()) { ctx->err = q->err; break; } return rc; }
+  m->F = F;
+  m->books_per_shard = true;
+  return BALM_OK;
+}
+
 int balm_set_features_cb(balm_ctx *ctx, int F, balm_fill_clusters_fn fill, void *user, const double *fix, const double *coeffs) {
   if (!ctx) return BALM_ERR_ARG;
   if (F < 1 || !fill || !coeffs) { ctx->err = "balm_set_features_cb: bad argument"; return BALM_ERR_ARG; }
   if (balm_multi *m = leader_of(ctx)) {
-    // sharded: the cost-balanced cut needs every feature's observation count before any shard can be installed -- the
-    // table is flattened once (all pool threads), then cut like balm_set_features'
-    const size_t row = (size_t)ctx->W * 10;
-    std::vector<double> flat((size_t)F * row);
-    parallel_ranges((size_t)F, (size_t)(32768 / row + 1), [&](size_t lo, size_t hi) { fill(user, (int)lo, (int)hi, flat.data() + lo * row); });
-    return multi_set_features(ctx, m, F, flat.data(), fix, coeffs);
+    // Sharded, in two passes over the CALLER's table and none over a copy of it (round 5 flattened all F x W x 80 bytes into a host
+    // vector first: 3.2 GB at BASELINE configs[3]): (1) every feature's observation count, read through `fill` into a scratch row per
+    // pool thread -- the cost-balanced cut needs them before any shard can leave; (2) every device thread pulls ITS features straight
+    // into its own pinned ring, the shards side by side.
+    const size_t Wc = (size_t)ctx->W, row = Wc * 10;
+    m->F = 0;
+    std::vector<double> cum((size_t)F + 1, 0.0);
+    parallel_ranges((size_t)F, (size_t)(32768 / row + 1), [&](size_t lo, size_t hi) {
+      const size_t blk = std::max<size_t>(1, (size_t)65536 / (row * sizeof(double)));      // features per call of fill: a 64 KB scratch
+      std::vector<double> scratch(blk * row);
+      for (size_t a0 = lo; a0 < hi; a0 += blk) {
+        const size_t a1 = std::min(hi, a0 + blk);
+        fill(user, (int)a0, (int)a1, scratch.data());
+        for (size_t a = a0; a < a1; a++) {
+          int na = 0;
+          const double *r = scratch.data() + (a - a0) * row;
+          for (size_t i = 0; i < Wc; i++) na += r[i * 10 + 9] != 0 ? 1 : 0;
+          cum[a + 1] = 0.5 * na * (na + 1.0) + 4.0 * na + 1.0;
+        }
+      }
+    });
+    for (int a = 0; a < F; a++) cum[(size_t)a + 1] += cum[(size_t)a];
+    multi_cut(m, F, cum);
+    int rc = multi_run(m, [&](int k) {
+      const int f0 = m->fbeg[(size_t)k], nf = m->fbeg[(size_t)k + 1] - f0;
+      return one_set_features_fn(m->sub[(size_t)k], nf, [fill, user, Wc, f0](int a0, int a1, double *dst, unsigned char *o) {
+        fill(user, f0 + a0, f0 + a1, dst);
+        const size_t cnt = (size_t)(a1 - a0) * Wc;
+        for (size_t t = 0; t < cnt; t++) o[t] = dst[t * 10 + 9] != 0 ? 1 : 0;
+      }, fix ? fix + (size_t)f0 * 10 : nullptr, coeffs + f0, /*shard_books=*/true);
+    });
+    return multi_done(ctx, m, F, rc, "balm_set_features_cb");
   }
   const size_t Wc = (size_t)ctx->W;
   return one_set_features_fn(ctx, F, [fill, user, Wc](int f0, int f1, double *dst, unsigned char *o) {
@@ -1637,8 +1696,41 @@ int balm_build_clusters(balm_ctx *ctx, int F, const float *xyz, const int *feat_
                         const double *fix, const double *coeffs, double *clusters_out) {
   balm_multi *m = leader_of(ctx);
   if (!m) return one_build_clusters(ctx, F, xyz, feat_id, pose_id, n_pts, fix, coeffs, clusters_out);
-  // one-off stage: the first device builds the whole table, then it is sharded like any other
-  if (F < 1) { ctx->err = "balm_build_clusters: bad argument"; return BALM_ERR_ARG; }
+  if (F < 1 || n_pts < 0 || !xyz || !feat_id || !pose_id || !coeffs) { ctx->err = "balm_build_clusters: bad argument"; return BALM_ERR_ARG; }
+  // Sharded: points that arrive feature by feature (feat_id ascending -- every driver of the reference pushes them that way,
+  // benchmark_virtual.cpp:392-403) are cut into stretches of equal length at feature boundaries and every device builds ITS features
+  // from its stretch: no whole table on the first device, no download and re-upload of it (3.2 GB each way at BASELINE configs[3]).
+  {
+    std::atomic<int> bad{0};
+    parallel_ranges((size_t)n_pts, (size_t)1 << 20, [&](size_t lo, size_t hi) {
+      int prev = lo > 0 ? feat_id[lo - 1] : 0, b = 0;
+      for (size_t p = lo; p < hi; p++) { const int f = feat_id[p]; b |= (f < prev || f < 0 || f >= F) ? 1 : 0; prev = f; }
+      if (b) bad.store(1, std::memory_order_relaxed);
+    });
+    if (!bad.load() && n_pts > 0) {
+      m->F = 0;
+      std::vector<long> pbeg((size_t)m->n + 1, 0);
+      m->fbeg[0] = 0; pbeg[0] = 0;
+      for (int k = 1; k < m->n; k++) {
+        const long target = n_pts * k / m->n;
+        int f = feat_id[target];                                                  // the feature the cut falls into starts the next shard
+        if (f < m->fbeg[(size_t)k - 1]) f = m->fbeg[(size_t)k - 1];
+        m->fbeg[(size_t)k] = f;
+        pbeg[(size_t)k] = (long)(std::lower_bound(feat_id, feat_id + n_pts, f) - feat_id);
+      }
+      m->fbeg[(size_t)m->n] = F; pbeg[(size_t)m->n] = n_pts;
+      const size_t Wc = (size_t)ctx->W;
+      int rc = multi_run(m, [&](int k) {
+        const int f0 = m->fbeg[(size_t)k], nf = m->fbeg[(size_t)k + 1] - f0;
+        const long p0 = pbeg[(size_t)k], np = pbeg[(size_t)k + 1] - p0;
+        if (nf == 0) return one_set_features(m->sub[(size_t)k], 0, nullptr, nullptr, nullptr);
+        return one_build_clusters(m->sub[(size_t)k], nf, xyz + 3 * p0, feat_id + p0, pose_id + p0, np, fix ? fix + (size_t)f0 * 10 : nullptr, coeffs + f0,
+                                  clusters_out ? clusters_out + (size_t)f0 * Wc * 10 : nullptr, nullptr, f0);
+      });
+      return multi_done(ctx, m, F, rc, "balm_build_clusters");
+    }
+  }
+  // points in no feature order: the first device builds the whole table, then it is sharded like any other
   std::vector<double> host((size_t)F * ctx->W * 10);
   ctx->multi = nullptr;                               // as a plain context for this one call
   int rc = one_build_clusters(ctx, F, xyz, feat_id, pose_id, n_pts, fix, coeffs, host.data());
@@ -1688,13 +1780,22 @@ int balm_build_clusters_planes(balm_ctx *ctx, int F, const void *const *plane_po
   }
   balm_multi *m = leader_of(ctx);
   if (!m) return one_build_clusters(ctx, F, nullptr, nullptr, nullptr, 0, fix, coeffs, clusters_out, &sp);
-  std::vector<double> host((size_t)F * ctx->W * 10);
-  ctx->multi = nullptr;
-  int rc = one_build_clusters(ctx, F, nullptr, nullptr, nullptr, 0, fix, coeffs, host.data(), &sp);
-  ctx->multi = m;
-  if (rc) return rc;
-  if (clusters_out) std::memcpy(clusters_out, host.data(), host.size() * sizeof(double));
-  return multi_set_features(ctx, m, F, host.data(), fix, coeffs);
+  if (!coeffs) { ctx->err = "balm_build_clusters_planes: bad argument"; return BALM_ERR_ARG; }
+  // sharded: the planes are cut into runs of (about) equal point count and every device packs, uploads and builds ITS planes
+  m->F = 0;
+  std::vector<double> cum((size_t)F + 1, 0.0);
+  for (int a = 0; a < F; a++) cum[(size_t)a + 1] = cum[(size_t)a] + (double)plane_count[a] + 1.0;
+  multi_cut(m, F, cum);
+  const size_t Wc = (size_t)ctx->W;
+  int rc = multi_run(m, [&](int k) {
+    const int f0 = m->fbeg[(size_t)k], nf = m->fbeg[(size_t)k + 1] - f0;
+    if (nf == 0) return one_set_features(m->sub[(size_t)k], 0, nullptr, nullptr, nullptr);
+    StridedPoints part;
+    if (!part.set(nf, plane_points + f0, plane_count + f0, stride_bytes, pose_offset_bytes)) return (int)BALM_ERR_ARG;
+    return one_build_clusters(m->sub[(size_t)k], nf, nullptr, nullptr, nullptr, 0, fix ? fix + (size_t)f0 * 10 : nullptr, coeffs + f0,
+                              clusters_out ? clusters_out + (size_t)f0 * Wc * 10 : nullptr, &part);
+  });
+  return multi_done(ctx, m, F, rc, "balm_build_clusters_planes");
 }
 
 int balm_window_add_scan_strided(balm_ctx *ctx, const void *points, long n_pts, size_t stride_bytes, const double *pose12) {
@@ -1818,6 +1919,16 @@ int balm_get_timing(balm_ctx *ctx, double *ms, long *count) {
   return BALM_OK;
 }
 
+int balm_get_shard_timing(balm_ctx *ctx, int shard, double *ms, long *count) {
+  if (!ctx) return BALM_ERR_ARG;
+  balm_ctx *q = ctx;
+  if (ctx->multi) {
+    if (shard < 0 || shard >= ctx->multi->n) { ctx->err = "balm_get_shard_timing: no such shard"; return BALM_ERR_ARG; }
+    q = ctx->multi->sub[(size_t)shard];
+  } else if (shard != 0) { ctx->err = "balm_get_shard_timing: no such shard"; return BALM_ERR_ARG; }
+  return balm_get_timing(q, ms, count);
+}
+
 int balm_chain_macro_plan(int panels, int helpers, int *table, long capacity) {
   if (!table || panels < 3 || helpers < 1 || capacity < (long)helpers * 64) return BALM_ERR_ARG;
   std::vector<int> tab;
@@ -1829,6 +1940,9 @@ int balm_chain_macro_plan(int panels, int helpers, int *table, long capacity) {
 int balm_reset_timing(balm_ctx *ctx) {
   if (!ctx) return BALM_ERR_ARG;
   for (int k = 0; k < BALM_T_COUNT; k++) { ctx->timer.ms[k] = 0; ctx->timer.cnt[k] = 0; }
+  if (balm_multi *m = leader_of(ctx))                      // every device's timers (balm_get_shard_timing reads them)
+    for (size_t q = 1; q < m->sub.size(); q++)
+      for (int k = 0; k < BALM_T_COUNT; k++) { m->sub[q]->timer.ms[k] = 0; m->sub[q]->timer.cnt[k] = 0; }
   return BALM_OK;
 }
 
@@ -1837,8 +1951,12 @@ int balm_work_model(balm_ctx *ctx, double *out4) {
   const double W = ctx->W, F = ctx->multi ? ctx->multi->F : ctx->F;
   out4[0] = ctx->work_S;
   out4[1] = ctx->work_B;
+  if (ctx->multi && ctx->multi->books_per_shard) {        // the shards were cut before a table existed on the host: every device keeps its share
+    out4[0] = out4[1] = 0;
+    for (const balm_ctx *q : ctx->multi->sub) { out4[0] += q->work_S; out4[1] += q->work_B; }
+  }
   (void)W;
-  out4[2] = 216.0 * ctx->work_B;                  // 108 FMA = 216 flop per unordered OBSERVED pose pair incl. the diagonal
+  out4[2] = 216.0 * out4[1];                      // 108 FMA = 216 flop per unordered OBSERVED pose pair incl. the diagonal
                                                   // (dense scenes: 108 F W (W+1))
   SyrkPlan p = plan_syrk(ctx->ntiles, 3L * (long)F);
   out4[3] = (double)ctx->ntiles * 25.0 * 2048.0 * ((double)p.Kpad / 4.0);   // 25 MFMAs per k-step of every job

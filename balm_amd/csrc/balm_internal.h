@@ -217,6 +217,7 @@ struct balm_multi {
   std::vector<balm_ctx *> sub;
   std::vector<int> fbeg;                    // shard k holds features [fbeg[k], fbeg[k+1]) of the caller's table
   int F = 0;
+  bool books_per_shard = false;             // planes per pose / work model: every device holds its share (else: device 0 holds the whole table's)
   // device threads (device 0 is driven by the calling thread)
   std::vector<std::thread> th;
   std::mutex mu;
@@ -317,6 +318,7 @@ void launch_build_clusters(hipStream_t s, const float *xyz, const int *feat_id, 
 void launch_build_clusters_any(hipStream_t s, const float *xyz, const int *feat_id, const int *pose_id, long n_pts,
                                int F, int W, double *soa);                       // any order: atomics
 void launch_soa_to_aos(hipStream_t s, const double *soa, double *aos, int F, int W);
+void launch_rebase_ids(hipStream_t s, int *d_id, long n, int base);                              // id[p] -= base (a shard's feature ids)
 void launch_expand_ids(hipStream_t s, const long *d_first, int m, long n, int *d_id);            // container index of every point from the containers' prefix counts
 void launch_unpack_xyzw(hipStream_t s, const float *d_rec, long n, float *d_xyz, int *d_aux);    // (x, y, z, w) records -> xyz + (int)w
 void launch_obs_mask(hipStream_t s, const double *soa, int F, int W, unsigned char *mask);      // N != 0 per (feature, pose)

@@ -18,6 +18,7 @@
 #include <cstdint>
 #include <cstring>
 #include <functional>
+#include <memory>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -105,7 +106,22 @@ inline GpuNode numa_node_cpus(int node) {
 
 class HostPool {
  public:
-  static HostPool &get() { static HostPool p; return p; }
+  // Pool 0 is the process's pool.  The device threads of a one-process multi-GPU context (balm_create_multi) each get a pool of
+  // their own (key = shard index, 1 ..): their uploads run side by side, each beside ITS GPU, instead of queueing behind one another
+  // for the one pool (8 x 400 MB one shard at a time at BASELINE configs[3], VERDICT r5 Weak 3a).
+  static constexpr int MAX_POOLS = 64;
+  static HostPool &get(int key = 0) {
+    static std::mutex mu;
+    static std::unique_ptr<HostPool> pools[MAX_POOLS];
+    if (key < 0 || key >= MAX_POOLS) key = 0;
+    std::lock_guard<std::mutex> lk(mu);
+    if (!pools[key]) pools[key].reset(new HostPool(key == 0 ? 0 : shard_pool_threads()));      // (the process's pool keeps its full size)
+    return *pools[key];
+  }
+  // Threads of the pools created from now on (0 = by the host's size): balm_create_multi sets it by its device count -- sixteen
+  // fillers per device saturate one link (host_stage.h's ring geometry), eight devices' worth of them next to four GPUs' memory
+  // controllers do not fit a socket: 8 per pool from five devices on.
+  static int &shard_pool_threads() { static int n = 0; return n; }
   int workers() const { return (int)th_.size(); }
   // every pool thread (and the caller) runs fn(thread index) once; returns when all have returned.  One job at a time.
   // aff (optional): the pool threads move to these CPUs first (and stay there until a job names other ones)
@@ -123,9 +139,10 @@ class HostPool {
   }
 
  private:
-  HostPool() {
+  explicit HostPool(int want = 0) {
     unsigned hc = std::thread::hardware_concurrency();
     int n = hc >= 64 ? 15 : hc >= 16 ? 7 : hc >= 4 ? 3 : 1;      // + the calling thread
+    if (want > 0 && want - 1 < n) n = want - 1;
 #ifdef BALM_HOST_POOL_THREADS                                     // (tools/ubench_h2d.hip: the pipeline by thread count)
     n = BALM_HOST_POOL_THREADS - 1;
 #endif
@@ -136,6 +153,7 @@ class HostPool {
     cv_go_.notify_all();
     for (auto &t : th_) t.join();
   }
+  friend struct std::default_delete<HostPool>;
   void loop(int t) {
     unsigned long seen = 0;
     cpu_set_t cur_aff;
@@ -300,9 +318,9 @@ struct StridedPoints {
 };
 
 // fn(lo, hi) over [0, n) in contiguous pieces, one or a few per pool thread; serial below `grain`
-inline void parallel_ranges(size_t n, size_t grain, const std::function<void(size_t, size_t)> &fn) {
+inline void parallel_ranges(size_t n, size_t grain, const std::function<void(size_t, size_t)> &fn, int pool_key = 0) {
   if (n == 0) return;
-  HostPool &pool = HostPool::get();
+  HostPool &pool = HostPool::get(pool_key);
   if (n <= grain || pool.workers() == 0) { fn(0, n); return; }
   const size_t pieces = std::min<size_t>((n + grain - 1) / grain, (size_t)(pool.workers() + 1) * 4);
   std::atomic<size_t> next{0};
@@ -356,6 +374,7 @@ struct PinnedRing {
   hipEvent_t ev[NBUF] = {};
   bool busy[NBUF] = {};      // a DMA out of this buffer was enqueued and its event not yet waited for
 
+  int pool_key = 0;            // whose host threads fill this ring (HostPool::get)
   GpuNode node;                // the CPUs next to the device the ring feeds (invalid: unknown, nobody is pinned)
   int pos = 0;                 // buffer of the next upload's first chunk: an upload continues round the ring where the previous one stopped,
                                // so its first chunks fill buffers that are already free while the previous upload's last DMAs still run
@@ -377,7 +396,7 @@ struct PinnedRing {
         if (e != hipSuccess) { err = e; return; }
       }
     };
-    HostPool &pool = HostPool::get();
+    HostPool &pool = HostPool::get(pool_key);
     if (pool.workers() > 0) pool.run_all([&](int t) { if (t == 0) alloc(); }, &node);
     else alloc();
     if (err != hipSuccess) release();
@@ -410,7 +429,7 @@ inline hipError_t staged_upload(PinnedRing &ring, int device, hipStream_t stream
     if (e == hipSuccess) { ring.busy[b] = true; ring.pos = (b + 1) % PinnedRing::NBUF; }
     return e;
   }
-  HostPool &pool = HostPool::get();
+  HostPool &pool = HostPool::get(ring.pool_key);
   const long p0 = ring.pos;
   // Chunk plan: the first chunks are small -- 4, 8, 16 MB, then full 32 MB chunks -- so that the link starts after 4 MB have been
   // filled instead of 32 (0.4 of the 3.5 ms the shipped window's points take; the link then never waits: each DMA covers the fill of

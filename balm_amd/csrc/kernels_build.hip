@@ -318,6 +318,16 @@ void launch_expand_ids(hipStream_t s, const long *d_first, int m, long n, int *d
   hipLaunchKernelGGL(k_expand_ids, dim3((unsigned)blocks), dim3(256), lds, s, d_first, m, n, d_id);
 }
 
+__global__ __launch_bounds__(256) void k_rebase_ids(int *__restrict__ id, long n, int base) {
+  for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (long)gridDim.x * blockDim.x) id[p] -= base;
+}
+void launch_rebase_ids(hipStream_t s, int *d_id, long n, int base) {
+  if (n <= 0 || base == 0) return;
+  long blocks = (n + 1023) / 1024;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(k_rebase_ids, dim3((unsigned)blocks), dim3(256), 0, s, d_id, n, base);
+}
+
 // 16-byte records (x, y, z, w) -> packed xyz + (int)w: the (int)ap.intensity of benchmark_virtual.cpp:396, C truncation
 __global__ __launch_bounds__(256) void k_unpack_xyzw(const float4 *__restrict__ rec, long n, float *__restrict__ xyz, int *__restrict__ aux) {
   for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (long)gridDim.x * blockDim.x) {

@@ -936,12 +936,16 @@ static void launch_build_A(balm_ctx *c) {
 static void launch_factor(balm_ctx *c) {
   hipStream_t s = c->stream;
   const int nA = c->nA, P = nA / NB;
-  bool want_fused = solve_is_persistent(c);
+  // The layout of d_A was decided ONCE for this solve, by launch_solve (c->solve_tiled = solve_wants_backsub at that moment).  The
+  // answer depends on the process-wide count of live contexts on the device: a context created or destroyed by another thread between
+  // the two evaluations must not send a tile-major matrix down a path that reads it column-major.
+  const bool backsub = c->solve_tiled;
+  bool want_fused = backsub || solve_is_persistent(c);
   c->solve_backsub = false;
   static const bool dbg = getenv("BALM_SOLVE_DEBUG") != nullptr;      // one line per factorisation: which path, and why not another
   if (dbg) fprintf(stderr, "balm_hip: solve P=%d persistent=%d backsub=%d chain_cap=%d fused_cap=%d multi=%d\n", P, (int)want_fused,
-                   (int)solve_wants_backsub(c), c->chain_cap, c->fused_cap, c->multi ? c->multi->n : 0);
-  if (want_fused && solve_wants_backsub(c)) {
+                   (int)backsub, c->chain_cap, c->fused_cap, c->multi ? c->multi->n : 0);
+  if (backsub) {
     if (launch_factor_chain(c, /*ident=*/false, c->solve_tiled)) { c->solve_backsub = true; return; }
     if (P > FUSED_MAX_P) want_fused = false;             // (refused: such a window is the launch path's, not k_ldl_fused's)
     if (c->solve_tiled) { c->solve_tiled = false; launch_build_A(c); }      // ... and the other paths read the column-major matrix

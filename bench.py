@@ -444,12 +444,18 @@ def main(argv=None):
     n = 6 * W
     per_step = {k: v[0] / args.steps for k, v in timing.items()}
 
+    # One process driving all N devices: the work model is the WHOLE table's, a timer is ONE device's.  Every roofline figure below is
+    # per device: a device's share of the work (the synthetic scene is dense: equal shards) over the mean of the devices' own launch
+    # times (balm_get_shard_timing) -- round 5 divided the aggregate by device 0's time and read N x too high.
+    shard_timings = [ctx.shard_timing(k) for k in range(n_gpus)] if inproc else [timing]
+    share = 1.0 / n_gpus if inproc else 1.0
+
     def avg_s(key):
-        ms, cnt = timing[key]
-        return ms / max(cnt, 1) * 1e-3 if cnt else None
+        per_dev = [t[key][0] / t[key][1] * 1e-3 for t in shard_timings if t[key][1]]
+        return float(np.mean(per_dev)) if per_dev else None
 
     syrk_s = avg_s("syrk")          # HIP events around the kernel's launch on the library's stream
-    achieved = wm["syrk_flops_algorithmic"] / syrk_s / 1e12 if syrk_s else None
+    achieved = share * wm["syrk_flops_algorithmic"] / syrk_s / 1e12 if syrk_s else None
     # HBM bytes per launch: NOT measured in this run (PMC counters need rocprofv3 around the process) -- read from the
     # committed summary of separate `rocprofv3 --pmc` passes of this same command; `traffic_source` names that run
     traffic, traffic_source = None, None
@@ -465,11 +471,13 @@ def main(argv=None):
         "unit": "TFLOP/s", "frac": (achieved / FP64_PEAK_TFLOPS) if achieved else None, "traffic": traffic,
         "traffic_source": traffic_source,
         "dtype": "f64", "avg_launch_ms": syrk_s * 1e3 if syrk_s else None, "launches": timing["syrk"][1],
-        "algorithmic_flops_per_launch": wm["syrk_flops_algorithmic"],
-        "issued_flops_per_launch": wm["syrk_flops_issued"],
+        "algorithmic_flops_per_launch": share * wm["syrk_flops_algorithmic"],
+        "issued_flops_per_launch": share * wm["syrk_flops_issued"],
     }
+    if inproc:
+        roofline["per_device"] = "1/%d of the table's work over the mean launch time of the %d devices' own timers" % (n_gpus, n_gpus)
     # the other kernel classes of the step against THEIR rooflines (algorithmic bytes/flops of SURVEY 8d; S = observations)
-    S = wm["S"]
+    S = share * wm["S"]
     secondary = {}
     t = avg_s("moments")
     if t:      # K1 + K1b: 80 B per observation read (two evaluations per step: Hessian side and residual side)
@@ -518,6 +526,11 @@ def main(argv=None):
                            "iterations_per_sec": len(lg_nat) / t_nat, "final_residual": float(lg_nat[-1, 1])},
         "final_residual": float(lg[-1, 1]),
     }
+    # a fraction above 1 says "the timed kernel did not do the work it is credited with": refuse the line rather than print it
+    fracs = [("roofline", roofline.get("frac"))] + [("roofline_secondary." + k, v.get("frac_of_copy_rate", v.get("frac"))) for k, v in secondary.items()]
+    over = [name for name, f in fracs if f is not None and f > 1.0]
+    if over:
+        out["error"] = "roofline fraction above 1: " + ", ".join(over)
     if accept is not None:
         accept.pop("_poses", None)
         out["acceptance"] = accept
@@ -627,6 +640,10 @@ def main(argv=None):
             out["cpu_baseline"] = {"error": repr(e)}
     # a sharded run must prove it really was N ranks: what the transport itself counts (ncclCommCount / the shard count)
     ranks_seen = out["comm"]["ranks_reported_by_transport"] if out.get("comm") else 1
+    if out.get("error", "").startswith("roofline fraction"):
+        print(json.dumps(out), flush=True)
+        print("bench.py: " + out["error"], file=sys.stderr)
+        sys.exit(6)
     if n_gpus > 1 and ranks_seen != n_gpus:
         out["error"] = "the transport reports %s ranks, the run was asked for %d" % (ranks_seen, n_gpus)
         print(json.dumps(out), flush=True)

@@ -306,6 +306,9 @@ enum {
   BALM_T_COUNT = 11
 };
 int balm_get_timing(balm_ctx *ctx, double *ms, long *count);
+/* The same for ONE device of a balm_create_multi context (shard = 0 .. n_devices - 1; balm_get_timing answers for device 0): the
+ * per-device launch times a sharded run's roofline fractions are computed from.  A plain context has shard 0 only. */
+int balm_get_shard_timing(balm_ctx *ctx, int shard, double *ms, long *count);
 
 /* Diagnostics of the persistent factorisation kernel: with BALM_SOLVE_TRACE=1 in the environment at balm_create, the
  * panel workgroups of the last solve leave wall-clock ticks (100 MHz) per (row block, column block, phase):
@@ -331,7 +334,7 @@ const char *balm_version(void);
 
 /* ABI revision of this header.  It changes whenever a struct above grows, an enum gains a member that sizes a caller's array
  * (BALM_T_COUNT) or an entry point changes its meaning: 3 = round 3 (balm_voxel_opts gained fix_point_limit / defer_recut,
- * BALM_T_COUNT went from 9 to 10), 4 = round 4 (balm_abi_version itself), 5 = round 5 (balm_set_features_cb, BALM_T_UPLOAD: BALM_T_COUNT 11), 6 = this header (the strided point-container entries balm_associate_scans / balm_build_clusters_planes / balm_window_add_scan_strided, balm_prewarm).  A caller built against another revision must not call anything else:
+ * BALM_T_COUNT went from 9 to 10), 4 = round 4 (balm_abi_version itself), 5 = round 5 (balm_set_features_cb, BALM_T_UPLOAD: BALM_T_COUNT 11), 6 = this header (the strided point-container entries balm_associate_scans / balm_build_clusters_planes / balm_window_add_scan_strided, balm_prewarm, balm_get_shard_timing).  A caller built against another revision must not call anything else:
  *     if (balm_abi_version() != BALM_ABI_VERSION) { refuse }                                                              */
 #define BALM_ABI_VERSION 6
 int balm_abi_version(void);
