@@ -422,7 +422,7 @@ int feature_bookkeeping(balm_ctx *ctx, int F, const unsigned char *obs, const do
   double S = 0, B = 0;
   int bad_a = F, bad_rc = BALM_OK;          // the first offending feature, whichever thread meets it
   std::mutex mu;
-  parallel_ranges((size_t)F, (size_t)(65536 / W + 1), [&](size_t lo, size_t hi) {
+  parallel_ranges((size_t)F, (size_t)((1 << 20) / W + 1), [&](size_t lo, size_t hi) {
     std::vector<int> ppp((size_t)W, 0);
     double s = 0, b = 0;
     int my_bad = F, my_rc = BALM_OK;
@@ -599,7 +599,7 @@ static int build_sparse_plan(balm_ctx *ctx, int F, const unsigned char *obs) {
                                                          //  sliding window installs a table per slide: the plan's host time is not free)
   struct Key { uint64_t hi, lo; int a; };
   std::vector<Key> keys((size_t)F);
-  parallel_ranges((size_t)F, (size_t)(65536 / W + 1), [&](size_t a0, size_t a1) {
+  parallel_ranges((size_t)F, (size_t)((1 << 20) / W + 1), [&](size_t a0, size_t a1) {       // (a megabyte of flags per piece: the shipped window's 400 KB stay on this thread)
     for (size_t a = a0; a < a1; a++) {
       uint64_t hi = 0, lo = 0;
       const unsigned char *oa = obs + a * W;
@@ -672,10 +672,13 @@ static int build_sparse_plan(balm_ctx *ctx, int F, const unsigned char *obs) {
   if ((rc = keep(ctx, &ctx->d_slot, &ctx->cap_slot, (size_t)F)) || (rc = keep(ctx, &ctx->d_items, &ctx->cap_items, sorted_items.size())) ||
       (rc = keep(ctx, &ctx->d_chunk_ids, &ctx->cap_chunk_ids, chunk_ids.size())) || (rc = keep(ctx, &ctx->d_csr, &ctx->cap_csr, csr.size())))
     return rc;
-  HIP_TRY(hipMemcpy(ctx->d_slot, slot.data(), slot.size() * sizeof(int), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(ctx->d_items, sorted_items.data(), sorted_items.size() * sizeof(int), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(ctx->d_chunk_ids, chunk_ids.data(), chunk_ids.size() * sizeof(int), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(ctx->d_csr, csr.data(), csr.size() * sizeof(int), hipMemcpyHostToDevice));
+  // (stream-ordered copies out of pageable vectors: the runtime stages them before it returns -- four blocking hipMemcpy were 0.15 of the
+  //  0.5 ms this function took per association of the shipped window; whoever uses the plan is on the same stream)
+  HIP_TRY(hipMemcpyAsync(ctx->d_slot, slot.data(), slot.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(ctx->d_items, sorted_items.data(), sorted_items.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(ctx->d_chunk_ids, chunk_ids.data(), chunk_ids.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(ctx->d_csr, csr.data(), csr.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));               // (the vectors die with this frame)
   ctx->sparse = true; ctx->sp_nsteps = nsteps; ctx->sp_nchunks = nchunks; ctx->sp_nitems = run; ctx->sp_steps = sparse_steps;
   return BALM_OK;
 }
@@ -885,10 +888,14 @@ static int install_associated(balm_ctx *ctx, int F, double *d_out, double *d_coe
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) rc = BALM_ERR_HIP;
   }
+  cold_mark("install: table transposed, obs / weights / fix / layers on the host");
   if (!rc) rc = feature_bookkeeping(ctx, F, obs.data(), has_fix ? ctx->assoc_fix.data() : nullptr, ctx->assoc_coeffs.data());
+  cold_mark("install: bookkeeping");
   if (!rc) rc = build_sparse_plan(ctx, F, obs.data());
+  cold_mark("install: sparse plan");
   if (!rc) rc = install_feature_buffers(ctx, F, has_fix ? d_fix : nullptr, d_coe, hipMemcpyDeviceToDevice);
   if (!rc) rc = sync_stream(ctx);
+  cold_mark("install: buffers + sync");
   if (owned) {
     hipFree(d_out); hipFree(d_coe); hipFree(d_fix); hipFree(d_lay);
     if (d_pf) hipFree(d_pf);

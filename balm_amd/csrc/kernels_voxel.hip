@@ -239,11 +239,16 @@ __global__ void k_make_ck(const unsigned int *__restrict__ rootid_incl, const un
 }
 
 // segment s = run of equal composite keys: its first position and its key in canonical form
+// (the entry behind the last segment's -- seg_start[NS] = n -- and the zeroed counters of the segment kernels' work lists ride along:
+//  one launch and one fill node less per level)
 template <class K>
 __global__ void k_seg_heads(const K *__restrict__ cks, const unsigned int *__restrict__ segid_incl, long n, int level, int fb,
-                            unsigned int *__restrict__ seg_start, unsigned long long *__restrict__ seg_ck) {
+                            unsigned int *__restrict__ seg_start, unsigned long long *__restrict__ seg_ck,
+                            unsigned int *__restrict__ counters4 = nullptr) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
+  if (i == n - 1) seg_start[segid_incl[i]] = (unsigned int)n;
+  if (i < 4 && counters4) counters4[i] = 0u;
   if (i == 0 || cks[i] != cks[i - 1]) {
     const unsigned int s = segid_incl[i] - 1;
     const unsigned long long k = cks[i];
@@ -799,7 +804,7 @@ inline void launch_seg_clusters_rec(hipStream_t st, const uint4 *rec, const doub
   if (NS <= 0) return;
   unsigned int *counters = lists;
   uint4 *long_list = reinterpret_cast<uint4 *>(lists + 4), *vlong_list = long_list + NS;
-  hipMemsetAsync(counters, 0, 4 * sizeof(unsigned int), st);
+  // (counters: zeroed by k_seg_heads, the launch in front of this one)
   hipLaunchKernelGGL(k_seg_lane, dim3((unsigned int)((NS + 255) / 256)), dim3(256), 0, st, rec, poses, seg_start, seg_ck, NS, seg_body, seg_world,
                      counters, long_list, vlong_list);
   const long want = (NS + 3) / 4;
@@ -814,6 +819,7 @@ __global__ void k_level_heads(const unsigned long long *__restrict__ seg_ck, con
                               unsigned int *__restrict__ node_seg, unsigned int *__restrict__ node_parent) {
   const long s = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= NS) return;
+  if (s == NS - 1) node_seg[nid_incl[s]] = (unsigned int)NS;        // the entry behind the last node's
   const unsigned long long ck = seg_ck[s];
   if (s == 0 || (ck >> 9) != (seg_ck[s - 1] >> 9)) {
     const unsigned int j = nid_incl[s] - 1;
@@ -1009,6 +1015,7 @@ __global__ void k_feature_flags(int level, long NN, const NodeTot *__restrict__ 
                                 const unsigned int *__restrict__ parent1, const unsigned int *__restrict__ parent2,
                                 VoxParams pr, unsigned int *__restrict__ flag) {
   const long j = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j == 0) flag[NN] = 0u;                                         // (the scan behind this kernel runs over NN + 1 entries)
   if (j >= NN) return;
   bool live;
   if (level == 0) live = st0[j] == NODE_PLANE;
@@ -1489,17 +1496,15 @@ int associate_device(hipStream_t s, const float *d_xyz, const int *d_frame, cons
     st.seg_world = sc.get<double>((size_t)v.NS * 10);
     st.nid = sc.get<unsigned int>(v.NS); st.pid = sc.get<unsigned int>(v.NS);
     v.seg_node = st.nid;
+    unsigned int *lists = st.rec ? sc.get<unsigned int>(4 + 8 * (size_t)v.NS) : nullptr;
     if (!sc.ok) return -1;
     if (st.narrow)
       hipLaunchKernelGGL((k_seg_heads<unsigned int>), dim3(grid_for(nL, B)), dim3(B), 0, s, (const unsigned int *)st.cks, st.incl, nL, L,
-                         fb, st.seg_start, v.seg_ck);
+                         fb, st.seg_start, v.seg_ck, lists);
     else
       hipLaunchKernelGGL((k_seg_heads<unsigned long long>), dim3(grid_for(nL, B)), dim3(B), 0, s, (const unsigned long long *)st.cks, st.incl, nL, L, fb,
-                         st.seg_start, v.seg_ck);
-    hipLaunchKernelGGL(k_set_u32, dim3(1), dim3(1), 0, s, st.seg_start + v.NS, (unsigned int)nL);
+                         st.seg_start, v.seg_ck, lists);
     if (st.rec) {
-      auto *lists = sc.get<unsigned int>(4 + 8 * (size_t)v.NS);
-      if (!sc.ok) return -1;
       launch_seg_clusters_rec(s, st.rec, d_poses, st.seg_start, v.seg_ck, v.NS, v.seg_body, st.seg_world, lists);
     }
     else launch_seg_clusters(s, d_xyz, d_poses, st.idx, st.seg_start, v.seg_ck, v.NS, v.seg_body, st.seg_world);
@@ -1524,7 +1529,6 @@ int associate_device(hipStream_t s, const float *d_xyz, const int *d_frame, cons
     if (!sc.ok) return -1;
     hipLaunchKernelGGL(k_level_heads, dim3(grid_for(v.NS, B)), dim3(B), 0, s, v.seg_ck, st.nid, st.pid, v.NS, pshift, v.node_seg,
                        v.node_parent);
-    hipLaunchKernelGGL(k_set_u32, dim3(1), dim3(1), 0, s, v.node_seg + v.NN, (unsigned int)v.NS);
     hipLaunchKernelGGL(k_node_totals, dim3(grid_for(v.NN * 16, B)), dim3(B), 0, s, st.seg_world, v.seg_ck, v.node_seg, v.NN,
                        o.fix_frames, v.tot);
     hipLaunchKernelGGL(k_node_status, dim3(grid_for(v.NN, 128)), dim3(128), 0, s, v.tot, v.NN, pr.thr[L], pr, v.status, plane);
@@ -1532,8 +1536,7 @@ int associate_device(hipStream_t s, const float *d_xyz, const int *d_frame, cons
       hipLaunchKernelGGL(k_point_plane_dist, dim3(grid_for(st.nL, B)), dim3(B), 0, s, d_xyz, scan, d_poses, st.idx, st.incl, st.nid, st.nL, plane,
                          o.max_dis, v.status);
     if (want_points) hipLaunchKernelGGL(k_point_nodes, dim3(grid_for(st.nL, B)), dim3(B), 0, s, st.idx, st.incl, st.nid, st.nL, pnode[L]);
-    hipMemsetAsync(v.flag + v.NN, 0, sizeof(unsigned int), s);
-    return 0;
+    return 0;           // (flag[NN] = 0: k_feature_flags)
   };
   // one level on its own: scan, count, segments, count, nodes (nn_known > 0: the node count is known -- level 0's nodes ARE the roots)
   auto finish_level = [&](int L, long nL, bool narrow, const void *cks_, const unsigned int *idxL_, const uint4 *recL, long nn_known = 0) -> int {

@@ -77,7 +77,7 @@ def check(obj=None, verbose=True):
         if kern == "k_ldl_chain":
             # the helpers' operand tiles go global -> LDS directly (ch_stage_tile: 2 pieces x 4 tiles in each of the two helper
             # roles).  Written as a plain copy loop the staging stayed ROLLED in the ISA for all of round 3 -- load, vmcnt(0),
-            # ds_write per iteration, ~10 serial memory round trips per round (DESIGN.md 4.6); tools/find_rolled_copies.py.
+            # ds_write per iteration, ~10 serial memory round trips per round (DESIGN.md 4.4); tools/find_rolled_copies.py.
             glds = sum(1 for l in body if "global_load_lds_dwordx4" in l)
             if verbose:
                 print("%-16s global_load_lds_dwordx4 %3d (>= 16)" % (kern, glds))

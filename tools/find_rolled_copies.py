@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Static audit of the gfx950 code objects in balm_amd/lib/*.so: loops whose body loads from global memory, waits for
 vmcnt(0) and only then stores to LDS (or to global memory), i.e. copy loops the compiler left ROLLED -- every iteration is a
-full memory round trip.  This is what the helpers of k_ldl_chain did for all of round 3 (DESIGN.md 4.6: ~10 serial round trips
+full memory round trip.  This is what the helpers of k_ldl_chain did for all of round 3 (DESIGN.md 4.4: ~10 serial round trips
 per round read as "the memory system is the bound").  Prints kernel, loop position, trip body summary.
    python tools/find_rolled_copies.py [lib.so ...]"""
 import os
