@@ -456,6 +456,221 @@ __global__ __launch_bounds__(256) void k_gather_records(const float *__restrict_
   tags[i] = (unsigned short)t;
 }
 
+// ---- round 6: the root order by a stable MULTISPLIT instead of a radix sort ------------------------------------------------------------
+// The packed root key has 24 bits on the shipped window -- and 1 633 VALUES: the points of a lidar window fall into a few thousand root
+// voxels, metres wide.  Sorting 13.4 M (key, index) pairs through three 8-bit radix passes, ranking the sorted keys and then gathering the
+// points by sorted index (5 x 74 + 30 + 254 + 21 us) does far more than the order needs:
+//   M1  k_ms_keys     pass B as before (key, tag) + the key's bit in a bitmap of the key space (2^key_bits bits: 2 MB)
+//   M2  rank          exclusive prefix popcount over the bitmap words: a key's DENSE root index = words before + bits below, in key order
+//                     -- the numbering the sort + head-flag scan produced
+//   M3  k_ms_hist     per tile of 8 192 consecutive points: how many fall into each root (LDS histogram); the dense index is kept per point
+//   M4  k_ms_group_sums / k_ms_bases / k_ms_tile_offsets   per root, an exclusive scan over the tiles (in 32 groups) on top of the roots' own
+//                     exclusive scan: where each tile's points of each root go.  Also root_start, which k_root_starts used to find.
+//   M5  k_ms_scatter  every point's record {x, y, z, tag} straight to its place: rank among the tile's points of its root = counts of
+//                     the earlier rounds + of the earlier wavefronts of this round + the lower lanes with the same root (ballots over the
+//                     index bits) -- stable, so a root's points stay in scan order and every sum downstream is the reference's, bit for bit.
+// ~60 bytes per point in two streaming passes instead of ~150 with a random gather.  Used when the fast path is certain and the window has at
+// most MS_MAX_ROOTS root voxels (else the radix path, unchanged); BALM_ASSOC=radix forces the radix path (A/B, tests).
+constexpr int MS_TILE = 8192, MS_MAX_ROOTS = 2048, MS_GROUPS = 32;
+
+template <class K>
+__global__ __launch_bounds__(256) void k_ms_keys(const float *__restrict__ xyz, const ScanOf scan, const double *__restrict__ poses, long n,
+                                                 double vs, KeyPack kp, K *__restrict__ k0, unsigned short *__restrict__ tag,
+                                                 unsigned int *__restrict__ bitmap) {
+  __shared__ int s_f0;
+  __shared__ long s_b[2];
+  __shared__ unsigned int s_set[512];
+  s_set[threadIdx.x] = 0xffffffffu; s_set[threadIdx.x + 256] = 0xffffffffu;
+  if (!scan.frame && threadIdx.x == 0) {
+    const int f0 = scan.find(min((long)blockIdx.x * blockDim.x, n - 1), scan.first);
+    s_f0 = f0;
+    s_b[0] = scan.first[min(f0 + 1, scan.m)]; s_b[1] = scan.first[min(f0 + 2, scan.m)];
+  }
+  __syncthreads();
+  const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  double q[3], po[3];
+  int fr;
+  if (scan.frame) fr = scan.frame[p];
+  else {
+    fr = s_f0 + (p >= s_b[0] ? 1 : 0) + (p >= s_b[1] ? 1 : 0);
+    if (p >= s_b[1]) fr = scan.advance(fr, p, scan.first);
+    fr = min(fr, scan.m - 1);
+  }
+  world_point(xyz, poses + 12 * (long)fr, p, q, po);
+  const float q1 = (float)(vs / 4.0);
+  unsigned long long key = 0;
+  int o1 = 0, o2 = 0;
+#pragma unroll
+  for (int j = 0; j < 3; j++) {
+    const long long kj = voxel_key(q[j], vs);
+    const float c0 = (float)((0.5 + (double)kj) * vs);
+    const int b1 = q[j] > (double)c0;
+    const float c1 = __fadd_rn(c0, __fmul_rn((float)(2 * b1 - 1), q1));
+    const int b2 = q[j] > (double)c1;
+    key = key * kp.n[j] + (unsigned long long)(kj - kp.off[j]);
+    o1 = (o1 << 1) | b1;
+    o2 = (o2 << 1) | b2;
+  }
+  k0[p] = (K)key;
+  tag[p] = (unsigned short)((o1 << 12) | (o2 << 9) | fr);
+  // The key's bit.  Device-wide looks at a few thousand hot words are expensive on eight XCDs (coherent accesses go past the L2s: one look
+  // per run of equal keys cost 290 us on the shipped window), so the workgroup thins them out first: the first lane of every run of equal
+  // keys claims the key in a small LDS set; only the one that claims it for the workgroup goes to memory -- a dozen per 256 points.
+  const unsigned int kk = (unsigned int)key, prev = __shfl_up(kk, 1, 64);
+  if ((threadIdx.x & 63) == 0 || prev != kk) {
+    unsigned int slot = (kk * 2654435761u) >> 23;           // 512 slots
+    for (int tries = 0; tries < 512; tries++) {
+      const unsigned int old = atomicCAS(&s_set[slot], 0xffffffffu, kk);
+      if (old == kk) break;                                   // somebody of this workgroup has it
+      if (old == 0xffffffffu) {
+        const unsigned int w = kk >> 5, bit = 1u << (kk & 31u);
+        if (!(__hip_atomic_load(bitmap + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bit)) atomicOr(bitmap + w, bit);
+        break;
+      }
+      slot = (slot + 1) & 511u;
+    }
+  }
+}
+
+struct PopcOf {
+  const unsigned int *w; long nw;
+  __device__ unsigned int operator()(long i) const { return i < nw ? (unsigned int)__popc(w[i]) : 0u; }
+};
+
+__device__ __forceinline__ unsigned int ms_root_of(unsigned int key, const unsigned int *__restrict__ bitmap, const unsigned int *__restrict__ rank_base) {
+  const unsigned int w = key >> 5;
+  return rank_base[w] + (unsigned int)__popc(bitmap[w] & ((1u << (key & 31u)) - 1u));
+}
+
+// hist[tile][r] = points of tile `tile` in root r; rid[p] = the point's dense root index
+__global__ __launch_bounds__(256) void k_ms_hist(const unsigned int *__restrict__ key, long n, const unsigned int *__restrict__ bitmap,
+                                                 const unsigned int *__restrict__ rank_base, int NR, unsigned short *__restrict__ rid,
+                                                 unsigned int *__restrict__ hist) {
+  __shared__ unsigned int h[MS_MAX_ROOTS];
+  for (int t = threadIdx.x; t < NR; t += 256) h[t] = 0;
+  __syncthreads();
+  const long a = (long)blockIdx.x * MS_TILE, e = min(n, a + MS_TILE);
+  for (long p = a + threadIdx.x; p < e; p += 256) {
+    const unsigned int r = ms_root_of(key[p], bitmap, rank_base);
+    rid[p] = (unsigned short)r;
+    // (runs of equal roots inside a wavefront: one LDS atomic per run)
+    const unsigned int prev = __shfl_up(r, 1, 64);
+    const bool head = (threadIdx.x & 63) == 0 || prev != r;
+    const unsigned long long heads = __ballot(head), act = __ballot(true);      // (both by every lane that still has a point)
+    if (head) {
+      const int lane = threadIdx.x & 63;
+      const unsigned long long above = lane == 63 ? 0ull : (heads >> (lane + 1));
+      const int next = above ? lane + 1 + __builtin_ctzll(above) : 64 - __builtin_clzll(act);
+      atomicAdd(&h[r], (unsigned int)(next - lane));
+    }
+  }
+  __syncthreads();
+  unsigned int *row = hist + (size_t)blockIdx.x * NR;
+  for (int t = threadIdx.x; t < NR; t += 256) row[t] = h[t];
+}
+
+// gsum[g][r] = points of root r in the tiles of group g
+__global__ __launch_bounds__(256) void k_ms_group_sums(const unsigned int *__restrict__ hist, int NR, long ntiles, int per_group,
+                                                       unsigned int *__restrict__ gsum) {
+  const int r = blockIdx.x * 256 + threadIdx.x, g = blockIdx.y;
+  if (r >= NR) return;
+  const long t0 = (long)g * per_group, t1 = min(ntiles, t0 + per_group);
+  unsigned int sacc = 0;
+  for (long t = t0; t < t1; t++) sacc += hist[(size_t)t * NR + r];
+  gsum[(size_t)g * NR + r] = sacc;
+}
+
+// one workgroup: per root the exclusive scan over the groups, the roots' totals and THEIR exclusive scan = root_start; gsum becomes
+// the first place of the group's points of the root
+__global__ __launch_bounds__(1024) void k_ms_bases(unsigned int *__restrict__ gsum, int NR, int groups, long n, unsigned int *__restrict__ root_start) {
+  __shared__ unsigned int wsum[16], carry;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  if (tid == 0) carry = 0;
+  __syncthreads();
+  for (int r0 = 0; r0 < NR; r0 += 1024) {
+    const int r = r0 + tid;
+    unsigned int tot = 0;
+    if (r < NR) for (int g = 0; g < groups; g++) { const unsigned int v = gsum[(size_t)g * NR + r]; gsum[(size_t)g * NR + r] = tot; tot += v; }
+    unsigned int x = tot;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const unsigned int y = __shfl_up(x, d, 64); if (lane >= d) x += y; }
+    if (lane == 63) wsum[wv] = x;
+    __syncthreads();
+    unsigned int base = carry;
+    for (int w = 0; w < wv; w++) base += wsum[w];
+    const unsigned int start = base + x - tot;
+    if (r < NR) {
+      root_start[r] = start;
+      for (int g = 0; g < groups; g++) gsum[(size_t)g * NR + r] += start;
+    }
+    __syncthreads();
+    if (tid == 1023) carry = base + x;
+    __syncthreads();
+  }
+  if (tid == 0) root_start[NR] = (unsigned int)n;
+}
+
+// hist[tile][r] -> the first place of tile `tile`'s points of root r
+__global__ __launch_bounds__(256) void k_ms_tile_offsets(unsigned int *__restrict__ hist, int NR, long ntiles, int per_group,
+                                                         const unsigned int *__restrict__ gsum) {
+  const int r = blockIdx.x * 256 + threadIdx.x, g = blockIdx.y;
+  if (r >= NR) return;
+  const long t0 = (long)g * per_group, t1 = min(ntiles, t0 + per_group);
+  unsigned int run = gsum[(size_t)g * NR + r];
+  for (long t = t0; t < t1; t++) { const unsigned int c = hist[(size_t)t * NR + r]; hist[(size_t)t * NR + r] = run; run += c; }
+}
+
+// every point's record to its place in root order (stable); ck0 = (root, scan), the tags again as a dense stream, optionally the index.
+// 256 points per round, the next round's loads in flight under the current round's three barriers (a barrier-free variant -- every
+// wavefront walking a quarter of the tile on its own running places -- measured slower: 312 against 223 us, one serial chain per wavefront).
+__global__ __launch_bounds__(256) void k_ms_scatter(const float *__restrict__ xyz, const unsigned short *__restrict__ tag,
+                                                    const unsigned short *__restrict__ rid, long n, const unsigned int *__restrict__ off, int NR,
+                                                    int rbits, int fb, uint4 *__restrict__ rec, unsigned int *__restrict__ ck0,
+                                                    unsigned short *__restrict__ tags, unsigned int *__restrict__ idxs) {
+  __shared__ unsigned int run[MS_MAX_ROOTS];
+  __shared__ unsigned short wc[4][MS_MAX_ROOTS];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const unsigned int *orow = off + (size_t)blockIdx.x * NR;
+  for (int t = tid; t < NR; t += 256) { run[t] = orow[t]; wc[0][t] = wc[1][t] = wc[2][t] = wc[3][t] = 0; }
+  const long a = (long)blockIdx.x * MS_TILE, e = min(n, a + MS_TILE);
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  unsigned int r = 0, t = 0;
+  float x = 0, y = 0, z = 0;
+  if (a + tid < e) { const long p = a + tid; r = rid[p]; t = tag[p]; x = xyz[3 * p]; y = xyz[3 * p + 1]; z = xyz[3 * p + 2]; }
+  __syncthreads();
+  for (long p0 = a; p0 < e; p0 += 256) {
+    const long p = p0 + tid, pn = p + 256;
+    const bool act = p < e;
+    unsigned int rn = 0, tn = 0;
+    float xn = 0, yn = 0, zn = 0;
+    if (pn < e) { rn = rid[pn]; tn = tag[pn]; xn = xyz[3 * pn]; yn = xyz[3 * pn + 1]; zn = xyz[3 * pn + 2]; }
+    unsigned long long m = __ballot(act);                    // lanes of this wavefront with the same root
+    for (int b = 0; b < rbits; b++) {
+      const unsigned long long bal = __ballot(act && ((r >> b) & 1u));
+      m &= ((r >> b) & 1u) ? bal : ~bal;
+    }
+    const unsigned int below = (unsigned int)__popcll(m & lt), cnt = (unsigned int)__popcll(m);
+    if (act && below == 0) wc[wv][r] = (unsigned short)cnt;
+    __syncthreads();
+    unsigned int d = 0;
+    if (act) {
+      d = run[r] + below;
+      for (int w = 0; w < wv; w++) d += wc[w][r];
+    }
+    __syncthreads();
+    if (act && below == 0) { atomicAdd(&run[r], cnt); wc[wv][r] = 0; }
+    if (act) {
+      rec[d] = make_uint4(__float_as_uint(x), __float_as_uint(y), __float_as_uint(z), t);
+      ck0[d] = (r << fb) | (t & 511u);
+      tags[d] = (unsigned short)t;
+      if (idxs) idxs[d] = (unsigned int)p;
+    }
+    r = rn; t = tn; x = xn; y = yn; z = zn;
+    __syncthreads();
+  }
+}
+
 // the sorted path's 64-bit sort values (point << 15 | octants << 9 | scan) in root order, from the fast path's root sort
 __global__ void k_vals_from_tags(const unsigned int *__restrict__ idxs, const unsigned short *__restrict__ tag, long n,
                                  unsigned long long *__restrict__ vals) {
@@ -1441,13 +1656,43 @@ int associate_device(hipStream_t s, const float *d_xyz, const int *d_frame, cons
   const bool fast_keys = scan_ordered && key_bits <= 32 && !(amode && !strcmp(amode, "sorted"));
   unsigned short *tag = nullptr, *tags = nullptr;
   unsigned int *idx0 = (unsigned int *)val, *idx0s = (unsigned int *)vals;       // (the fast path's sort values live in the u64 arrays)
+  // round 6: the root order by multisplit (see k_ms_keys) when the key space is small enough for a bitmap and -- known after M2 -- the
+  // window has few enough roots; BALM_ASSOC=radix keeps round 5's radix sort of (key, index) pairs
+  const bool want_ms = fast_keys && key_bits <= 26 && !(amode && !strcmp(amode, "radix"));
+  bool ms = false;
+  long NR = -1;
+  unsigned int *ms_bitmap = nullptr, *ms_rank = nullptr;
+  const long ms_tiles = (n + MS_TILE - 1) / MS_TILE;
   if (fast_keys) {
     tag = sc.get<unsigned short>(n); tags = sc.get<unsigned short>(n);
     if (!sc.ok) return -1;
-    hipLaunchKernelGGL((k_vox_keys_tag<unsigned int>), dim3(grid_for(n, B)), dim3(B), 0, s, d_xyz, scan, d_poses, n, o.voxel_size, kp,
-                       (unsigned int *)k0, idx0, tag);
-    sort_pairs(sc, s, (unsigned int *)k0, (unsigned int *)k0s, idx0, idx0s, n, key_bits);
-    scan_heads(sc, s, (const unsigned int *)k0s, 0, rootid, n);
+    if (want_ms) {
+      const long nw = (long)(((1ull << key_bits) + 31ull) / 32ull);
+      ms_bitmap = sc.get<unsigned int>(nw); ms_rank = sc.get<unsigned int>(nw + 1);
+      if (!sc.ok) return -1;
+      hipMemsetAsync(ms_bitmap, 0, (size_t)nw * sizeof(unsigned int), s);
+      hipLaunchKernelGGL((k_ms_keys<unsigned int>), dim3(grid_for(n, B)), dim3(B), 0, s, d_xyz, scan, d_poses, n, o.voxel_size, kp,
+                         (unsigned int *)k0, tag, ms_bitmap);
+      {
+        auto in = rocprim::make_transform_iterator(rocprim::counting_iterator<long>(0), PopcOf{ms_bitmap, nw});
+        size_t tmp = 0;
+        rocprim::exclusive_scan(nullptr, tmp, in, ms_rank, 0u, (size_t)(nw + 1), rocprim::plus<unsigned int>(), s);
+        void *d = sc.get<char>(tmp);
+        if (!d) return -1;
+        rocprim::exclusive_scan(d, tmp, in, ms_rank, 0u, (size_t)(nw + 1), rocprim::plus<unsigned int>(), s);
+      }
+      NR = last_u32(s, ms_rank, nw + 1, mail);
+      int rb = 1;
+      while ((1l << rb) < NR) rb++;
+      ms = NR >= 1 && NR <= MS_MAX_ROOTS && rb + 3 * (levels - 1) + fb <= 32 && ms_tiles * NR <= (64l << 20);
+    }
+    if (!ms) {                     // round 5's root order (also: more roots than the multisplit's LDS tables hold)
+      hipLaunchKernelGGL((k_vox_keys_tag<unsigned int>), dim3(grid_for(n, B)), dim3(B), 0, s, d_xyz, scan, d_poses, n, o.voxel_size, kp,
+                         (unsigned int *)k0, idx0, tag);
+      sort_pairs(sc, s, (unsigned int *)k0, (unsigned int *)k0s, idx0, idx0s, n, key_bits);
+      scan_heads(sc, s, (const unsigned int *)k0s, 0, rootid, n);
+      NR = -1;
+    }
   } else {
     auto root_keys = [&](auto *ka, auto *kb) {     // 32-bit radix keys whenever the packed key fits
       using K = std::remove_pointer_t<decltype(ka)>;
@@ -1459,7 +1704,7 @@ int associate_device(hipStream_t s, const float *d_xyz, const int *d_frame, cons
     else root_keys(k0, k0s);
   }
   if (!sc.ok) return -1;
-  const long NR = last_u32(s, rootid, n, mail);
+  if (NR < 0) NR = last_u32(s, rootid, n, mail);
   int root_bits = 1;
   while ((1l << root_bits) < NR) root_bits++;
   const bool fast = fast_keys && root_bits + 3 * (levels - 1) + fb <= 32;
@@ -1552,8 +1797,22 @@ int associate_device(hipStream_t s, const float *d_xyz, const int *d_frame, cons
     auto *root_start = sc.get<unsigned int>(NR + 1), *live_start = sc.get<unsigned int>(NR + 1), *tile_base = sc.get<unsigned int>(NR + 1);
     auto *plan = sc.get<unsigned int>(4);
     if (!sc.ok) return -1;
-    hipLaunchKernelGGL(k_gather_records, dim3(grid_for(n, B)), dim3(B), 0, s, d_xyz, tag, idx0s, rootid, n, fb, rec0, ck0, tags);
-    if (levels > 1) hipLaunchKernelGGL(k_root_starts, dim3(grid_for(n, B)), dim3(B), 0, s, (const unsigned int *)k0s, rootid, n, NR, root_start);
+    if (ms) {
+      auto *rid = sc.get<unsigned short>(n);
+      auto *hist = sc.get<unsigned int>((size_t)ms_tiles * NR), *gsum = sc.get<unsigned int>((size_t)MS_GROUPS * NR);
+      if (!sc.ok) return -1;
+      const int per_group = (int)((ms_tiles + MS_GROUPS - 1) / MS_GROUPS), groups = (int)((ms_tiles + per_group - 1) / per_group);
+      const dim3 rgrid((unsigned int)((NR + 255) / 256), (unsigned int)groups);
+      hipLaunchKernelGGL(k_ms_hist, dim3((unsigned int)ms_tiles), dim3(256), 0, s, (const unsigned int *)k0, n, ms_bitmap, ms_rank, (int)NR, rid, hist);
+      hipLaunchKernelGGL(k_ms_group_sums, rgrid, dim3(256), 0, s, hist, (int)NR, ms_tiles, per_group, gsum);
+      hipLaunchKernelGGL(k_ms_bases, dim3(1), dim3(1024), 0, s, gsum, (int)NR, groups, n, root_start);
+      hipLaunchKernelGGL(k_ms_tile_offsets, rgrid, dim3(256), 0, s, hist, (int)NR, ms_tiles, per_group, gsum);
+      hipLaunchKernelGGL(k_ms_scatter, dim3((unsigned int)ms_tiles), dim3(256), 0, s, d_xyz, tag, rid, n, hist, (int)NR, root_bits, fb, rec0, ck0, tags,
+                         need_idx ? idx0s : (unsigned int *)nullptr);
+    } else {
+      hipLaunchKernelGGL(k_gather_records, dim3(grid_for(n, B)), dim3(B), 0, s, d_xyz, tag, idx0s, rootid, n, fb, rec0, ck0, tags);
+      if (levels > 1) hipLaunchKernelGGL(k_root_starts, dim3(grid_for(n, B)), dim3(B), 0, s, (const unsigned int *)k0s, rootid, n, NR, root_start);
+    }
     if (finish_level(0, n, true, ck0, idx0s, rec0, NR)) return -1;          // (ck0 numbers the roots 0 .. NR - 1: level 0 has NR nodes)
     if (levels > 1) {
       // levels 1 and 2 for the points of the roots recut splits (status NODE_SPLIT, known now), in compact lists

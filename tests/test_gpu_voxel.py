@@ -310,12 +310,43 @@ def test_partition_path_is_the_sorted_path_bit_for_bit(seed, W, voxel, layer_lim
         return out
 
     F_a, nr_a, feats_a = run()
-    monkeypatch.setenv("BALM_ASSOC", "sorted")
-    F_b, nr_b, feats_b = run()
-    assert F_a == F_b and nr_a == nr_b and F_a > (0 if opts.get("strict") else 5)
-    assert len(feats_a) == len(feats_b)
-    for x, y in zip(feats_a, feats_b):
-        assert (x is None and y is None) or np.array_equal(x, y)
+    # BALM_ASSOC=radix: round 5's root order (radix sort of (key, index) pairs + gather) instead of round 6's stable multisplit
+    for other in ("sorted", "radix"):
+        monkeypatch.setenv("BALM_ASSOC", other)
+        F_b, nr_b, feats_b = run()
+        assert F_a == F_b and nr_a == nr_b and F_a > (0 if opts.get("strict") else 5)
+        assert len(feats_a) == len(feats_b)
+        for x, y in zip(feats_a, feats_b):
+            assert (x is None and y is None) or np.array_equal(x, y)
+
+
+@pytest.mark.gpu
+def test_multisplit_root_order_on_ragged_tiles_and_many_roots(monkeypatch):
+    """the multisplit's corners: a last tile of a few points, one-point scans, a window with more root voxels than its LDS tables hold
+    (falls back to the radix order) -- always the table of BALM_ASSOC=radix, bit for bit, with the feature of every point"""
+    def both(frames, poses, voxel, W):
+        outs = []
+        for mode in ("", "radix"):
+            if mode:
+                monkeypatch.setenv("BALM_ASSOC", mode)
+            else:
+                monkeypatch.delenv("BALM_ASSOC", raising=False)
+            c = capi.Context(W)
+            outs.append(rw.associate_gpu(c, frames, poses, voxel, want_points=True))
+            c.close()
+        (Fa, na, fa), (Fb, nb, fb) = outs
+        assert Fa == Fb and na == nb
+        for x, y in zip(fa or (), fb or ()):
+            assert (x is None and y is None) or np.array_equal(x, y)
+        return Fa, na
+    poses, frames = cluttered_window(31, 7, 40, 150, 2500)
+    frames[3] = frames[3][:1]                                   # a one-point scan
+    frames[6] = frames[6][:8192 * 2 + 3 - sum(len(f) for f in frames[:6]) % 8192] if len(frames[6]) > 20000 else frames[6]
+    F, nroots = both(frames, poses, 4.0, 7)
+    assert F > 2 and nroots <= 2048
+    # a fine grid: thousands of roots -> the radix path by itself
+    F2, nroots2 = both(frames, poses, 1.0, 7)
+    assert F2 > 5 and nroots2 > 2048
 
 
 @pytest.mark.gpu
