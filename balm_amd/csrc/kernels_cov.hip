@@ -81,7 +81,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                                                      double *__restrict__ dpart) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   double *sp = sm;                 // [12][W] poses
-  double *sacc = sm + 12 * W;      // [21][W]
+  double *sacc = sm + 12 * W;      // [21][W]  (in registers instead -- 42 of them per lane, measured round 6 -- the kernel spills more than it saves:
+                                   // the register file, not the LDS, is what holds a CU at two workgroups)
   __shared__ double sq[4][6];
   for (int t = threadIdx.x; t < 12 * W; t += blockDim.x) {
     int i = t / 12, c = t - 12 * i;
@@ -149,56 +150,35 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
               Pw[r][c] = RP[r][0] * R[c] + RP[r][1] * R[3 + c] + RP[r][2] * R[6 + c] + Rv[r] * p[c] + p[r] * b[c];
         }
         const double c2 = 2.0 * iNN;
-        // Gm (3x9): rows u_k^T Gkl / ((lam0 - lam_k) NN), k = 1, 2, and m = [0 0 0 0 0 0 r3]      (:431-441)
-        //   Gkl[:3] = R g1([r3; p.u0])[:3] + (p - vbar) (x) [0..0 r3] - [0 | (vbar.u0) R]
-        double r3[3];
+        // Round 6: the sparse structure is used instead of carried.  g1(w) (BAs_left.hpp:320-330) has fifteen non-zeros that four scalars
+        // define -- row j of its top: w0, w1, w2 at the coordinates of P's row j, w3 at v_j; bottom row [0 .. 0 w0 w1 w2] -- so
+        //     Gm's rows      k_k (ru_k^T g1([r3; p.u0])[:3] + [0 | pv_k r3 - (vbar.u0) ru_k]),  m = [0 .. 0 r3]        (:431-441)
+        //     D = (2/NN) U_0 Y,  Y = T_j G1,  G1 = g1([r3; (p - vbar).u0])  (4 x 9),  T_j = [R p; 0 1]                    (:449-450)
+        // and everything that round 5 computed on the 3 x 9 Y (27 registers, beside the 27 of c_cov Gm^T) is computed on G1 and lifted
+        // through T_j afterwards:   Y sg = T_j (G1 sg),   Y c_cov Y^T = T_j (G1 c_cov G1^T) T_j^T.  One 9-vector is alive at a time.
+        double r3[3], ru1[3], ru2[3];
 #pragma unroll
-        for (int c = 0; c < 3; c++) r3[c] = R[3 * c] * u0[0] + R[3 * c + 1] * u0[1] + R[3 * c + 2] * u0[2];   // R^T u0
+        for (int c = 0; c < 3; c++) {
+          r3[c] = R[3 * c] * u0[0] + R[3 * c + 1] * u0[1] + R[3 * c + 2] * u0[2];    // R^T u0
+          ru1[c] = R[3 * c] * u1[0] + R[3 * c + 1] * u1[1] + R[3 * c + 2] * u1[2];   // R^T u_k  (u_k^T R)
+          ru2[c] = R[3 * c] * u2[0] + R[3 * c + 1] * u2[1] + R[3 * c + 2] * u2[2];
+        }
         const double pu = p[0] * u0[0] + p[1] * u0[1] + p[2] * u0[2];
-        double gm[3][9];
-        {
-          const double wa[4] = {r3[0], r3[1], r3[2], pu};
-          double g1a[3][9];
-          g1_top(wa, g1a);
-          double ru1[3], ru2[3];     // R^T u_k  (u_k^T R)
+        const double st = pu - vu0;
+        // row j of g1_top(w) as a dense 9-vector (the zeros are literals: they cost no register)
+        auto g1row = [&](int j, double w3, double x[9]) {
 #pragma unroll
-          for (int c = 0; c < 3; c++) {
-            ru1[c] = R[3 * c] * u1[0] + R[3 * c + 1] * u1[1] + R[3 * c + 2] * u1[2];
-            ru2[c] = R[3 * c] * u2[0] + R[3 * c + 1] * u2[1] + R[3 * c + 2] * u2[2];
-          }
-          const double pv1 = (p[0] - vbar[0]) * u1[0] + (p[1] - vbar[1]) * u1[1] + (p[2] - vbar[2]) * u1[2];
-          const double pv2 = (p[0] - vbar[0]) * u2[0] + (p[1] - vbar[1]) * u2[1] + (p[2] - vbar[2]) * u2[2];
-#pragma unroll
-          for (int c = 0; c < 9; c++) {
-            double e1 = ru1[0] * g1a[0][c] + ru1[1] * g1a[1][c] + ru1[2] * g1a[2][c];
-            double e2 = ru2[0] * g1a[0][c] + ru2[1] * g1a[1][c] + ru2[2] * g1a[2][c];
-            if (c >= 6) {
-              e1 += pv1 * r3[c - 6] - vu0 * ru1[c - 6];
-              e2 += pv2 * r3[c - 6] - vu0 * ru2[c - 6];
-            }
-            gm[0][c] = k1 * e1;
-            gm[1][c] = k2 * e2;
-            gm[2][c] = c >= 6 ? r3[c - 6] : 0.0;
-          }
-        }
-        // D = (2/NN) U_0 Y (6x9),  Y = T_j g1([r3; (p - vbar).u0]) (4x9), U_0 = [[hat(-u0), 0], [0, u0]]    (:449-450)
-        //   Y[:3] = R g1t[:3] + p (x) [0..0 r3],  Y[3] = [0 0 0 0 0 0 r3]
-        // everything downstream is done on the 4-row Y and lifted through U_0 at the end
-        double Y[3][9];
-        {
-          const double st = pu - vu0;
-          const double wt[4] = {r3[0], r3[1], r3[2], st};
-          double g1t[3][9];
-          g1_top(wt, g1t);
-#pragma unroll
-          for (int c = 0; c < 9; c++)
-#pragma unroll
-            for (int r = 0; r < 3; r++) {
-              double y = R[r] * g1t[0][c] + R[3 + r] * g1t[1][c] + R[6 + r] * g1t[2][c];
-              if (c >= 6) y += p[r] * r3[c - 6];
-              Y[r][c] = y;
-            }
-        }
+          for (int c = 0; c < 9; c++) x[c] = 0.0;
+          if (j == 0) { x[0] = r3[0]; x[1] = r3[1]; x[2] = r3[2]; x[6] = w3; }
+          else if (j == 1) { x[1] = r3[0]; x[3] = r3[1]; x[4] = r3[2]; x[7] = w3; }
+          else { x[2] = r3[0]; x[4] = r3[1]; x[5] = r3[2]; x[8] = w3; }
+        };
+        // x . (row j of g1_top(w)): four terms
+        auto g1dot = [&](int j, double w3, const double x[9]) {
+          return j == 0 ? r3[0] * x[0] + r3[1] * x[1] + r3[2] * x[2] + w3 * x[6]
+               : j == 1 ? r3[0] * x[1] + r3[1] * x[3] + r3[2] * x[4] + w3 * x[7]
+                        : r3[0] * x[2] + r3[1] * x[4] + r3[2] * x[5] + w3 * x[8];
+        };
         // products with the cluster's 9x9 noise covariance (symmetric): explicit matrix, or the isotropic closed form
         double cc[EXPLICIT ? 9 : 1][9];
         if (EXPLICIT) {
@@ -221,70 +201,91 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             iso_cov_mv(P, v, N, sigma2, x, y);
           }
         };
-        double sg[9][3];                       // c_cov Gm^T  (Gm row 2 = [0 0 0 0 0 0 r3])
+        // c_cov Gm^T ONE COLUMN AT A TIME: a column feeds its part of Q (Gm's rows r <= k against it), its column of Rr (through G1 and T_j)
+        // and -- the third -- N4's corner, then it is dead: 9 registers instead of round 5's 27.
+        // Gm's dense rows: gm_k[c] = k_k (ru_k . g1_top([r3; pu])[:, c] (+ the v-part's extras)); row 2 = [0 .. 0 r3]
+        double n33;
         {
-          double col[9];
-          covmv(gm[0], col);
+          const double pv1 = (p[0] - vbar[0]) * u1[0] + (p[1] - vbar[1]) * u1[1] + (p[2] - vbar[2]) * u1[2];
+          const double pv2 = (p[0] - vbar[0]) * u2[0] + (p[1] - vbar[1]) * u2[1] + (p[2] - vbar[2]) * u2[2];
+          double gmq[2][9];
 #pragma unroll
-          for (int r = 0; r < 9; r++) sg[r][0] = col[r];
-          covmv(gm[1], col);
+          for (int k = 0; k < 2; k++) {
+            const double *ru = k == 0 ? ru1 : ru2;
+            const double kk = k == 0 ? k1 : k2, pv = k == 0 ? pv1 : pv2;
+            double *g = gmq[k];
+            g[0] = kk * (ru[0] * r3[0]);
+            g[1] = kk * (ru[0] * r3[1] + ru[1] * r3[0]);
+            g[2] = kk * (ru[0] * r3[2] + ru[2] * r3[0]);
+            g[3] = kk * (ru[1] * r3[1]);
+            g[4] = kk * (ru[1] * r3[2] + ru[2] * r3[1]);
+            g[5] = kk * (ru[2] * r3[2]);
 #pragma unroll
-          for (int r = 0; r < 9; r++) sg[r][1] = col[r];
-          covmv(gm[2], col);
-#pragma unroll
-          for (int r = 0; r < 9; r++) sg[r][2] = col[r];
-        }
-        {
-          int t = 0;
-#pragma unroll
-          for (int r = 0; r < 3; r++)
-#pragma unroll
-            for (int k = r; k < 3; k++) {
-              double s = 0.0;
-#pragma unroll
-              for (int c = (r == 2 ? 6 : 0); c < 9; c++) s += gm[r][c] * sg[c][k];
-              q[t++] += s;
-            }
-        }
-        // Rr = D c_cov Gm^T = c2 U_0 (Y sg):  rows 0..2 = (Y[:3] sg) x u0 per column, rows 3..5 = u0 (Y[3] sg)
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-          double ys[3];
-#pragma unroll
-          for (int r = 0; r < 3; r++) {
-            double s = 0.0;
-#pragma unroll
-            for (int c = 0; c < 9; c++) s += Y[r][c] * sg[c][k];
-            ys[r] = s;
+            for (int c = 0; c < 3; c++) g[6 + c] = kk * (ru[c] * pu + pv * r3[c] - vu0 * ru[c]);
           }
-          const double y3 = r3[0] * sg[6][k] + r3[1] * sg[7][k] + r3[2] * sg[8][k];
-          double yx[3];
-          cross3(ys, u0, yx);                  // hat(-u0) y = y x u0
+          const double m9[9] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, r3[0], r3[1], r3[2]};
+          // q's order: (0,0) (0,1) (0,2) (1,1) (1,2) (2,2)
+          const int qi[3][3] = {{0, 1, 2}, {-1, 3, 4}, {-1, -1, 5}};
 #pragma unroll
-          for (int r = 0; r < 3; r++) { rr[r][k] = c2 * yx[r]; rr[3 + r][k] = c2 * u0[r] * y3; }
-        }
-        // S_j = D c_cov D^T = c2^2 U_0 M U_0^T,  M = Y4 c_cov Y4^T (4x4 symmetric)
-        {
-          double M[4][4];
+          for (int k = 0; k < 3; k++) {
+            double col[9];
+            covmv(k == 0 ? gmq[0] : (k == 1 ? gmq[1] : m9), col);
 #pragma unroll
-          for (int r = 0; r < 4; r++) {
-            double e[9];                       // row r of Y4 c_cov (c_cov symmetric; row 3 of Y4 is Gm's row 2)
-            if (r < 3) covmv(Y[r], e);
-            else {
+            for (int r = 0; r <= k; r++) {
+              double sum = 0.0;
+              if (r < 2) {
 #pragma unroll
-              for (int c = 0; c < 9; c++) e[c] = sg[c][2];
-            }
-#pragma unroll
-            for (int k = r; k < 4; k++) {
-              double m = 0.0;
-              if (k < 3) {
-#pragma unroll
-                for (int c = 0; c < 9; c++) m += e[c] * Y[k][c];
+                for (int c = 0; c < 9; c++) sum += gmq[r][c] * col[c];
               } else {
-                m = e[6] * r3[0] + e[7] * r3[1] + e[8] * r3[2];
+                sum = r3[0] * col[6] + r3[1] * col[7] + r3[2] * col[8];
               }
-              M[r][k] = M[k][r] = m;
+              q[qi[r][k]] += sum;
             }
+            // Rr[:, k] = c2 U_0 (T_j (G1 col)):  rows 0..2 = (R (G1top col) + p (r3 . col[6..8])) x u0, rows 3..5 = u0 (r3 . col[6..8])
+            const double t0 = g1dot(0, st, col), t1 = g1dot(1, st, col), t2 = g1dot(2, st, col);
+            const double y3 = r3[0] * col[6] + r3[1] * col[7] + r3[2] * col[8];
+            double ys[3];
+#pragma unroll
+            for (int r = 0; r < 3; r++) ys[r] = R[r] * t0 + R[3 + r] * t1 + R[6 + r] * t2 + p[r] * y3;
+            double yx[3];
+            cross3(ys, u0, yx);                  // hat(-u0) y = y x u0
+#pragma unroll
+            for (int r = 0; r < 3; r++) { rr[r][k] = c2 * yx[r]; rr[3 + r][k] = c2 * u0[r] * y3; }
+            if (k == 2) n33 = y3;                // m . c_cov m
+          }
+        }
+        // S_j = D c_cov D^T = c2^2 U_0 M U_0^T,  M = Y4 c_cov Y4^T = T_j N4 T_j^T,  N4 = G1 c_cov G1^T (4x4 symmetric)
+        {
+          double n00, n01, n02, n03, n11, n12, n13, n22, n23;
+          {
+            double x[9], f[9];
+            g1row(0, st, x); covmv(x, f);
+            n00 = g1dot(0, st, f); n01 = g1dot(1, st, f); n02 = g1dot(2, st, f); n03 = r3[0] * f[6] + r3[1] * f[7] + r3[2] * f[8];
+            g1row(1, st, x); covmv(x, f);
+            n11 = g1dot(1, st, f); n12 = g1dot(2, st, f); n13 = r3[0] * f[6] + r3[1] * f[7] + r3[2] * f[8];
+            g1row(2, st, x); covmv(x, f);
+            n22 = g1dot(2, st, f); n23 = r3[0] * f[6] + r3[1] * f[7] + r3[2] * f[8];
+          }
+          const double N3[3][3] = {{n00, n01, n02}, {n01, n11, n12}, {n02, n12, n22}}, n3[3] = {n03, n13, n23};
+          double M[4][4];
+          {
+            double A3[3][3], Rn[3];              // A3 = R N3,  Rn = R n3
+#pragma unroll
+            for (int r = 0; r < 3; r++) {
+#pragma unroll
+              for (int c = 0; c < 3; c++) A3[r][c] = R[r] * N3[0][c] + R[3 + r] * N3[1][c] + R[6 + r] * N3[2][c];
+              Rn[r] = R[r] * n3[0] + R[3 + r] * n3[1] + R[6 + r] * n3[2];
+            }
+#pragma unroll
+            for (int r = 0; r < 3; r++) {
+#pragma unroll
+              for (int c = r; c < 3; c++) {
+                const double m = A3[r][0] * R[c] + A3[r][1] * R[3 + c] + A3[r][2] * R[6 + c] + Rn[r] * p[c] + p[r] * Rn[c] + n33 * p[r] * p[c];
+                M[r][c] = M[c][r] = m;
+              }
+              M[r][3] = M[3][r] = Rn[r] + n33 * p[r];
+            }
+            M[3][3] = n33;
           }
           // top-left: K M33 K^T with K = hat(-u0) (K y = y x u0); top-right: (K M[:3][3]) u0^T; bottom-right: M33' = M[3][3] u0 u0^T
           double KM[3][3];                     // column c of K M33: M33[:, c] x u0
