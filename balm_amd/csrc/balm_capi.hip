@@ -422,7 +422,7 @@ int feature_bookkeeping(balm_ctx *ctx, int F, const unsigned char *obs, const do
   double S = 0, B = 0;
   int bad_a = F, bad_rc = BALM_OK;          // the first offending feature, whichever thread meets it
   std::mutex mu;
-  parallel_ranges((size_t)F, (size_t)((1 << 20) / W + 1), [&](size_t lo, size_t hi) {
+  parallel_ranges((size_t)F, (size_t)(65536 / W + 1), [&](size_t lo, size_t hi) {
     std::vector<int> ppp((size_t)W, 0);
     double s = 0, b = 0;
     int my_bad = F, my_rc = BALM_OK;
@@ -599,7 +599,7 @@ static int build_sparse_plan(balm_ctx *ctx, int F, const unsigned char *obs) {
                                                          //  sliding window installs a table per slide: the plan's host time is not free)
   struct Key { uint64_t hi, lo; int a; };
   std::vector<Key> keys((size_t)F);
-  parallel_ranges((size_t)F, (size_t)((1 << 20) / W + 1), [&](size_t a0, size_t a1) {       // (a megabyte of flags per piece: the shipped window's 400 KB stay on this thread)
+  parallel_ranges((size_t)F, (size_t)(65536 / W + 1), [&](size_t a0, size_t a1) {       // (pieces of 64 KB of flags; the shipped window's 400 KB on ONE thread: 0.3 ms, measured round 6)
     for (size_t a = a0; a < a1; a++) {
       uint64_t hi = 0, lo = 0;
       const unsigned char *oa = obs + a * W;
@@ -672,13 +672,12 @@ static int build_sparse_plan(balm_ctx *ctx, int F, const unsigned char *obs) {
   if ((rc = keep(ctx, &ctx->d_slot, &ctx->cap_slot, (size_t)F)) || (rc = keep(ctx, &ctx->d_items, &ctx->cap_items, sorted_items.size())) ||
       (rc = keep(ctx, &ctx->d_chunk_ids, &ctx->cap_chunk_ids, chunk_ids.size())) || (rc = keep(ctx, &ctx->d_csr, &ctx->cap_csr, csr.size())))
     return rc;
-  // (stream-ordered copies out of pageable vectors: the runtime stages them before it returns -- four blocking hipMemcpy were 0.15 of the
-  //  0.5 ms this function took per association of the shipped window; whoever uses the plan is on the same stream)
-  HIP_TRY(hipMemcpyAsync(ctx->d_slot, slot.data(), slot.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
-  HIP_TRY(hipMemcpyAsync(ctx->d_items, sorted_items.data(), sorted_items.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
-  HIP_TRY(hipMemcpyAsync(ctx->d_chunk_ids, chunk_ids.data(), chunk_ids.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
-  HIP_TRY(hipMemcpyAsync(ctx->d_csr, csr.data(), csr.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
-  HIP_TRY(hipStreamSynchronize(ctx->stream));               // (the vectors die with this frame)
+  // (blocking copies of a few KB each.  Stream-ordered copies out of the pageable vectors + one synchronise were measured in their place in
+  //  round 6: 1.10 instead of 0.49 ms for this function on the shipped window -- the runtime's asynchronous pageable path is the slow one)
+  HIP_TRY(hipMemcpy(ctx->d_slot, slot.data(), slot.size() * sizeof(int), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(ctx->d_items, sorted_items.data(), sorted_items.size() * sizeof(int), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(ctx->d_chunk_ids, chunk_ids.data(), chunk_ids.size() * sizeof(int), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(ctx->d_csr, csr.data(), csr.size() * sizeof(int), hipMemcpyHostToDevice));
   ctx->sparse = true; ctx->sp_nsteps = nsteps; ctx->sp_nchunks = nchunks; ctx->sp_nitems = run; ctx->sp_steps = sparse_steps;
   return BALM_OK;
 }

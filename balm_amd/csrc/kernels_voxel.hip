@@ -361,20 +361,32 @@ __global__ __launch_bounds__(256) void k_seg_clusters(const float *__restrict__ 
     xn[0] = xyz[3 * pn]; xn[1] = xyz[3 * pn + 1]; xn[2] = xyz[3 * pn + 2];
     pn = idx[min(i + 128 + lane, i1 - 1)];
     const PointTerms t = point_terms(x, P);
+    // the chunk padded with +0.0 (x + 0.0 = x bit for bit for every x these sums can hold) and ONE fully unrolled chain of 64 additions
+    // whose LDS reads run sixteen values ahead -- k_seg_wave's add phase (round 5).  The rolled loop with its tail paid an LDS round trip
+    // per eight additions, ~1.5 us per chunk: the longest segment of a scan set the launch's length (23.6 us, 2.75 times per
+    // balm_window_add_scan).
+    const bool in = lane < cnt;
 #pragma unroll
-    for (int c = 0; c < SEG_TERMS; c++) mine[c * SEG_LD + lane] = t.t[c];
+    for (int c = 0; c < SEG_TERMS; c++) mine[c * SEG_LD + lane] = in ? t.t[c] : 0.0;
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_s_waitcnt(0xc07f);        // lgkmcnt(0): the wave's LDS writes have landed
-    const double *colp = mine + col * SEG_LD;
-    int l = 0;
-    for (; l + 8 <= cnt; l += 8) {
-      double v[8];
+    if (lane < SEG_TERMS) {
+      const double *colp = mine + col * SEG_LD;
+      double va[16], vb[16];
 #pragma unroll
-      for (int u = 0; u < 8; u++) v[u] = colp[l + u];
+      for (int u = 0; u < 16; u++) va[u] = colp[u];
 #pragma unroll
-      for (int u = 0; u < 8; u++) acc = __dadd_rn(acc, v[u]);
+      for (int b = 0; b < 4; b++) {
+        if (b < 3) {
+#pragma unroll
+          for (int u = 0; u < 16; u++) vb[u] = colp[16 * (b + 1) + u];
+        }
+#pragma unroll
+        for (int u = 0; u < 16; u++) acc = __dadd_rn(acc, va[u]);
+#pragma unroll
+        for (int u = 0; u < 16; u++) va[u] = vb[u];
+      }
     }
-    for (; l < cnt; l++) acc = __dadd_rn(acc, colp[l]);
     __builtin_amdgcn_wave_barrier();
   }
   if (lane < 9) seg_body[s * 10 + lane] = acc;
