@@ -1064,55 +1064,8 @@ struct NodeTot {
   int nobs;            // scans that stay and observe the node
 };
 
-// node totals: the per-frame world clusters added in frame order (= judge_eigen's `covMat += sig_tran[i]`);
-// 16 lanes per node, lane c < 10 owns component c (coalesced 80-byte rows)
-__global__ __launch_bounds__(256) void k_node_totals(const double *__restrict__ seg_world,
-                                                     const unsigned long long *__restrict__ seg_ck,
-                                                     const unsigned int *__restrict__ node_seg, long NN, int fix_frames,
-                                                     NodeTot *__restrict__ tot) {
-  const long j = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
-  const int c = threadIdx.x & 15;
-  if (j >= NN) return;
-  const unsigned int s0 = node_seg[j], s1 = node_seg[j + 1];
-  if (fix_frames == 0) {                 // the benchmark drivers' case: nothing is marginalised
-    if (c < 10) {
-      double t = 0.0;
-      unsigned int s = s0;
-      for (; s + 8 <= s1; s += 8) {             // loads of eight scans in flight, the sum stays in scan order
-        double v[8];
-#pragma unroll
-        for (int u = 0; u < 8; u++) v[u] = seg_world[(size_t)(s + u) * 10 + c];
-#pragma unroll
-        for (int u = 0; u < 8; u++) t = __dadd_rn(t, v[u]);
-      }
-      for (; s < s1; s++) t = __dadd_rn(t, seg_world[(size_t)s * 10 + c]);
-      tot[j].c[c] = t;
-      tot[j].fixc[c] = 0.0;
-      if (c == 9) tot[j].nrest = t;
-    } else if (c == 10) {
-      tot[j].nobs = (int)(s1 - s0);
-    }
-    return;
-  }
-  if (c < 10) {
-    double t = 0.0, fx = 0.0;
-    for (unsigned int s = s0; s < s1; s++) {
-      const double v = seg_world[(size_t)s * 10 + c];
-      t = __dadd_rn(t, v);
-      if ((int)(seg_ck[s] & 511ull) < fix_frames) fx = __dadd_rn(fx, v);
-    }
-    tot[j].c[c] = t;
-    tot[j].fixc[c] = fx;
-  } else if (c == 10) {
-    double nrest = 0.0;
-    int nobs = 0;
-    for (unsigned int s = s0; s < s1; s++)
-      if ((int)(seg_ck[s] & 511ull) >= fix_frames) { nrest += seg_world[(size_t)s * 10 + 9]; nobs++; }
-    tot[j].nrest = nrest;
-    tot[j].nobs = nobs;
-  }
-}
-
+// (node totals: the per-frame world clusters added in frame order = judge_eigen's `covMat += sig_tran[i]`; 16 lanes per node, lane c < 10
+// owns component c -- k_node_totals_status below)
 // eigenvalues of a symmetric 3x3 (cyclic Jacobi, same rotation order as the host restatement the tests compare it with)
 __device__ void eigvals3(double a00, double a01, double a02, double a11, double a12, double a22, double lam[3]) {
   for (int sweep = 0; sweep < 60; sweep++) {
@@ -1179,19 +1132,70 @@ __device__ void eig3_vec(double a00, double a01, double a02, double a11, double 
   nrm[0] = V[0][i0]; nrm[1] = V[1][i0]; nrm[2] = V[2][i0];
 }
 
-// plane[j] (strict mode only): normal(3), centre(3) of the candidate planes, for the distance pass
-__global__ __launch_bounds__(128) void k_node_status(const NodeTot *__restrict__ tot, long NN, float thr, VoxParams pr,
-                                                     unsigned char *__restrict__ status, double *__restrict__ plane) {
-  const long j = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= NN) return;
-  const NodeTot t = tot[j];
+__device__ __forceinline__ int node_status_of(const double c[10], float thr, const VoxParams &pr, double *__restrict__ pl);
+
+// k_node_totals and k_node_status in ONE launch (round 6: one launch less per level): the sixteen lanes of a node form its totals as
+// k_node_totals does, hand the ten components to the node's first lane (shuffles inside the 16-lane group), which judges the plane
+__global__ __launch_bounds__(256) void k_node_totals_status(const double *__restrict__ seg_world, const unsigned long long *__restrict__ seg_ck,
+                                                            const unsigned int *__restrict__ node_seg, long NN, int fix_frames,
+                                                            NodeTot *__restrict__ tot, float thr, VoxParams pr,
+                                                            unsigned char *__restrict__ status, double *__restrict__ plane) {
+  const long j = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+  const int c = threadIdx.x & 15;
+  const bool live = j < NN;
+  double t = 0.0;
+  if (live) {
+    const unsigned int s0 = node_seg[j], s1 = node_seg[j + 1];
+    if (fix_frames == 0) {
+      if (c < 10) {
+        unsigned int sgi = s0;
+        for (; sgi + 8 <= s1; sgi += 8) {             // loads of eight scans in flight, the sum stays in scan order
+          double v[8];
+#pragma unroll
+          for (int u = 0; u < 8; u++) v[u] = seg_world[(size_t)(sgi + u) * 10 + c];
+#pragma unroll
+          for (int u = 0; u < 8; u++) t = __dadd_rn(t, v[u]);
+        }
+        for (; sgi < s1; sgi++) t = __dadd_rn(t, seg_world[(size_t)sgi * 10 + c]);
+        tot[j].c[c] = t;
+        tot[j].fixc[c] = 0.0;
+        if (c == 9) tot[j].nrest = t;
+      } else if (c == 10) {
+        tot[j].nobs = (int)(s1 - s0);
+      }
+    } else if (c < 10) {
+      double fx = 0.0;
+      for (unsigned int sgi = s0; sgi < s1; sgi++) {
+        const double v = seg_world[(size_t)sgi * 10 + c];
+        t = __dadd_rn(t, v);
+        if ((int)(seg_ck[sgi] & 511ull) < fix_frames) fx = __dadd_rn(fx, v);
+      }
+      tot[j].c[c] = t;
+      tot[j].fixc[c] = fx;
+    } else if (c == 10) {
+      double nrest = 0.0;
+      int nobs = 0;
+      for (unsigned int sgi = s0; sgi < s1; sgi++)
+        if ((int)(seg_ck[sgi] & 511ull) >= fix_frames) { nrest += seg_world[(size_t)sgi * 10 + 9]; nobs++; }
+      tot[j].nrest = nrest;
+      tot[j].nobs = nobs;
+    }
+  }
+  double cc[10];
+#pragma unroll
+  for (int k = 0; k < 10; k++) cc[k] = __shfl(t, k, 16);           // (every lane of the wavefront takes part; lanes 10..15 hold junk nobody asks for)
+  if (live && c == 0) status[j] = (unsigned char)node_status_of(cc, thr, pr, plane ? plane + (size_t)j * 6 : nullptr);
+}
+
+// a node's verdict from its world cluster c[10]; pl (strict mode only): normal(3), centre(3) of the candidate plane, for the distance pass
+__device__ __forceinline__ int node_status_of(const double c[10], float thr, const VoxParams &pr, double *__restrict__ pl) {
   int st = NODE_DEAD;
-  if ((int)t.c[9] > pr.min_ps) {
-    const double n = t.c[9], cx = t.c[6] / n, cy = t.c[7] / n, cz = t.c[8] / n;
+  if ((int)c[9] > pr.min_ps) {
+    const double n = c[9], cx = c[6] / n, cy = c[7] / n, cz = c[8] / n;
     double lam[3];
-    const double a00 = t.c[0] / n - cx * cx, a01 = t.c[1] / n - cx * cy, a02 = t.c[2] / n - cx * cz, a11 = t.c[3] / n - cy * cy,
-                 a12 = t.c[4] / n - cy * cz, a22 = t.c[5] / n - cz * cz;
-    if (!plane) {
+    const double a00 = c[0] / n - cx * cx, a01 = c[1] / n - cx * cy, a02 = c[2] / n - cx * cz, a11 = c[3] / n - cy * cy,
+                 a12 = c[4] / n - cy * cz, a22 = c[5] / n - cz * cz;
+    if (!pl) {
       eigvals3(a00, a01, a02, a11, a12, a22, lam);
       st = lam[0] / lam[1] < (double)thr ? NODE_PLANE : NODE_SPLIT;
     } else {
@@ -1200,11 +1204,10 @@ __global__ __launch_bounds__(128) void k_node_status(const NodeTot *__restrict__
       const bool ok = lam[0] / lam[1] < (double)thr && (pr.ratio21_max <= 0 || lam[2] / lam[1] < pr.ratio21_max) &&
                       (pr.lam0_max <= 0 || lam[0] < pr.lam0_max);
       st = ok ? NODE_PLANE : NODE_SPLIT;
-      double *pl = plane + (size_t)j * 6;
       pl[0] = nrm[0]; pl[1] = nrm[1]; pl[2] = nrm[2]; pl[3] = cx; pl[4] = cy; pl[5] = cz;
     }
   }
-  status[j] = (unsigned char)st;
+  return st;
 }
 
 // strict mode: a candidate plane with a point farther than max_dis from it is not a plane (BAs_left.hpp:658-674).
@@ -1237,13 +1240,23 @@ __global__ void k_point_nodes(const unsigned int *__restrict__ idx, const unsign
 // recut's descent (bavoxel.hpp:737-776) + tras_opt / push_voxel (:908-929, :30-37): a node is a feature when
 // every ancestor was split, it is a plane with more than min_ps points, the scans that stay hold at least min_ps
 // of them and at least min_observers of those scans observe it
-__global__ void k_feature_flags(int level, long NN, const NodeTot *__restrict__ tot, const unsigned char *__restrict__ st0,
+// Round 6: ONE launch for the (up to) three levels -- their node lists laid end to end, each followed by a zero entry -- and ONE exclusive
+// scan behind it: a node's scanned value is its feature's index in the table (level 0's features first, then level 1's, then level 2's),
+// the values at the three zero entries are the running feature counts.  (Three flag launches + three library scans of two launches each before.)
+struct FlagLevels { long NN[3], off[3]; const NodeTot *tot[3]; };
+__global__ void k_feature_flags(FlagLevels fl, int levels, const unsigned char *__restrict__ st0,
                                 const unsigned char *__restrict__ st1, const unsigned char *__restrict__ st2,
                                 const unsigned int *__restrict__ parent1, const unsigned int *__restrict__ parent2,
-                                VoxParams pr, unsigned int *__restrict__ flag) {
-  const long j = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (j == 0) flag[NN] = 0u;                                         // (the scan behind this kernel runs over NN + 1 entries)
-  if (j >= NN) return;
+                                VoxParams pr, unsigned int *__restrict__ flag_all) {
+  const long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  int level = 0;
+  if (levels > 1 && g >= fl.off[1]) level = 1;
+  if (levels > 2 && g >= fl.off[2]) level = 2;
+  const long j = g - fl.off[level], NN = fl.NN[level];
+  if (j > NN) return;
+  unsigned int *flag = flag_all + fl.off[level];
+  if (j == NN) { flag[NN] = 0u; return; }
+  const NodeTot *tot = fl.tot[level];
   bool live;
   if (level == 0) live = st0[j] == NODE_PLANE;
   else if (level == 1) live = st1[j] == NODE_PLANE && st0[parent1[j]] == NODE_SPLIT;
@@ -1274,11 +1287,22 @@ __global__ void k_point_features(long n, int levels, const unsigned int *__restr
 
 // per-(feature, pose) body clusters = the feature node's own segments (sig_orig) of the scans that stay, shifted by
 // the marginalised ones: one lane per (segment, component)
-__global__ __launch_bounds__(256) void k_emit_segments(long NS, const unsigned int *__restrict__ nid_incl,
-                                                       const unsigned int *__restrict__ flag, const unsigned int *__restrict__ fid_excl,
-                                                       unsigned int fid_base, const unsigned long long *__restrict__ seg_ck,
-                                                       const double *__restrict__ seg_body, int Wout, int fix_frames,
-                                                       double *__restrict__ out) {
+// (round 6: the level's nodes ride in the same launch -- blocks [seg_blocks, ...) are k_emit_nodes' -- and fid_excl is the feature's index
+// in the whole table already, k_feature_flags' one scan over all levels)
+__device__ __forceinline__ void emit_node(long j, int c, const unsigned int *__restrict__ flag, const unsigned int *__restrict__ fid_excl,
+                                          const NodeTot *__restrict__ tot, int layer, double *__restrict__ coe, double *__restrict__ fixout,
+                                          int *__restrict__ layer_out);
+__global__ __launch_bounds__(256) void k_emit_level(long NS, int seg_blocks, const unsigned int *__restrict__ nid_incl,
+                                                    const unsigned int *__restrict__ flag, const unsigned int *__restrict__ fid_excl,
+                                                    const unsigned long long *__restrict__ seg_ck,
+                                                    const double *__restrict__ seg_body, int Wout, int fix_frames,
+                                                    double *__restrict__ out, long NN, const NodeTot *__restrict__ tot, int layer,
+                                                    double *__restrict__ coe, double *__restrict__ fixout, int *__restrict__ layer_out) {
+  if ((int)blockIdx.x >= seg_blocks) {
+    const long tn = ((long)blockIdx.x - seg_blocks) * blockDim.x + threadIdx.x;
+    if ((tn >> 4) < NN) emit_node(tn >> 4, (int)(tn & 15), flag, fid_excl, tot, layer, coe, fixout, layer_out);
+    return;
+  }
   const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const long s = t >> 4;
   const int c = (int)(t & 15);
@@ -1287,20 +1311,17 @@ __global__ __launch_bounds__(256) void k_emit_segments(long NS, const unsigned i
   if (!flag[j]) return;
   const int fr = (int)(seg_ck[s] & 511ull) - fix_frames;
   if (fr < 0) return;
-  const size_t f = fid_base + fid_excl[j];
+  const size_t f = fid_excl[j];
   out[(f * Wout + (size_t)fr) * 10 + c] = seg_body[(size_t)s * 10 + c];
 }
 
 // per feature: weight = sum_i N_i over the scans that stay (VOX_HESS::push_voxel, bavoxel.hpp:42-44), fix cluster =
 // the marginalised scans' world cluster, octree layer
-__global__ __launch_bounds__(256) void k_emit_nodes(long NN, const unsigned int *__restrict__ flag,
-                                                    const unsigned int *__restrict__ fid_excl, unsigned int fid_base,
-                                                    const NodeTot *__restrict__ tot, int layer, double *__restrict__ coe,
-                                                    double *__restrict__ fixout, int *__restrict__ layer_out) {
-  const long j = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
-  const int c = threadIdx.x & 15;
-  if (j >= NN || !flag[j]) return;
-  const size_t f = fid_base + fid_excl[j];
+__device__ __forceinline__ void emit_node(long j, int c, const unsigned int *__restrict__ flag, const unsigned int *__restrict__ fid_excl,
+                                          const NodeTot *__restrict__ tot, int layer, double *__restrict__ coe, double *__restrict__ fixout,
+                                          int *__restrict__ layer_out) {
+  if (!flag[j]) return;
+  const size_t f = fid_excl[j];
   if (c < 10) fixout[f * 10 + c] = tot[j].fixc[c];
   else if (c == 10) { coe[f] = tot[j].nrest; layer_out[f] = layer; }
 }
@@ -1780,15 +1801,12 @@ int associate_device(hipStream_t s, const float *d_xyz, const int *d_frame, cons
     v.node_parent = sc.get<unsigned int>(v.NN);
     v.tot = sc.get<NodeTot>(v.NN);
     v.status = sc.get<unsigned char>(v.NN);
-    v.flag = sc.get<unsigned int>(v.NN + 1);
-    v.fid = sc.get<unsigned int>(v.NN + 1);
     double *plane = strict ? sc.get<double>((size_t)v.NN * 6) : nullptr;
     if (!sc.ok) return -1;
     hipLaunchKernelGGL(k_level_heads, dim3(grid_for(v.NS, B)), dim3(B), 0, s, v.seg_ck, st.nid, st.pid, v.NS, pshift, v.node_seg,
                        v.node_parent);
-    hipLaunchKernelGGL(k_node_totals, dim3(grid_for(v.NN * 16, B)), dim3(B), 0, s, st.seg_world, v.seg_ck, v.node_seg, v.NN,
-                       o.fix_frames, v.tot);
-    hipLaunchKernelGGL(k_node_status, dim3(grid_for(v.NN, 128)), dim3(128), 0, s, v.tot, v.NN, pr.thr[L], pr, v.status, plane);
+    hipLaunchKernelGGL(k_node_totals_status, dim3(grid_for(v.NN * 16, B)), dim3(B), 0, s, st.seg_world, v.seg_ck, v.node_seg, v.NN,
+                       o.fix_frames, v.tot, pr.thr[L], pr, v.status, plane);
     if (strict && o.max_dis > 0)
       hipLaunchKernelGGL(k_point_plane_dist, dim3(grid_for(st.nL, B)), dim3(B), 0, s, d_xyz, scan, d_poses, st.idx, st.incl, st.nid, st.nL, plane,
                          o.max_dis, v.status);
@@ -1890,24 +1908,26 @@ int associate_device(hipStream_t s, const float *d_xyz, const int *d_frame, cons
   }
   if (lv[0].NN != NR) return -1;
   unsigned int FL[3] = {0, 0, 0};
-  for (int L = 0; L < levels; L++) {
-    if (lv[L].NN == 0) continue;                  // (the fast path's levels 1 and 2 when no root was split)
-    hipLaunchKernelGGL(k_feature_flags, dim3(grid_for(lv[L].NN, B)), dim3(B), 0, s, L, lv[L].NN, lv[L].tot, lv[0].status,
-                       lv[1].status, lv[2].status, lv[1].node_parent, lv[2].node_parent, pr, lv[L].flag);
-    scan_excl(sc, s, lv[L].flag, lv[L].fid, lv[L].NN + 1);
-  }
-  if (!sc.ok) return -1;
   {
-    const unsigned int *src[4] = {nullptr, nullptr, nullptr, nullptr};
-    int live_levels = 0;
-    for (int L = 0; L < levels; L++) if (lv[L].NN > 0) { src[L] = lv[L].fid + lv[L].NN; live_levels++; }
-    if (live_levels > 0) {
-      const unsigned int *any = src[0] ? src[0] : (src[1] ? src[1] : src[2]);
-      for (int k = 0; k < 4; k++) if (!src[k]) src[k] = any;
-      unsigned int got[4] = {0, 0, 0, 0};
-      if (!mail_u32x4(s, mail, src, got)) return -1;
-      for (int L = 0; L < levels; L++) if (lv[L].NN > 0) FL[L] = got[L];
+    // every level's nodes (a level without nodes -- no root was split -- is an empty stretch) + its zero entry, end to end
+    FlagLevels fl;
+    long total = 0;
+    for (int L = 0; L < 3; L++) {
+      fl.NN[L] = L < levels ? lv[L].NN : 0; fl.tot[L] = lv[L].tot; fl.off[L] = total;
+      if (L < levels) total += fl.NN[L] + 1;
     }
+    auto *flag_all = sc.get<unsigned int>(total), *fid_all = sc.get<unsigned int>(total);
+    if (!sc.ok) return -1;
+    for (int L = 0; L < levels; L++) { lv[L].flag = flag_all + fl.off[L]; lv[L].fid = fid_all + fl.off[L]; }
+    hipLaunchKernelGGL(k_feature_flags, dim3(grid_for(total, B)), dim3(B), 0, s, fl, levels, lv[0].status, lv[1].status, lv[2].status,
+                       lv[1].node_parent, lv[2].node_parent, pr, flag_all);
+    scan_excl(sc, s, flag_all, fid_all, total);
+    if (!sc.ok) return -1;
+    const unsigned int *src[4];
+    for (int k = 0; k < 4; k++) src[k] = fid_all + fl.off[k < levels ? k : levels - 1] + fl.NN[k < levels ? k : levels - 1];     // the zero entries: running counts
+    unsigned int got[4] = {0, 0, 0, 0};
+    if (!mail_u32x4(s, mail, src, got)) return -1;
+    for (int L = 0; L < levels; L++) FL[L] = got[L] - (L ? got[L - 1] : 0u);
   }
   const long F = (long)FL[0] + FL[1] + FL[2];
   *n_roots = NR;
@@ -1936,17 +1956,15 @@ int associate_device(hipStream_t s, const float *d_xyz, const int *d_frame, cons
       return fail();
   }
   hipMemsetAsync(out, 0, (size_t)F * Wout * 10 * sizeof(double), s);
-  unsigned int base[3] = {0, FL[0], FL[0] + FL[1]};
   for (int L = 0; L < levels; L++) {
     if (lv[L].NN == 0 || FL[L] == 0) continue;
-    hipLaunchKernelGGL(k_emit_segments, dim3(grid_for(lv[L].NS * 16, B)), dim3(B), 0, s, lv[L].NS, lv[L].seg_node, lv[L].flag,
-                       lv[L].fid, base[L], lv[L].seg_ck, lv[L].seg_body, Wout, o.fix_frames, out);
-    hipLaunchKernelGGL(k_emit_nodes, dim3(grid_for(lv[L].NN * 16, B)), dim3(B), 0, s, lv[L].NN, lv[L].flag, lv[L].fid, base[L],
-                       lv[L].tot, L, coe, fixo, lay);
+    const int seg_blocks = grid_for(lv[L].NS * 16, B);
+    hipLaunchKernelGGL(k_emit_level, dim3(seg_blocks + grid_for(lv[L].NN * 16, B)), dim3(B), 0, s, lv[L].NS, seg_blocks, lv[L].seg_node, lv[L].flag,
+                       lv[L].fid, lv[L].seg_ck, lv[L].seg_body, Wout, o.fix_frames, out, lv[L].NN, lv[L].tot, L, coe, fixo, lay);
   }
-  if (want_points)
+  if (want_points)         // (the scanned values are indices in the whole table: no per-level base)
     hipLaunchKernelGGL(k_point_features, dim3(grid_for(n, B)), dim3(B), 0, s, n, levels, pnode[0], pnode[1], pnode[2], lv[0].flag,
-                       lv[1].flag, lv[2].flag, lv[0].fid, lv[1].fid, lv[2].fid, base[1], base[2], pf);
+                       lv[1].NN ? lv[1].flag : (unsigned int *)nullptr, lv[2].NN ? lv[2].flag : (unsigned int *)nullptr, lv[0].fid, lv[1].fid, lv[2].fid, 0u, 0u, pf);
   if (hipStreamSynchronize(s) != hipSuccess || hipGetLastError() != hipSuccess) return fail();
   *F_out = (int)F; *d_out = out; *d_coe = coe; *d_fix = fixo; *d_layer = lay;
   if (want_points) *d_point_feat = pf;
