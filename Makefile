@@ -6,7 +6,7 @@ CXX      ?= g++
 HIPFLAGS  = --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=on -Wall -Wno-unused-value -Wno-unused-result -Wno-unused-function
 CSRC      = balm_amd/csrc
 LIB       = balm_amd/lib
-HIP_OBJS  = $(LIB)/kernels_accum.o $(LIB)/kernels_solve.o $(LIB)/kernels_build.o $(LIB)/kernels_voxel.o $(LIB)/kernels_cov.o $(LIB)/balm_multi.o $(LIB)/balm_capi.o
+HIP_OBJS  = $(LIB)/kernels_accum.o $(LIB)/kernels_solve.o $(LIB)/kernels_build.o $(LIB)/kernels_voxel.o $(LIB)/kernels_cov.o $(LIB)/kernels_syrk_i8.o $(LIB)/balm_multi.o $(LIB)/balm_capi.o
 HIP_DEPS  = $(CSRC)/balm_internal.h $(CSRC)/host_stage.h $(CSRC)/syrk_mfma_asm.inc $(CSRC)/kernels_window.inc $(CSRC)/kernels_chain.inc $(CSRC)/kernels_small.inc include/balm_hip.h
 
 all: $(LIB)/libbalm_hip.so $(LIB)/libbalm_scene.so

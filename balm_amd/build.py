@@ -10,7 +10,7 @@ import sys
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIBDIR = os.path.join(_HERE, "lib")
-HIP_SOURCES = ["kernels_accum.hip", "kernels_solve.hip", "kernels_build.hip", "kernels_voxel.hip", "kernels_cov.hip", "balm_multi.hip", "balm_capi.hip"]
+HIP_SOURCES = ["kernels_accum.hip", "kernels_solve.hip", "kernels_build.hip", "kernels_voxel.hip", "kernels_cov.hip", "kernels_syrk_i8.hip", "balm_multi.hip", "balm_capi.hip"]
 # association decisions must reproduce the reference's un-fused float/double arithmetic bit for bit
 EXTRA_FLAGS = {"kernels_voxel.hip": ["-ffp-contract=off"]}
 HIP_DEPS = ["balm_internal.h", "host_stage.h", "syrk_mfma_asm.inc", "kernels_window.inc", "kernels_chain.inc", "kernels_small.inc", os.path.join("..", "..", "include", "balm_hip.h")]

@@ -279,6 +279,9 @@ bool fuse_trial(const balm_ctx *ctx) {
   return ctx->W <= 256 && ctx->F > 0 && e && e[0] == '1';
 }
 
+// BALM_SYRK=int8: the dense SYRK on the INT8 matrix cores (kernels_syrk_i8.hip; opt-in, the default stays FP64 MFMA)
+static bool syrk_int8_mode() { const char *m = getenv("BALM_SYRK"); return m && !strcmp(m, "int8"); }
+
 // scratch of one Hessian evaluation over nf features (grown, never shrunk): every allocation an evaluation can need
 // happens here, so that a rank of a sharded run can fail BEFORE the collectives start (see one_damping_iter)
 int prepare_evaluate(balm_ctx *ctx, int form, int nf) {
@@ -296,6 +299,10 @@ int prepare_evaluate(balm_ctx *ctx, int form, int nf) {
     if (ctx->d_Gt != before) ctx->gt_dirty_cols = ~(size_t)0;        // fresh memory: nothing is known to be zero
   }
   if ((rc = ensure(ctx, &ctx->d_part, &ctx->cap_part, parts * TILE_ELEMS))) return rc;
+  if (syrk_int8_mode() && !(ctx->sparse && nf == ctx->F)) {
+    if ((rc = ensure(ctx, &ctx->d_i8, &ctx->cap_i8, syrk_i8_scratch_bytes(ctx->n, 3L * nf, nullptr)))) return rc;
+    HIP_TRY(prepare_device_syrk_i8());
+  }
   if ((rc = ensure(ctx, &ctx->d_dpart, &ctx->cap_dpart, (size_t)factors_grid(ctx->W, nf, form) * DACC_MAX * ctx->W))) return rc;
   if (nf == ctx->F && fuse_trial(ctx)) {       // the trial poses' factors (same sizes; reallocation invalidates what they held)
     if (ctx->cap_Gt2 < gcols * ctx->npad || ctx->cap_dpart2 < (size_t)factors_grid(ctx->W, nf, form) * DACC_MAX * ctx->W) ctx->gt_trial_valid = false;
@@ -351,9 +358,16 @@ int evaluate_device(balm_ctx *ctx, int form, const double *d_poses, int f0, int 
   // the moments / factor kernels ask for up to 150 KB of dynamic LDS (above the 64 KiB default: granted per device by
   // prepare_device_accum); a refused launch must surface here, not as stale results at the next synchronisation
   HIP_TRY(hipGetLastError());
+  // BALM_SYRK=int8 (opt-in, round 6): the dense product on the INT8 matrix cores by error-free slicing (kernels_syrk_i8.hip); it leaves ONE
+  // split-K slice in d_part
+  const bool int8 = !sparse && syrk_int8_mode();      // (its scratch: prepare_evaluate)
   {
     Span sp(ctx, BALM_T_SYRK);
     if (sparse) launch_syrk_sparse(s, ctx->d_Gt, ctx->npad, ctx->d_jobs, ctx->d_items, ctx->d_chunk_ids, ctx->sp_nsteps, ctx->sp_nitems, ctx->d_part);
+    else if (int8) {
+      if (launch_syrk_i8(s, ctx->d_Gt, ctx->npad, ctx->n, 3L * nf, ctx->d_sub, ctx->ntiles, ctx->d_i8, ctx->d_part)) { ctx->err = "INT8 SYRK: unsupported size"; return BALM_ERR_ARG; }
+      plan.SG = 1;
+    }
     else launch_syrk(s, ctx->d_Gt, ctx->npad, ctx->ntiles, ctx->d_jobs, plan, ctx->d_part);
   }
   {
@@ -572,7 +586,7 @@ static void one_destroy(balm_ctx *ctx) {
   if (ctx->window) { window_close(ctx->window); ctx->window = nullptr; }
   void *ptrs[] = {ctx->d_cl, ctx->d_fix, ctx->d_coe, ctx->d_poses, ctx->d_poses_tmp, ctx->d_C, ctx->d_feat,
                   ctx->d_Gt, ctx->d_Gt2, ctx->d_dpart2, ctx->d_part, ctx->d_dpart, ctx->d_rpart, ctx->d_feat_tmp, ctx->d_rpart_tmp, ctx->d_red, ctx->d_jobs, ctx->d_sub, ctx->d_H,
-                  ctx->d_g, ctx->d_A, ctx->d_Wp, ctx->d_dvec, ctx->d_z, ctx->d_x, ctx->d_perm, ctx->d_dx, ctx->d_scal, ctx->d_arena, ctx->d_pre, ctx->d_flags, ctx->d_minv, ctx->d_macro_tab, ctx->d_trace, ctx->d_slot, ctx->d_items, ctx->d_csr, ctx->d_chunk_ids, ctx->d_stage};
+                  ctx->d_g, ctx->d_A, ctx->d_Wp, ctx->d_dvec, ctx->d_z, ctx->d_x, ctx->d_perm, ctx->d_dx, ctx->d_scal, ctx->d_arena, ctx->d_pre, ctx->d_flags, ctx->d_minv, ctx->d_macro_tab, ctx->d_trace, ctx->d_slot, ctx->d_items, ctx->d_csr, ctx->d_chunk_ids, ctx->d_stage, ctx->d_i8};
   for (void *p : ptrs) if (p) hipFree(p);
   if (ctx->h_scal) hipHostFree(ctx->h_scal);
   ctx->ring.release();
@@ -593,7 +607,7 @@ static void one_destroy(balm_ctx *ctx) {
 static int build_sparse_plan(balm_ctx *ctx, int F, const unsigned char *obs) {
   ctx->sparse = false;
   const char *mode = getenv("BALM_SYRK");
-  if (mode && !strcmp(mode, "dense")) return BALM_OK;
+  if (mode && (!strcmp(mode, "dense") || !strcmp(mode, "int8"))) return BALM_OK;      // (the INT8 product is a dense plan)
   const int W = ctx->W, T = ctx->T, ntiles = ctx->ntiles;
   if (T > 128 || T <= 2 || F < 64) return BALM_OK;      // (two row blocks: three tile jobs, nothing a plan could skip -- and a 20-pose
                                                          //  sliding window installs a table per slide: the plan's host time is not free)

@@ -171,6 +171,7 @@ struct balm_ctx {
   bool comm_aborted = false;        // ncclCommAbort was called on `comm` (guarded by comm_mu)
   std::timed_mutex comm_mu;         // [check comm_dead + enqueue ncclAllReduce] vs [set comm_dead + ncclCommAbort]
   int rank = 0, nranks = 1;
+  unsigned char *d_i8 = nullptr; size_t cap_i8 = 0;     // scratch of the INT8 SYRK (BALM_SYRK=int8): digits, row scales, int32 partial tiles
   struct balm_multi *multi = nullptr;   // set on every device context of a balm_create_multi context
   double *d_pre = nullptr;          // [W + 2] pre-loop all-reduce: planes per pose, error flag
 };
@@ -206,6 +207,11 @@ void launch_reduce(hipStream_t s, const double *part, int SG, long tile_elems_to
 void launch_assemble(hipStream_t s, int form, const double *red, long red_dacc_off, const int *tileIJ, int ntiles,
                      int W, double *H, double *g, const double *r_in = nullptr, double *r_out = nullptr);
 void launch_sum_scalar(hipStream_t s, const double *rpart, int nr, double *out);
+// kernels_syrk_i8.hip: Gt Gt^T on the INT8 matrix cores by error-free slicing (BALM_SYRK=int8, opt-in)
+struct I8Layout { int T, rows_p, NT; long Kp; size_t off_digits, off_rowmax, off_scale, off_part; };
+size_t syrk_i8_scratch_bytes(int n, long K, I8Layout *lay);
+hipError_t prepare_device_syrk_i8();
+int launch_syrk_i8(hipStream_t s, const double *Gt, int npad, int n, long K, const int *tileIJ, int ntiles, unsigned char *scratch, double *part);
 
 // balm_multi.hip: one context over several devices of this process, RCCL loaded on first use
 struct Barrier;

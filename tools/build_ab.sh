@@ -8,7 +8,7 @@ EXTRA=""; [ "$SRC" = "kernels_voxel.hip" ] && EXTRA="-ffp-contract=off"
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=on -Wall -Wno-unused-value -Wno-unused-result -Wno-unused-function $EXTRA $FLAGS \
   -c balm_amd/csrc/$SRC -o balm_amd/lib/ab/${NAME}.o
 OBJS=""
-for o in kernels_accum kernels_solve kernels_build kernels_voxel kernels_cov balm_multi balm_capi; do
+for o in kernels_accum kernels_solve kernels_build kernels_voxel kernels_cov kernels_syrk_i8 balm_multi balm_capi; do
   if [ "$o.hip" = "$SRC" ]; then OBJS="$OBJS balm_amd/lib/ab/${NAME}.o"; else OBJS="$OBJS balm_amd/lib/$o.o"; fi
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o balm_amd/lib/ab/libbalm_hip_${NAME}.so $OBJS -ldl -pthread
