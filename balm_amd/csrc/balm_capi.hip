@@ -301,6 +301,11 @@ int prepare_evaluate(balm_ctx *ctx, int form, int nf) {
   if ((rc = ensure(ctx, &ctx->d_part, &ctx->cap_part, parts * TILE_ELEMS))) return rc;
   if (syrk_int8_mode() && !(ctx->sparse && nf == ctx->F)) {
     if ((rc = ensure(ctx, &ctx->d_i8, &ctx->cap_i8, syrk_i8_scratch_bytes(ctx->n, 3L * nf, nullptr)))) return rc;
+    // the rows' largest |entries|, left by the factor kernels beside Gt / Gt2 (where their pose-per-lane variants run)
+    if (!ctx->d_rowmax) ctx->rowmax_cur_valid = false;
+    if (!ctx->d_rowmax2) ctx->rowmax_trial_valid = false;
+    if ((rc = ensure(ctx, &ctx->d_rowmax, &ctx->cap_rowmax, (size_t)ctx->npad + 128))) return rc;
+    if ((rc = ensure(ctx, &ctx->d_rowmax2, &ctx->cap_rowmax2, (size_t)ctx->npad + 128))) return rc;
     HIP_TRY(prepare_device_syrk_i8());
   }
   if ((rc = ensure(ctx, &ctx->d_dpart, &ctx->cap_dpart, (size_t)factors_grid(ctx->W, nf, form) * DACC_MAX * ctx->W))) return rc;
@@ -351,8 +356,8 @@ int evaluate_device(balm_ctx *ctx, int form, const double *d_poses, int f0, int 
       HIP_TRY(hipMemsetAsync(ctx->d_Gt + k0 * ctx->npad, 0, (std::max(ctx->gt_dirty_cols, k1) - k0) * ctx->npad * sizeof(double), s));
     }
     ctx->gt_dirty_cols = k0;
-    launch_factors(s, form, ctx->d_cl, d_poses, ctx->d_feat, W, ctx->npad, f0, f1, ctx->d_Gt, ctx->d_dpart, nblk,
-                   sparse ? ctx->d_slot : nullptr);
+    ctx->rowmax_cur_valid = launch_factors(s, form, ctx->d_cl, d_poses, ctx->d_feat, W, ctx->npad, f0, f1, ctx->d_Gt, ctx->d_dpart, nblk,
+                                           sparse ? ctx->d_slot : nullptr, (!sparse && syrk_int8_mode()) ? ctx->d_rowmax : nullptr);
     ctx->gt_cur_valid = false;                // (set by the LM loop only, when an accepted trial's factors become current)
   }
   // the moments / factor kernels ask for up to 150 KB of dynamic LDS (above the 64 KiB default: granted per device by
@@ -365,7 +370,8 @@ int evaluate_device(balm_ctx *ctx, int form, const double *d_poses, int f0, int 
     Span sp(ctx, BALM_T_SYRK);
     if (sparse) launch_syrk_sparse(s, ctx->d_Gt, ctx->npad, ctx->d_jobs, ctx->d_items, ctx->d_chunk_ids, ctx->sp_nsteps, ctx->sp_nitems, ctx->d_part);
     else if (int8) {
-      if (launch_syrk_i8(s, ctx->d_Gt, ctx->npad, ctx->n, 3L * nf, ctx->d_sub, ctx->ntiles, ctx->d_i8, ctx->d_part)) { ctx->err = "INT8 SYRK: unsupported size"; return BALM_ERR_ARG; }
+      if (launch_syrk_i8(s, ctx->d_Gt, ctx->npad, ctx->n, 3L * nf, ctx->d_sub, ctx->ntiles, ctx->d_i8, ctx->d_part,
+                         ctx->rowmax_cur_valid ? ctx->d_rowmax : nullptr)) { ctx->err = "INT8 SYRK: unsupported size"; return BALM_ERR_ARG; }
       plan.SG = 1;
     }
     else launch_syrk(s, ctx->d_Gt, ctx->npad, ctx->ntiles, ctx->d_jobs, plan, ctx->d_part);
@@ -401,7 +407,9 @@ int trial_device(balm_ctx *ctx, int form, const double *d_poses, int slot) {
       HIP_TRY(hipMemset2DAsync(ctx->d_Gt2 + ctx->n, (size_t)ctx->npad * sizeof(double), 0,
                                (size_t)(ctx->npad - ctx->n) * sizeof(double), k0, s));
     ctx->nr_tmp = launch_moments_factors(s, form, ctx->d_cl, d_poses, ctx->has_fix ? ctx->d_fix : nullptr, ctx->d_coe, W, ctx->npad, F,
-                                         ctx->d_Gt2, ctx->d_dpart2, nblk, sparse ? ctx->d_slot : nullptr, ctx->d_feat_tmp, ctx->d_rpart_tmp);
+                                         ctx->d_Gt2, ctx->d_dpart2, nblk, sparse ? ctx->d_slot : nullptr, ctx->d_feat_tmp, ctx->d_rpart_tmp,
+                                         (!sparse && syrk_int8_mode() && ctx->d_rowmax2) ? ctx->d_rowmax2 : nullptr);
+    ctx->rowmax_trial_valid = !sparse && syrk_int8_mode() && ctx->d_rowmax2;
   }
   HIP_TRY(hipGetLastError());
   {
@@ -586,7 +594,7 @@ static void one_destroy(balm_ctx *ctx) {
   if (ctx->window) { window_close(ctx->window); ctx->window = nullptr; }
   void *ptrs[] = {ctx->d_cl, ctx->d_fix, ctx->d_coe, ctx->d_poses, ctx->d_poses_tmp, ctx->d_C, ctx->d_feat,
                   ctx->d_Gt, ctx->d_Gt2, ctx->d_dpart2, ctx->d_part, ctx->d_dpart, ctx->d_rpart, ctx->d_feat_tmp, ctx->d_rpart_tmp, ctx->d_red, ctx->d_jobs, ctx->d_sub, ctx->d_H,
-                  ctx->d_g, ctx->d_A, ctx->d_Wp, ctx->d_dvec, ctx->d_z, ctx->d_x, ctx->d_perm, ctx->d_dx, ctx->d_scal, ctx->d_arena, ctx->d_pre, ctx->d_flags, ctx->d_minv, ctx->d_macro_tab, ctx->d_trace, ctx->d_slot, ctx->d_items, ctx->d_csr, ctx->d_chunk_ids, ctx->d_stage, ctx->d_i8};
+                  ctx->d_g, ctx->d_A, ctx->d_Wp, ctx->d_dvec, ctx->d_z, ctx->d_x, ctx->d_perm, ctx->d_dx, ctx->d_scal, ctx->d_arena, ctx->d_pre, ctx->d_flags, ctx->d_minv, ctx->d_macro_tab, ctx->d_trace, ctx->d_slot, ctx->d_items, ctx->d_csr, ctx->d_chunk_ids, ctx->d_stage, ctx->d_i8, ctx->d_rowmax, ctx->d_rowmax2};
   for (void *p : ptrs) if (p) hipFree(p);
   if (ctx->h_scal) hipHostFree(ctx->h_scal);
   ctx->ring.release();
@@ -1519,6 +1527,8 @@ static int one_damping_iter(balm_ctx *ctx, const balm_lm_opts *o, double *poses,
       ctx->gt_cur_valid = ctx->gt_trial_valid;        // the trial's factors (fused evaluation) become the current poses'
       if (ctx->gt_trial_valid) {
         std::swap(ctx->d_Gt, ctx->d_Gt2); std::swap(ctx->cap_Gt, ctx->cap_Gt2);
+        std::swap(ctx->d_rowmax, ctx->d_rowmax2); std::swap(ctx->cap_rowmax, ctx->cap_rowmax2);        // (BALM_SYRK=int8: the row maxima go with their Gt)
+        ctx->rowmax_cur_valid = ctx->rowmax_trial_valid;
         ctx->gt_dirty_cols = ~(size_t)0;       // (the other buffer's zero state is the trial kernel's business, not tracked)
         std::swap(ctx->d_dpart, ctx->d_dpart2); std::swap(ctx->cap_dpart, ctx->cap_dpart2);
         ctx->gt_parity ^= 1;

@@ -519,12 +519,28 @@ __device__ __forceinline__ void obs_factors(const FeatRec &fr, const double P[6]
 // accumulators live in registers instead of LDS -- no LDS traffic per observation but the staging block's (78 LDS instructions per observation
 // before): 0.434 -> 0.408 ms at config 2 on top of the coalesced stores, bit for bit the same sums (profiles/r04l_factors_staged.txt).  (Tried
 // in round 1 on the lane-by-lane stores: no gain -- the stores hid it.  The right form's 30 accumulators do not fit beside its working set.)
-template <int FORM, bool REGS>
+// MAXR (round 6, BALM_SYRK=int8): the lane -- one pose for the workgroup's whole life -- also keeps the largest |entry| of its six Gt rows and
+// leaves it in rowmax[6 pose + r] (atomic max over the workgroups; non-negative doubles order like their bit patterns): the row exponents of
+// the INT8 product's digit slicing (kernels_syrk_i8.hip) without a pass of their own over Gt.  The default instantiations are MAXR = false.
+__device__ __forceinline__ void track_rowmax(double rm[6], const double col0[6], const double col1[6], const double col2[6]) {
+#pragma unroll
+  for (int k = 0; k < 6; k++) rm[k] = fmax(rm[k], fmax(fabs(col0[k]), fmax(fabs(col1[k]), fabs(col2[k]))));
+}
+__device__ __forceinline__ void publish_rowmax(unsigned long long *rowmax, int pose, const double rm[6]) {
+#pragma unroll
+  for (int k = 0; k < 6; k++)
+    if (rm[k] > 0.0) atomicMax(rowmax + 6 * pose + k, (unsigned long long)__double_as_longlong(rm[k]));
+}
+
+template <int FORM, bool REGS, bool MAXR = false>
 __global__ __launch_bounds__(256) void k_feature_factors(const double *__restrict__ cl,
                                                          const double *__restrict__ poses,
                                                          const double *__restrict__ feat, int W, int Wc, int npad, int f0,
                                                          int f1, double *__restrict__ Gt,
-                                                         double *__restrict__ dpart, const int *__restrict__ slot, int staged) {
+                                                         double *__restrict__ dpart, const int *__restrict__ slot, int staged,
+                                                         unsigned long long *__restrict__ rowmax = nullptr) {
+  static_assert(!MAXR || REGS, "the row maxima live in the lane that owns the pose");
+  double rm[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
   // staged (round 4, the default wherever the LDS has room): a lane's six values of a Gt column are 48 contiguous bytes, a wavefront's 64 poses
   // 3 KB -- written lane by lane as three 16-byte stores, every store instruction touches a THIRD of each 48-byte segment of 24 cache lines,
   // three times over.  Through a 3 KB staging block per wavefront in LDS the same bytes leave as three stores of 1 KB each, consecutive lanes
@@ -613,6 +629,7 @@ __global__ __launch_bounds__(256) void k_feature_factors(const double *__restric
       if (il == (int)threadIdx.x && a + a_step < a_end) fetch(a + a_step, i_first);
       if (REGS) obs_factors<FORM>(fr, P, v, N, preg, racc, 1, 0, col0, col1, col2);
       else obs_factors<FORM>(fr, P, v, N, sp, sacc, Wc, act ? il : wc - 1, col0, col1, col2);
+      if (MAXR) track_rowmax(rm, col0, col1, col2);
       // (Measured and rejected on the lane-by-lane stores, round 4, profiles/r04d_factors_ab.txt: streaming (nontemporal) stores -- 0.555 vs
       // 0.553 ms; the lane's pose in twelve registers instead of the LDS table, i.e. THREE workgroups per CU -- 0.565 vs 0.554.)
       if (!staged) {
@@ -649,6 +666,7 @@ __global__ __launch_bounds__(256) void k_feature_factors(const double *__restric
     if (threadIdx.x < (unsigned)wc) {
 #pragma unroll
       for (int k = 0; k < DACC; k++) dp[(size_t)k * W + threadIdx.x] = racc[k];
+      if (MAXR) publish_rowmax(rowmax, p0 + (int)threadIdx.x, rm);
     }
     return;
   }
@@ -669,13 +687,14 @@ __global__ __launch_bounds__(256) void k_feature_factors(const double *__restric
 // with the cluster still in their registers.  If the step is accepted the next Hessian evaluation starts at the SYRK; if
 // not, the Gt of the current poses is still there (two Gt buffers).  Windows up to 256 poses (one pose per lane).
 // ------------------------------------------------------------------------------------------------
-template <int FORM>
+template <int FORM, bool MAXR = false>
 __global__ __launch_bounds__(320, 3) void k_moments_factors(const double *__restrict__ cl, const double *__restrict__ poses,
                                                          const double *__restrict__ fix, const double *__restrict__ coe_in, int W, int npad,
                                                          int F, double *__restrict__ Gt, double *__restrict__ dpart,
                                                          const int *__restrict__ slot, double *__restrict__ feat_out,
-                                                         double *__restrict__ rpart) {
+                                                         double *__restrict__ rpart, unsigned long long *__restrict__ rowmax = nullptr) {
   constexpr int DACC = FORM == 0 ? DACC_LEFT : DACC_RIGHT;
+  double rm[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};      // (MAXR: k_feature_factors)
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int npl = (int)blockDim.x - 64, npw = npl >> 6;      // pose lanes / waves; the last wave is the eigen wave
   double *sp = sm;                                           // [12][W] poses
@@ -787,6 +806,7 @@ __global__ __launch_bounds__(320, 3) void k_moments_factors(const double *__rest
       if (has_pose) {
         double col0[6], col1[6], col2[6];
         obs_factors<FORM>(fr, cur, cur + 6, cur[9], sp, sacc, W, il, col0, col1, col2);
+        if (MAXR) track_rowmax(rm, col0, col1, col2);
         double *g0 = Gt + (size_t)(3 * (slot ? slot[a] : a)) * npad;
         store6(g0 + 6 * il, col0);
         store6(g0 + (size_t)npad + 6 * il, col1);
@@ -800,6 +820,7 @@ __global__ __launch_bounds__(320, 3) void k_moments_factors(const double *__rest
   }
   double *dp = dpart + (size_t)blockIdx.x * DACC * W;
   for (int t = tid; t < DACC * W; t += blockDim.x) dp[t] = sacc[t];
+  if (MAXR && has_pose) publish_rowmax(rowmax, il, rm);
   if (!is_pose && lane == 0) rpart[blockIdx.x] = res;
 }
 
@@ -840,26 +861,40 @@ hipError_t prepare_device_accum() {
   if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_feature_factors<0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_feature_factors<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_feature_factors<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_moments_factors<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_moments_factors<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_feature_factors<0, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_moments_factors<0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_moments_factors<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_moments_factors<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_moments_factors<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   return e;
 }
 
 // the fused trial evaluation: residual partials (one per workgroup: returns their number), eigen records, Gt, per-pose partials
 int launch_moments_factors(hipStream_t s, int form, const double *cl, const double *poses, const double *fix, const double *coe, int W,
-                           int npad, int F, double *Gt, double *dpart, int nblk, const int *slot, double *feat, double *rpart) {
+                           int npad, int F, double *Gt, double *dpart, int nblk, const int *slot, double *feat, double *rpart,
+                           unsigned long long *rowmax) {
   const int dacc = form == 0 ? DACC_LEFT : DACC_RIGHT;
   const size_t lds = (size_t)((12 + dacc) * W + 80 + 2 * FEAT_STRIDE) * sizeof(double);
   const int bs = (W <= 64 ? 64 : (W <= 128 ? 128 : 256)) + 64;
+  if (rowmax) {          // (the INT8 product's row exponents ride along: npad entries, zeroed here)
+    (void)hipMemsetAsync(rowmax, 0, (size_t)npad * sizeof(unsigned long long), s);
+    if (form == 0)
+      hipLaunchKernelGGL((k_moments_factors<0, true>), dim3(nblk), dim3(bs), lds, s, cl, poses, fix, coe, W, npad, F, Gt, dpart, slot, feat, rpart, rowmax);
+    else
+      hipLaunchKernelGGL((k_moments_factors<1, true>), dim3(nblk), dim3(bs), lds, s, cl, poses, fix, coe, W, npad, F, Gt, dpart, slot, feat, rpart, rowmax);
+    return nblk;
+  }
   if (form == 0)
-    hipLaunchKernelGGL(k_moments_factors<0>, dim3(nblk), dim3(bs), lds, s, cl, poses, fix, coe, W, npad, F, Gt, dpart, slot, feat, rpart);
+    hipLaunchKernelGGL((k_moments_factors<0, false>), dim3(nblk), dim3(bs), lds, s, cl, poses, fix, coe, W, npad, F, Gt, dpart, slot, feat, rpart, nullptr);
   else
-    hipLaunchKernelGGL(k_moments_factors<1>, dim3(nblk), dim3(bs), lds, s, cl, poses, fix, coe, W, npad, F, Gt, dpart, slot, feat, rpart);
+    hipLaunchKernelGGL((k_moments_factors<1, false>), dim3(nblk), dim3(bs), lds, s, cl, poses, fix, coe, W, npad, F, Gt, dpart, slot, feat, rpart, nullptr);
   return nblk;
 }
 
-void launch_factors(hipStream_t s, int form, const double *cl, const double *poses, const double *feat, int W,
-                    int npad, int f0, int f1, double *Gt, double *dpart, int nblk, const int *slot) {
+// rowmax (may be null): where the kernel variant that tracks them exists -- the left form with a pose per lane -- the rows' largest |entries|
+// are left there (npad entries) and the call returns true
+bool launch_factors(hipStream_t s, int form, const double *cl, const double *poses, const double *feat, int W,
+                    int npad, int f0, int f1, double *Gt, double *dpart, int nblk, const int *slot, unsigned long long *rowmax) {
   const int Wc = factors_chunk(W), chunks = (W + Wc - 1) / Wc;
   size_t lds = factors_lds(W, form);
   int bs = W <= 64 ? 64 : (W <= 128 ? 128 : 256);
@@ -867,10 +902,16 @@ void launch_factors(hipStream_t s, int form, const double *cl, const double *pos
   if (staged) lds += FACTORS_STAGE_BYTES;
   const char *er = getenv("BALM_FACTORS_REGS");                     // 0: the accumulators in LDS at every window (A/B, tests)
   const bool regs = form == 0 && chunks == 1 && W <= bs && !(er && er[0] == '0');
-#define BALM_FACTORS(F, R) hipLaunchKernelGGL((k_feature_factors<F, R>), dim3(nblk, chunks), dim3(bs), lds, s, cl, poses, feat, W, Wc, npad, f0, f1, Gt, dpart, slot, staged)
+  if (rowmax && regs) {
+    (void)hipMemsetAsync(rowmax, 0, (size_t)npad * sizeof(unsigned long long), s);
+    hipLaunchKernelGGL((k_feature_factors<0, true, true>), dim3(nblk, chunks), dim3(bs), lds, s, cl, poses, feat, W, Wc, npad, f0, f1, Gt, dpart, slot, staged, rowmax);
+    return true;
+  }
+#define BALM_FACTORS(F, R) hipLaunchKernelGGL((k_feature_factors<F, R, false>), dim3(nblk, chunks), dim3(bs), lds, s, cl, poses, feat, W, Wc, npad, f0, f1, Gt, dpart, slot, staged, nullptr)
   if (form == 0) { if (regs) BALM_FACTORS(0, true); else BALM_FACTORS(0, false); }
   else BALM_FACTORS(1, false);
 #undef BALM_FACTORS
+  return false;
 }
 
 // ------------------------------------------------------------------------------------------------

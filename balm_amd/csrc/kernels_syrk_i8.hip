@@ -109,7 +109,6 @@ __device__ __forceinline__ void i8_glds16(const signed char *src, void *lds_wave
 // Eight wavefronts, two per SIMD, 32 x 64 of the 128 x 128 tile each: 5 sets x 2 x 4 accumulator tiles = 160 registers (all AGPRs -- with
 // four wavefronts of 64 x 64 the 320 accumulator registers do not fit the 256 AGPRs and the compiler shuttles the rest through
 // v_accvgpr moves, 768 per step: 2.05 ms, measured), the second wavefront of a SIMD covers the other's LDS waits.
-template <int MODE>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_syrk_i8(const signed char *__restrict__ D, long Kp, int rows_p, int T,
                                                                                            int NT, int *__restrict__ P) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];      // two stages of [side 2][digit 4][row group 8][1 KB]: 128 KB
@@ -149,7 +148,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   for (int step = 0; step < nsteps; step++) {
     __builtin_amdgcn_s_waitcnt(0x0f70);          // vmcnt(0): this wavefront's pieces of the stage are in LDS
     __syncthreads();                             // ... and everybody else's; and everybody is done reading the other buffer
-    if (step + 1 < nsteps && !(MODE & 2)) issue(step + 1);
+    if (step + 1 < nsteps) issue(step + 1);
     const unsigned char *buf = lds + (size_t)(step & 1) * 65536;
     const unsigned char *bufA = buf + (size_t)(wr * 2) * 1024 + lane * 16;
     const unsigned char *bufB = buf + (size_t)((diag ? 0 : 32) + wc * 4) * 1024 + lane * 16;
@@ -171,10 +170,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
         for (int i = 0; i < 2; i++)
 #pragma unroll
-          for (int j = 0; j < 4; j++) {
-            if (MODE & 1) acc[set][i][j] += A[a][i] ^ B[j];
-            else acc[set][i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[a][i], B[j], acc[set][i][j], 0, 0, 0);
-          }
+          for (int j = 0; j < 4; j++) acc[set][i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[a][i], B[j], acc[set][i][j], 0, 0, 0);
       }
     }
   }
@@ -242,14 +238,14 @@ size_t syrk_i8_scratch_bytes(int n, long K, I8Layout *lay) {
 }
 
 hipError_t prepare_device_syrk_i8() {
-  hipFuncSetAttribute((const void *)k_syrk_i8<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-  hipFuncSetAttribute((const void *)k_syrk_i8<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-  return hipFuncSetAttribute((const void *)k_syrk_i8<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+  return hipFuncSetAttribute((const void *)k_syrk_i8, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
 }
 
 // Gt [K][npad] (column k of the factor matrix = npad contiguous rows, as k_feature_factors writes it) -> part: one split-K slice of Gt Gt^T
 // in k_hessian_syrk's tile layout.  The int32 accumulators bound a k-slice: K / 8 * 4 * 64^2 < 2^31, i.e. K < 1.04 million columns.
-int launch_syrk_i8(hipStream_t s, const double *Gt, int npad, int n, long K, const int *tileIJ, int ntiles, unsigned char *scratch, double *part) {
+// rowmax_known: the rows' largest |entries| where the factor kernel left them (k_feature_factors MAXR), else a pass over Gt finds them.
+int launch_syrk_i8(hipStream_t s, const double *Gt, int npad, int n, long K, const int *tileIJ, int ntiles, unsigned char *scratch, double *part,
+                   const unsigned long long *rowmax_known) {
   I8Layout L;
   syrk_i8_scratch_bytes(n, K, &L);
   if (K < 1 || L.Kp / I8_XCDS * 4 * 4096 >= (1l << 31) || (size_t)I8_DIGITS * L.rows_p * L.Kp >= ((size_t)1 << 32)) return -1;
@@ -257,15 +253,12 @@ int launch_syrk_i8(hipStream_t s, const double *Gt, int npad, int n, long K, con
   auto *rowmax = reinterpret_cast<unsigned long long *>(scratch + L.off_rowmax);
   double *rowscale = reinterpret_cast<double *>(scratch + L.off_scale);
   int *P = reinterpret_cast<int *>(scratch + L.off_part);
-  hipMemsetAsync(rowmax, 0, (size_t)L.rows_p * 8, s);
   const int kchunk = 512;
-  hipLaunchKernelGGL(k_i8_rowmax, dim3((npad + 255) / 256, (unsigned int)((K + kchunk - 1) / kchunk)), dim3(256), 0, s, Gt, npad, npad < L.rows_p ? npad : L.rows_p, K, kchunk, rowmax);
+  if (rowmax_known) rowmax = const_cast<unsigned long long *>(rowmax_known);
+  else if (hipMemsetAsync(rowmax, 0, (size_t)L.rows_p * 8, s) != hipSuccess) return -1;
+  if (!rowmax_known) hipLaunchKernelGGL(k_i8_rowmax, dim3((npad + 255) / 256, (unsigned int)((K + kchunk - 1) / kchunk)), dim3(256), 0, s, Gt, npad, npad < L.rows_p ? npad : L.rows_p, K, kchunk, rowmax);
   hipLaunchKernelGGL(k_i8_slice, dim3(L.rows_p / 64, (unsigned int)(L.Kp / 64)), dim3(256), 0, s, Gt, npad, K, L.Kp, L.rows_p, rowmax, D, rowscale);
-  const char *dbg = getenv("BALM_I8_MODE");
-  const int md = dbg ? atoi(dbg) : 0;
-  if (md == 1) hipLaunchKernelGGL(k_syrk_i8<1>, dim3(I8_XCDS * L.NT), dim3(512), 128 * 1024, s, D, L.Kp, L.rows_p, L.T, L.NT, P);
-  else if (md == 2) hipLaunchKernelGGL(k_syrk_i8<2>, dim3(I8_XCDS * L.NT), dim3(512), 128 * 1024, s, D, L.Kp, L.rows_p, L.T, L.NT, P);
-  else hipLaunchKernelGGL(k_syrk_i8<0>, dim3(I8_XCDS * L.NT), dim3(512), 128 * 1024, s, D, L.Kp, L.rows_p, L.T, L.NT, P);
+  hipLaunchKernelGGL(k_syrk_i8, dim3(I8_XCDS * L.NT), dim3(512), 128 * 1024, s, D, L.Kp, L.rows_p, L.T, L.NT, P);
   long total = (long)ntiles * TILE_ELEMS;
   int grid = (int)((total + 255) / 256);
   if (grid > 8192) grid = 8192;
