@@ -306,6 +306,7 @@ int prepare_evaluate(balm_ctx *ctx, int form, int nf) {
     if (!ctx->d_rowmax2) ctx->rowmax_trial_valid = false;
     if ((rc = ensure(ctx, &ctx->d_rowmax, &ctx->cap_rowmax, (size_t)ctx->npad + 128))) return rc;
     if ((rc = ensure(ctx, &ctx->d_rowmax2, &ctx->cap_rowmax2, (size_t)ctx->npad + 128))) return rc;
+    if ((rc = ensure(ctx, &ctx->d_rowmax_part, &ctx->cap_rowmax_part, (size_t)factors_grid(ctx->W, nf, form) * 6 * ctx->W))) return rc;
     HIP_TRY(prepare_device_syrk_i8());
   }
   if ((rc = ensure(ctx, &ctx->d_dpart, &ctx->cap_dpart, (size_t)factors_grid(ctx->W, nf, form) * DACC_MAX * ctx->W))) return rc;
@@ -357,7 +358,7 @@ int evaluate_device(balm_ctx *ctx, int form, const double *d_poses, int f0, int 
     }
     ctx->gt_dirty_cols = k0;
     ctx->rowmax_cur_valid = launch_factors(s, form, ctx->d_cl, d_poses, ctx->d_feat, W, ctx->npad, f0, f1, ctx->d_Gt, ctx->d_dpart, nblk,
-                                           sparse ? ctx->d_slot : nullptr, (!sparse && syrk_int8_mode()) ? ctx->d_rowmax : nullptr);
+                                           sparse ? ctx->d_slot : nullptr, (!sparse && syrk_int8_mode()) ? ctx->d_rowmax : nullptr, ctx->d_rowmax_part);
     ctx->gt_cur_valid = false;                // (set by the LM loop only, when an accepted trial's factors become current)
   }
   // the moments / factor kernels ask for up to 150 KB of dynamic LDS (above the 64 KiB default: granted per device by
@@ -408,7 +409,7 @@ int trial_device(balm_ctx *ctx, int form, const double *d_poses, int slot) {
                                (size_t)(ctx->npad - ctx->n) * sizeof(double), k0, s));
     ctx->nr_tmp = launch_moments_factors(s, form, ctx->d_cl, d_poses, ctx->has_fix ? ctx->d_fix : nullptr, ctx->d_coe, W, ctx->npad, F,
                                          ctx->d_Gt2, ctx->d_dpart2, nblk, sparse ? ctx->d_slot : nullptr, ctx->d_feat_tmp, ctx->d_rpart_tmp,
-                                         (!sparse && syrk_int8_mode() && ctx->d_rowmax2) ? ctx->d_rowmax2 : nullptr);
+                                         (!sparse && syrk_int8_mode() && ctx->d_rowmax2) ? ctx->d_rowmax2 : nullptr, ctx->d_rowmax_part);
     ctx->rowmax_trial_valid = !sparse && syrk_int8_mode() && ctx->d_rowmax2;
   }
   HIP_TRY(hipGetLastError());
@@ -594,7 +595,7 @@ static void one_destroy(balm_ctx *ctx) {
   if (ctx->window) { window_close(ctx->window); ctx->window = nullptr; }
   void *ptrs[] = {ctx->d_cl, ctx->d_fix, ctx->d_coe, ctx->d_poses, ctx->d_poses_tmp, ctx->d_C, ctx->d_feat,
                   ctx->d_Gt, ctx->d_Gt2, ctx->d_dpart2, ctx->d_part, ctx->d_dpart, ctx->d_rpart, ctx->d_feat_tmp, ctx->d_rpart_tmp, ctx->d_red, ctx->d_jobs, ctx->d_sub, ctx->d_H,
-                  ctx->d_g, ctx->d_A, ctx->d_Wp, ctx->d_dvec, ctx->d_z, ctx->d_x, ctx->d_perm, ctx->d_dx, ctx->d_scal, ctx->d_arena, ctx->d_pre, ctx->d_flags, ctx->d_minv, ctx->d_macro_tab, ctx->d_trace, ctx->d_slot, ctx->d_items, ctx->d_csr, ctx->d_chunk_ids, ctx->d_stage, ctx->d_i8, ctx->d_rowmax, ctx->d_rowmax2};
+                  ctx->d_g, ctx->d_A, ctx->d_Wp, ctx->d_dvec, ctx->d_z, ctx->d_x, ctx->d_perm, ctx->d_dx, ctx->d_scal, ctx->d_arena, ctx->d_pre, ctx->d_flags, ctx->d_minv, ctx->d_macro_tab, ctx->d_trace, ctx->d_slot, ctx->d_items, ctx->d_csr, ctx->d_chunk_ids, ctx->d_stage, ctx->d_i8, ctx->d_rowmax, ctx->d_rowmax2, ctx->d_rowmax_part};
   for (void *p : ptrs) if (p) hipFree(p);
   if (ctx->h_scal) hipHostFree(ctx->h_scal);
   ctx->ring.release();

@@ -172,6 +172,7 @@ struct balm_ctx {
   std::timed_mutex comm_mu;         // [check comm_dead + enqueue ncclAllReduce] vs [set comm_dead + ncclCommAbort]
   int rank = 0, nranks = 1;
   unsigned long long *d_rowmax = nullptr, *d_rowmax2 = nullptr; size_t cap_rowmax = 0, cap_rowmax2 = 0;      // ... the rows' maxima of Gt / Gt2
+  double *d_rowmax_part = nullptr; size_t cap_rowmax_part = 0;      // ... per workgroup of the factor kernel, before their reduction
   bool rowmax_cur_valid = false, rowmax_trial_valid = false;
   unsigned char *d_i8 = nullptr; size_t cap_i8 = 0;     // scratch of the INT8 SYRK (BALM_SYRK=int8): digits, row scales, int32 partial tiles
   struct balm_multi *multi = nullptr;   // set on every device context of a balm_create_multi context
@@ -195,10 +196,10 @@ int factors_grid(int W, int nfeat, int form);
 int factors_chunk(int W);     // poses per workgroup of the factor kernel (the whole window up to MAX_W_LDS)
 bool launch_factors(hipStream_t s, int form, const double *cl, const double *poses, const double *feat, int W,
                     int npad, int f0, int f1, double *Gt, double *dpart, int nblk, const int *slot = nullptr,
-                    unsigned long long *rowmax = nullptr);      // rowmax: the INT8 product's row maxima ride along (true if they did)
+                    unsigned long long *rowmax = nullptr, double *rowmax_part = nullptr);      // rowmax: the INT8 product's row maxima ride along (true if they did)
 int launch_moments_factors(hipStream_t s, int form, const double *cl, const double *poses, const double *fix, const double *coe, int W,
                            int npad, int F, double *Gt, double *dpart, int nblk, const int *slot, double *feat, double *rpart,
-                           unsigned long long *rowmax = nullptr);
+                           unsigned long long *rowmax = nullptr, double *rowmax_part = nullptr);
 struct SyrkPlan { int SG; int nsteps; int Kpad; long nblocks; };   // k-slices, MFMA k-steps per wave, padded K, workgroups
 SyrkPlan plan_syrk(int ntiles, long K);
 void launch_syrk(hipStream_t s, const double *Gt, int npad, int ntiles, const int *tileIJ, const SyrkPlan &p,
@@ -212,7 +213,7 @@ void launch_assemble(hipStream_t s, int form, const double *red, long red_dacc_o
                      int W, double *H, double *g, const double *r_in = nullptr, double *r_out = nullptr);
 void launch_sum_scalar(hipStream_t s, const double *rpart, int nr, double *out);
 // kernels_syrk_i8.hip: Gt Gt^T on the INT8 matrix cores by error-free slicing (BALM_SYRK=int8, opt-in)
-struct I8Layout { int T, rows_p, NT; long Kp; size_t off_digits, off_rowmax, off_scale, off_part; };
+struct I8Layout { int T, rows_p, NT, M; long Kp; size_t off_digits, off_rowmax, off_scale, off_part; };
 size_t syrk_i8_scratch_bytes(int n, long K, I8Layout *lay);
 hipError_t prepare_device_syrk_i8();
 int launch_syrk_i8(hipStream_t s, const double *Gt, int npad, int n, long K, const int *tileIJ, int ntiles, unsigned char *scratch, double *part,

@@ -520,16 +520,47 @@ __device__ __forceinline__ void obs_factors(const FeatRec &fr, const double P[6]
 // before): 0.434 -> 0.408 ms at config 2 on top of the coalesced stores, bit for bit the same sums (profiles/r04l_factors_staged.txt).  (Tried
 // in round 1 on the lane-by-lane stores: no gain -- the stores hid it.  The right form's 30 accumulators do not fit beside its working set.)
 // MAXR (round 6, BALM_SYRK=int8): the lane -- one pose for the workgroup's whole life -- also keeps the largest |entry| of its six Gt rows and
-// leaves it in rowmax[6 pose + r] (atomic max over the workgroups; non-negative doubles order like their bit patterns): the row exponents of
-// the INT8 product's digit slicing (kernels_syrk_i8.hip) without a pass of their own over Gt.  The default instantiations are MAXR = false.
+// leaves it in rowmax_part[workgroup][r][pose]; k_rowmax_reduce takes the maximum over the workgroups: the row exponents of the INT8
+// product's digit slicing (kernels_syrk_i8.hip) without a pass of their own over Gt.  (One atomicMax per lane and row on rowmax itself: 512
+// workgroups x 1200 addresses, 512 device-scope atomics in a row on every address -- +48 us on the 407 us kernel, measured.)  The default
+// instantiations are MAXR = false.
 __device__ __forceinline__ void track_rowmax(double rm[6], const double col0[6], const double col1[6], const double col2[6]) {
 #pragma unroll
   for (int k = 0; k < 6; k++) rm[k] = fmax(rm[k], fmax(fabs(col0[k]), fmax(fabs(col1[k]), fabs(col2[k]))));
 }
-__device__ __forceinline__ void publish_rowmax(unsigned long long *rowmax, int pose, const double rm[6]) {
+__device__ __forceinline__ void publish_rowmax(double *__restrict__ part, int W, int pose, const double rm[6]) {
 #pragma unroll
-  for (int k = 0; k < 6; k++)
-    if (rm[k] > 0.0) atomicMax(rowmax + 6 * pose + k, (unsigned long long)__double_as_longlong(rm[k]));
+  for (int k = 0; k < 6; k++) part[(size_t)(blockIdx.x * 6 + k) * W + pose] = rm[k];
+}
+// rowmax[6 pose + r] = max over the workgroups, as the bit pattern the slicing kernel reads (non-negative doubles order like their bits);
+// rows beyond the window: 0
+__global__ __launch_bounds__(1024) void k_rowmax_reduce(const double *__restrict__ part, int nblk, int W, int npad, unsigned long long *__restrict__ rowmax) {
+  // 64 values t = r * W + pose per workgroup (consecutive lanes, consecutive addresses of a workgroup's record), sixteen wavefronts share the
+  // records -- 512 of them at config 2, a chain of dependent maxima per value otherwise (one wavefront per 64 values: 44 us)
+  __shared__ double sm[16][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6, t = blockIdx.x * 64 + tx;
+  double m[4] = {0.0, 0.0, 0.0, 0.0};
+  if (t < 6 * W) {
+    int b = ty;
+    for (; b + 48 < nblk; b += 64) {
+#pragma unroll
+      for (int u = 0; u < 4; u++) m[u] = fmax(m[u], part[(size_t)(b + 16 * u) * 6 * W + t]);
+    }
+    for (; b < nblk; b += 16) m[0] = fmax(m[0], part[(size_t)b * 6 * W + t]);
+  }
+  sm[ty][tx] = fmax(fmax(m[0], m[1]), fmax(m[2], m[3]));
+  __syncthreads();
+  if (ty == 0) {
+    double v = sm[0][tx];
+#pragma unroll
+    for (int k = 1; k < 16; k++) v = fmax(v, sm[k][tx]);
+    if (t < 6 * W) {
+      const int r = t / W, pose = t - r * W;
+      rowmax[6 * pose + r] = (unsigned long long)__double_as_longlong(v);
+    } else if (t < npad) {
+      rowmax[t] = 0ull;
+    }
+  }
 }
 
 template <int FORM, bool REGS, bool MAXR = false>
@@ -538,7 +569,7 @@ __global__ __launch_bounds__(256) void k_feature_factors(const double *__restric
                                                          const double *__restrict__ feat, int W, int Wc, int npad, int f0,
                                                          int f1, double *__restrict__ Gt,
                                                          double *__restrict__ dpart, const int *__restrict__ slot, int staged,
-                                                         unsigned long long *__restrict__ rowmax = nullptr) {
+                                                         double *__restrict__ rowmax_part = nullptr) {
   static_assert(!MAXR || REGS, "the row maxima live in the lane that owns the pose");
   double rm[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
   // staged (round 4, the default wherever the LDS has room): a lane's six values of a Gt column are 48 contiguous bytes, a wavefront's 64 poses
@@ -666,7 +697,7 @@ __global__ __launch_bounds__(256) void k_feature_factors(const double *__restric
     if (threadIdx.x < (unsigned)wc) {
 #pragma unroll
       for (int k = 0; k < DACC; k++) dp[(size_t)k * W + threadIdx.x] = racc[k];
-      if (MAXR) publish_rowmax(rowmax, p0 + (int)threadIdx.x, rm);
+      if (MAXR) publish_rowmax(rowmax_part, W, p0 + (int)threadIdx.x, rm);
     }
     return;
   }
@@ -692,7 +723,7 @@ __global__ __launch_bounds__(320, 3) void k_moments_factors(const double *__rest
                                                          const double *__restrict__ fix, const double *__restrict__ coe_in, int W, int npad,
                                                          int F, double *__restrict__ Gt, double *__restrict__ dpart,
                                                          const int *__restrict__ slot, double *__restrict__ feat_out,
-                                                         double *__restrict__ rpart, unsigned long long *__restrict__ rowmax = nullptr) {
+                                                         double *__restrict__ rpart, double *__restrict__ rowmax_part = nullptr) {
   constexpr int DACC = FORM == 0 ? DACC_LEFT : DACC_RIGHT;
   double rm[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};      // (MAXR: k_feature_factors)
   extern __shared__ __attribute__((aligned(16))) double sm[];
@@ -820,7 +851,7 @@ __global__ __launch_bounds__(320, 3) void k_moments_factors(const double *__rest
   }
   double *dp = dpart + (size_t)blockIdx.x * DACC * W;
   for (int t = tid; t < DACC * W; t += blockDim.x) dp[t] = sacc[t];
-  if (MAXR && has_pose) publish_rowmax(rowmax, il, rm);
+  if (MAXR && has_pose) publish_rowmax(rowmax_part, W, il, rm);
   if (!is_pose && lane == 0) rpart[blockIdx.x] = res;
 }
 
@@ -872,16 +903,16 @@ hipError_t prepare_device_accum() {
 // the fused trial evaluation: residual partials (one per workgroup: returns their number), eigen records, Gt, per-pose partials
 int launch_moments_factors(hipStream_t s, int form, const double *cl, const double *poses, const double *fix, const double *coe, int W,
                            int npad, int F, double *Gt, double *dpart, int nblk, const int *slot, double *feat, double *rpart,
-                           unsigned long long *rowmax) {
+                           unsigned long long *rowmax, double *rowmax_part) {
   const int dacc = form == 0 ? DACC_LEFT : DACC_RIGHT;
   const size_t lds = (size_t)((12 + dacc) * W + 80 + 2 * FEAT_STRIDE) * sizeof(double);
   const int bs = (W <= 64 ? 64 : (W <= 128 ? 128 : 256)) + 64;
-  if (rowmax) {          // (the INT8 product's row exponents ride along: npad entries, zeroed here)
-    (void)hipMemsetAsync(rowmax, 0, (size_t)npad * sizeof(unsigned long long), s);
+  if (rowmax) {          // (the INT8 product's row maxima ride along: per workgroup, then one small reduction)
     if (form == 0)
-      hipLaunchKernelGGL((k_moments_factors<0, true>), dim3(nblk), dim3(bs), lds, s, cl, poses, fix, coe, W, npad, F, Gt, dpart, slot, feat, rpart, rowmax);
+      hipLaunchKernelGGL((k_moments_factors<0, true>), dim3(nblk), dim3(bs), lds, s, cl, poses, fix, coe, W, npad, F, Gt, dpart, slot, feat, rpart, rowmax_part);
     else
-      hipLaunchKernelGGL((k_moments_factors<1, true>), dim3(nblk), dim3(bs), lds, s, cl, poses, fix, coe, W, npad, F, Gt, dpart, slot, feat, rpart, rowmax);
+      hipLaunchKernelGGL((k_moments_factors<1, true>), dim3(nblk), dim3(bs), lds, s, cl, poses, fix, coe, W, npad, F, Gt, dpart, slot, feat, rpart, rowmax_part);
+    hipLaunchKernelGGL(k_rowmax_reduce, dim3((npad + 63) / 64), dim3(1024), 0, s, rowmax_part, nblk, W, npad, rowmax);
     return nblk;
   }
   if (form == 0)
@@ -892,9 +923,9 @@ int launch_moments_factors(hipStream_t s, int form, const double *cl, const doub
 }
 
 // rowmax (may be null): where the kernel variant that tracks them exists -- the left form with a pose per lane -- the rows' largest |entries|
-// are left there (npad entries) and the call returns true
+// are left there (npad entries; rowmax_part: 6 W doubles per workgroup of scratch) and the call returns true
 bool launch_factors(hipStream_t s, int form, const double *cl, const double *poses, const double *feat, int W,
-                    int npad, int f0, int f1, double *Gt, double *dpart, int nblk, const int *slot, unsigned long long *rowmax) {
+                    int npad, int f0, int f1, double *Gt, double *dpart, int nblk, const int *slot, unsigned long long *rowmax, double *rowmax_part) {
   const int Wc = factors_chunk(W), chunks = (W + Wc - 1) / Wc;
   size_t lds = factors_lds(W, form);
   int bs = W <= 64 ? 64 : (W <= 128 ? 128 : 256);
@@ -903,8 +934,8 @@ bool launch_factors(hipStream_t s, int form, const double *cl, const double *pos
   const char *er = getenv("BALM_FACTORS_REGS");                     // 0: the accumulators in LDS at every window (A/B, tests)
   const bool regs = form == 0 && chunks == 1 && W <= bs && !(er && er[0] == '0');
   if (rowmax && regs) {
-    (void)hipMemsetAsync(rowmax, 0, (size_t)npad * sizeof(unsigned long long), s);
-    hipLaunchKernelGGL((k_feature_factors<0, true, true>), dim3(nblk, chunks), dim3(bs), lds, s, cl, poses, feat, W, Wc, npad, f0, f1, Gt, dpart, slot, staged, rowmax);
+    hipLaunchKernelGGL((k_feature_factors<0, true, true>), dim3(nblk, chunks), dim3(bs), lds, s, cl, poses, feat, W, Wc, npad, f0, f1, Gt, dpart, slot, staged, rowmax_part);
+    hipLaunchKernelGGL(k_rowmax_reduce, dim3((npad + 63) / 64), dim3(1024), 0, s, rowmax_part, nblk, W, npad, rowmax);
     return true;
   }
 #define BALM_FACTORS(F, R) hipLaunchKernelGGL((k_feature_factors<F, R, false>), dim3(nblk, chunks), dim3(bs), lds, s, cl, poses, feat, W, Wc, npad, f0, f1, Gt, dpart, slot, staged, nullptr)

@@ -26,6 +26,12 @@ namespace balm {
 namespace {
 
 constexpr int I8_DIGITS = 4, I8_SETS = 5, I8_TILE = 128, I8_KS = 64, I8_XCDS = 8;
+// The digits' radix: 254, not 256 -- round-to-nearest digits of radix 256 reach +128, which an int8 does not hold (and a digit set [-128, 127]
+// leaves the greedy expansion exactly one admissible rounding offset, 127/255: one ulp decides), 254 keeps |digit| <= 127 by construction.  A
+// radix that is not a power of two costs the slicing one rounding (2^-53 of the entry) per digit: the products stay exact integers, the
+// weights radix^-(a+b+2) are applied once, in FP64.  (Radix 128, |digit| <= 64, was the first build: 2.4e-11 of the full-size test's scale
+// instead of 1.1e-12.)
+constexpr double I8_RADIX = 254.0;
 typedef int v4i __attribute__((ext_vector_type(4)));
 
 __global__ __launch_bounds__(256) void k_i8_rowmax(const double *__restrict__ Gt, int npad, int rows, long K, int kchunk,
@@ -76,8 +82,8 @@ __global__ __launch_bounds__(256) void k_i8_slice(const double *__restrict__ Gt,
       double r = isfinite(x[u]) ? ldexp(x[u], -e) : 0.0;
 #pragma unroll
       for (int a = 0; a < I8_DIGITS; a++) {
-        r *= 128.0;
-        const double d = rint(r);
+        r *= I8_RADIX;
+        const double d = rint(r);            // |r| <= 127: |x / 2^e| < 0.5 for the first digit, a remainder |r - d| <= 0.5 for the next
         r -= d;
         w[a] |= ((unsigned int)(int)d & 0xffu) << (8 * u);
       }
@@ -110,15 +116,16 @@ __device__ __forceinline__ void i8_glds16(const signed char *src, void *lds_wave
 // four wavefronts of 64 x 64 the 320 accumulator registers do not fit the 256 AGPRs and the compiler shuttles the rest through
 // v_accvgpr moves, 768 per step: 2.05 ms, measured), the second wavefront of a SIMD covers the other's LDS waits.
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_syrk_i8(const signed char *__restrict__ D, long Kp, int rows_p, int T,
-                                                                                           int NT, int *__restrict__ P) {
+                                                                                           int NT, int M, int *__restrict__ P) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];      // two stages of [side 2][digit 4][row group 8][1 KB]: 128 KB
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, wr = wv >> 1, wc = wv & 1;      // rows wr * 32 .., columns wc * 64 .. of the tile
   const int xcd = blockIdx.x & 7;                 // (the hardware places workgroup b on XCD b mod 8: an XCD's workgroups share its eighth of the columns)
-  int tile = blockIdx.x >> 3, I = 0;
+  const int ksl = xcd * M + (int)((blockIdx.x >> 3) % M);      // the k-slice: M per XCD (1 up to 262 144 columns: the int32 sums' bound)
+  int tile = (int)((blockIdx.x >> 3) / M), I = 0;
   { int left = tile; while (left >= T - I) { left -= T - I; I++; } tile = left; }
   const int J = I + tile;
-  const int tix = blockIdx.x >> 3;
-  const long Kx = Kp / I8_XCDS;
+  const int tix = (int)((blockIdx.x >> 3) / M);
+  const long Kx = Kp / (I8_XCDS * M);
   const int nsteps = (int)(Kx / I8_KS);
   const bool diag = I == J;
   // this wavefront's eight pieces of a stage: piece p = wv * 8 + i -> (side, digit, row group); the lane's source offset inside a stage
@@ -128,7 +135,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
   for (int i = 0; i < 8; i++) {
     const int p = wv * 8 + i, side = p >> 5, dg = (p >> 3) & 3, rg = p & 7;
-    src[i] = ((dg * RG + (side ? J : I) * 8 + rg) * KS + xcd * nsteps) * 1024u + lane * 16;
+    src[i] = ((dg * RG + (side ? J : I) * 8 + rg) * KS + ksl * nsteps) * 1024u + lane * 16;
   }
   v4i acc[I8_SETS][2][4];
 #pragma unroll
@@ -148,6 +155,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   for (int step = 0; step < nsteps; step++) {
     __builtin_amdgcn_s_waitcnt(0x0f70);          // vmcnt(0): this wavefront's pieces of the stage are in LDS
     __syncthreads();                             // ... and everybody else's; and everybody is done reading the other buffer
+    // (the stage in two halves, the second between the MFMA groups: 1.40 ms against 1.10 -- the compiler fences the fragment reads behind it)
     if (step + 1 < nsteps) issue(step + 1);
     const unsigned char *buf = lds + (size_t)(step & 1) * 65536;
     const unsigned char *bufA = buf + (size_t)(wr * 2) * 1024 + lane * 16;
@@ -175,7 +183,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
   }
   // C/D layout of the 16 x 16 forms: col = lane & 15, row = (lane >> 4) * 4 + reg
-  int *out = P + ((size_t)xcd * NT + tix) * I8_SETS * (I8_TILE * I8_TILE);
+  int *out = P + ((size_t)ksl * NT + tix) * I8_SETS * (I8_TILE * I8_TILE);
 #pragma unroll
   for (int s = 0; s < I8_SETS; s++)
 #pragma unroll
@@ -191,7 +199,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
 // sum over k-slices and sets -> FP64 in k_hessian_syrk's tile layout (one split-K slice): part[tile * 6400 + (mt * 4 + reg) * 64 + lane]
 __global__ __launch_bounds__(256) void k_i8_pack(const int *__restrict__ P, int NT, int T, const double *__restrict__ rowscale, const int *__restrict__ tileIJ,
-                                                 int ntiles, int n, double *__restrict__ part) {
+                                                 int ntiles, int n, int nslices, double *__restrict__ part) {
   const long total = (long)ntiles * TILE_ELEMS;
   for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
     const int tl = (int)(t / TILE_ELEMS);
@@ -206,12 +214,12 @@ __global__ __launch_bounds__(256) void k_i8_pack(const int *__restrict__ P, int 
       const int I = row / I8_TILE, J = col / I8_TILE;
       const int tix = I * T - I * (I - 1) / 2 + (J - I);
       const int ri = row - I * I8_TILE, cj = col - J * I8_TILE;
-      double w = 1.0 / 16384.0;                                  // 128^-(a+b+2) for a + b = 0
+      double w = 1.0 / (I8_RADIX * I8_RADIX);                    // radix^-(a+b+2) for a + b = 0
       for (int s = 0; s < I8_SETS; s++) {
         long long sum = 0;
-        for (int x = 0; x < I8_XCDS; x++) sum += P[(((size_t)x * NT + tix) * I8_SETS + s) * (I8_TILE * I8_TILE) + ri * I8_TILE + cj];
+        for (int x = 0; x < nslices; x++) sum += P[(((size_t)x * NT + tix) * I8_SETS + s) * (I8_TILE * I8_TILE) + ri * I8_TILE + cj];
         val += w * (double)sum;
-        w *= 1.0 / 128.0;
+        w *= 1.0 / I8_RADIX;
       }
       val *= rowscale[row] * rowscale[col];
     }
@@ -227,12 +235,15 @@ size_t syrk_i8_scratch_bytes(int n, long K, I8Layout *lay) {
   L.T = (n + I8_TILE - 1) / I8_TILE;
   L.rows_p = L.T * I8_TILE;
   L.NT = L.T * (L.T + 1) / 2;
-  L.Kp = (K + I8_XCDS * I8_KS - 1) / (I8_XCDS * I8_KS) * (I8_XCDS * I8_KS);
+  // k-slices: eight (one per XCD) times M, M the smallest count that keeps a slice's int32 sums exact: 4 pairs x 128^2 x columns < 2^31
+  L.M = 1;
+  while ((K + (long)I8_XCDS * L.M * I8_KS - 1) / ((long)I8_XCDS * L.M * I8_KS) * I8_KS > 32704) L.M++;
+  L.Kp = (K + (long)I8_XCDS * L.M * I8_KS - 1) / ((long)I8_XCDS * L.M * I8_KS) * ((long)I8_XCDS * L.M * I8_KS);
   L.off_digits = 0;
   size_t off = (size_t)I8_DIGITS * L.rows_p * L.Kp;
   off = (off + 255) & ~(size_t)255; L.off_rowmax = off; off += (size_t)L.rows_p * 8;
   off = (off + 255) & ~(size_t)255; L.off_scale = off; off += (size_t)L.rows_p * 8;
-  off = (off + 255) & ~(size_t)255; L.off_part = off; off += (size_t)I8_XCDS * L.NT * I8_SETS * I8_TILE * I8_TILE * sizeof(int);
+  off = (off + 255) & ~(size_t)255; L.off_part = off; off += (size_t)I8_XCDS * L.M * L.NT * I8_SETS * I8_TILE * I8_TILE * sizeof(int);
   if (lay) *lay = L;
   return off;
 }
@@ -248,7 +259,7 @@ int launch_syrk_i8(hipStream_t s, const double *Gt, int npad, int n, long K, con
                    const unsigned long long *rowmax_known) {
   I8Layout L;
   syrk_i8_scratch_bytes(n, K, &L);
-  if (K < 1 || L.Kp / I8_XCDS * 4 * 4096 >= (1l << 31) || (size_t)I8_DIGITS * L.rows_p * L.Kp >= ((size_t)1 << 32)) return -1;
+  if (K < 1 || (size_t)I8_DIGITS * L.rows_p * L.Kp >= ((size_t)1 << 32)) return -1;      // (k_syrk_i8's 32-bit operand offsets)
   signed char *D = reinterpret_cast<signed char *>(scratch + L.off_digits);
   auto *rowmax = reinterpret_cast<unsigned long long *>(scratch + L.off_rowmax);
   double *rowscale = reinterpret_cast<double *>(scratch + L.off_scale);
@@ -258,11 +269,11 @@ int launch_syrk_i8(hipStream_t s, const double *Gt, int npad, int n, long K, con
   else if (hipMemsetAsync(rowmax, 0, (size_t)L.rows_p * 8, s) != hipSuccess) return -1;
   if (!rowmax_known) hipLaunchKernelGGL(k_i8_rowmax, dim3((npad + 255) / 256, (unsigned int)((K + kchunk - 1) / kchunk)), dim3(256), 0, s, Gt, npad, npad < L.rows_p ? npad : L.rows_p, K, kchunk, rowmax);
   hipLaunchKernelGGL(k_i8_slice, dim3(L.rows_p / 64, (unsigned int)(L.Kp / 64)), dim3(256), 0, s, Gt, npad, K, L.Kp, L.rows_p, rowmax, D, rowscale);
-  hipLaunchKernelGGL(k_syrk_i8, dim3(I8_XCDS * L.NT), dim3(512), 128 * 1024, s, D, L.Kp, L.rows_p, L.T, L.NT, P);
+  hipLaunchKernelGGL(k_syrk_i8, dim3(I8_XCDS * L.M * L.NT), dim3(512), 128 * 1024, s, D, L.Kp, L.rows_p, L.T, L.NT, L.M, P);
   long total = (long)ntiles * TILE_ELEMS;
   int grid = (int)((total + 255) / 256);
   if (grid > 8192) grid = 8192;
-  hipLaunchKernelGGL(k_i8_pack, dim3(grid), dim3(256), 0, s, P, L.NT, L.T, rowscale, tileIJ, ntiles, n, part);
+  hipLaunchKernelGGL(k_i8_pack, dim3(grid), dim3(256), 0, s, P, L.NT, L.T, rowscale, tileIJ, ntiles, n, I8_XCDS * L.M, part);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

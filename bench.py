@@ -309,6 +309,7 @@ def main(argv=None):
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--no-strong-ref", action="store_true",
                     help="N = 1: skip the extra untimed-contract leg that runs configs[3]'s 200 000 features on the one GPU")
+    ap.add_argument("--no-int8", action="store_true", help="N = 1: skip the extra leg that repeats the timed loop with BALM_SYRK=int8")
     ap.add_argument("--no-realworld", action="store_true", help="N = 1: skip the shipped-window end-to-end leg (datasets/realworld_w177.npz)")
     ap.add_argument("--no-one-gpu-ref", action="store_true",
                     help="N > 1: skip rank 0's run of the whole problem on one GPU (speedup_vs_one_gpu_same_problem / scaling_efficiency stay null)")
@@ -390,14 +391,14 @@ def main(argv=None):
 
     # the natural LM run first (untimed region of the contract; reported as its own figure): from the noisy start to
     # the reference's own stop rule, benchmark_virtual.cpp's constants
-    ctx.evaluate(0, sc.poses_init)                 # (the process's first device work -- code objects, buffers -- is not the run's)
+    H_first = ctx.evaluate(0, sc.poses_init)[0]    # (the process's first device work -- code objects, buffers -- is not the run's)
     barrier()
     t0 = time.perf_counter()
-    _, lg_nat = ctx.damping_iter(sc.poses_init, form=0, u0=0.1, max_iter=20)
+    poses_nat, lg_nat = ctx.damping_iter(sc.poses_init, form=0, u0=0.1, max_iter=20)
     barrier()
     t_nat = time.perf_counter() - t0
 
-    def run_steps(k):
+    def run_steps(k, ctx=ctx):
         """exactly k LM iterations, in runs of at most 20 from the noisy start (a run that sat at the optimum for hundreds
         of iterations would only multiply the damping after rounding-level rejections)"""
         logs = []
@@ -607,6 +608,43 @@ def main(argv=None):
             ctx.set_features(sc.clusters, None, sc.coeffs)
         except Exception as e:
             out["strong_scaling_reference"] = {"error": repr(e)}
+    if n_gpus == 1 and not multi and not args.no_cpu and not args.no_int8:
+        # BALM_SYRK=int8 (opt-in): the same workload, the same timed loop, K3 on the INT8 matrix cores by error-free slicing.  An
+        # EXTRA key: `value`, `dtype` and `roofline` above are the default FP64 path's.
+        try:
+            os.environ["BALM_SYRK"] = "int8"
+            c8 = capi.Context(W, local_rank, capi.FLAG_TIMING)
+            c8.set_features(sc.clusters, None, sc.coeffs)
+            H8 = c8.evaluate(0, sc.poses_init)[0]
+            poses8, lg8 = c8.damping_iter(sc.poses_init, form=0, u0=0.1, max_iter=20)
+            if args.warmup > 0:
+                run_steps(args.warmup, c8)
+            c8.reset_timing()
+            barrier()
+            t0 = time.perf_counter()
+            lg8s = run_steps(args.steps, c8)
+            barrier()
+            dt8 = time.perf_counter() - t0
+            t8 = c8.timing()
+            c8.close()
+            rot8, tr8 = _pose_diff(poses8, poses_nat)
+            out["int8_syrk"] = {
+                "what": "the same %d timed LM iterations with BALM_SYRK=int8: Gt Gt^T as eleven exact int32 digit products on v_mfma_i32_16x16x64_i8 "
+                        "(4 signed 7-bit digits per entry, one exponent per row), everything else unchanged; opt-in, not the default" % args.steps,
+                "value": args.steps / dt8, "unit": "iter/s", "ms_per_step": dt8 / args.steps * 1e3,
+                "speedup_vs_value": (args.steps / dt8) / iters_per_s,
+                "dtype": "i8 digits x i8 digits -> i32 (exact), recombined in f64",
+                "syrk_avg_launch_ms": t8["syrk"][0] / max(1, t8["syrk"][1]), "fp64_syrk_avg_launch_ms": syrk_s * 1e3 if syrk_s else None,
+                "kernel_ms_per_step": {k: v[0] / args.steps for k, v in t8.items()},
+                "max_abs_H_difference_over_max_abs_diag_H": float(np.abs(H8 - H_first).max() / np.abs(np.diag(H_first)).max()),
+                "natural_lm_run": {"iterations": int(len(lg8)), "iterations_fp64": int(len(lg_nat)), "final_residual": float(lg8[-1, 1]),
+                                   "final_residual_fp64": float(lg_nat[-1, 1]), "max_pose_difference_to_fp64_run": {"rot_rad": rot8, "trans_m": tr8}},
+                "final_residual": float(lg8s[-1, 1]),
+            }
+        except Exception as e:
+            out["int8_syrk"] = {"error": repr(e)}
+        finally:
+            os.environ.pop("BALM_SYRK", None)
     if n_gpus == 1 and not multi and not args.no_cpu and not args.no_realworld:
         # the path the reference ships data for (benchmark_realworld.cpp:183-218), end to end from host memory; an extra key,
         # outside the timed region of `value`
