@@ -373,6 +373,9 @@ def test_bench_size_properties():
     orthogonality of the gradient, the oracle on a random sample of the features through the sub-range entry, and
     an LM run that must reach the ground truth."""
     W, F = 200, 50000
+    # (under BALM_SYRK=int8 -- the whole suite can be run with it -- the Hessian's tolerances are the switch's contract at this size, 1e-11 of the
+    #  largest entry: a sub-range and a reweighted table slice to different digits; g and the residual do not pass through the product)
+    htol_split, htol_lin = (1e-11, 1e-11) if os.environ.get("BALM_SYRK") == "int8" else (1e-12, 1e-13)
     sc = scene.generate(123, W, F, 6, mode=1)
     c = capi.Context(W)
     c.set_features(sc.clusters, None, sc.coeffs)
@@ -382,7 +385,7 @@ def test_bench_size_properties():
     cut = 17321
     H1, g1, r1 = c.evaluate(0, sc.poses_init, 0, cut)
     H2, g2, r2 = c.evaluate(0, sc.poses_init, cut, F)
-    assert rel_err(H1 + H2, H) < 1e-12 and rel_err(g1 + g2, g) < 1e-12 and abs(r1 + r2 - r) / r < 1e-13
+    assert rel_err(H1 + H2, H) < htol_split and rel_err(g1 + g2, g) < 1e-12 and abs(r1 + r2 - r) / r < 1e-13
     # (2) gauge: a common left translation leaves the residual unchanged
     assert np.abs(g.reshape(W, 6)[:, 3:].sum(0)).max() < 1e-9 * np.abs(g).max()
     # (3) the oracle on 48 consecutive features somewhere in the middle, via the sub-range entry
@@ -396,7 +399,7 @@ def test_bench_size_properties():
     c2 = capi.Context(W)
     c2.set_features(sc.clusters, None, 3.0 * sc.coeffs)
     H3, g3, r3 = c2.evaluate(0, sc.poses_init)
-    assert rel_err(H3, 3.0 * H) < 1e-13 and abs(r3 - 3.0 * r) / r < 1e-13
+    assert rel_err(H3, 3.0 * H) < htol_lin and abs(r3 - 3.0 * r) / r < 1e-13
     c2.close()
     # (6) the LM loop reaches the ground truth of the scene (RSME as benchmark_virtual.cpp:48-61 reports it)
     out, lg = c.damping_iter(sc.poses_init, form=0, u0=0.1, max_iter=20)

@@ -22,6 +22,7 @@ def evaluate(sc, mode, form=0, fix=None, sub=None):
         os.environ["BALM_SYRK"] = mode
     else:
         os.environ.pop("BALM_SYRK", None)
+    os.environ["BALM_SYRK_INT8_MIN_COLS"] = "0"      # (the switch engages from 12 288 columns on by itself: here at every size)
     try:
         c = capi.Context(sc.W)
         c.set_features(sc.clusters, fix, sc.coeffs)
@@ -29,6 +30,7 @@ def evaluate(sc, mode, form=0, fix=None, sub=None):
         c.close()
     finally:
         os.environ.pop("BALM_SYRK", None)
+        os.environ.pop("BALM_SYRK_INT8_MIN_COLS", None)
     return out
 
 
@@ -46,6 +48,24 @@ def test_int8_product_against_the_fp64_product(seed, W, F, form):
     assert np.array_equal(gd, gi) and rd == ri
     assert np.abs(Hi - Hd).max() <= 5e-10 * scale, np.abs(Hi - Hd).max() / scale
     assert form == 1 or np.array_equal(Hi, Hi.T)
+
+
+def test_int8_engages_from_12288_columns_on_by_itself(monkeypatch):
+    """below the threshold BALM_SYRK=int8 leaves the FP64 product in place: bit for bit the default's Hessian; above it, not"""
+    from balm_amd import capi
+    monkeypatch.setenv("BALM_SYRK", "dense")
+    out = {}
+    for F in (4000, 4200):
+        sc = scene.generate(31, 24, F, 6, mode=1)
+        for mode in ("dense", "int8"):
+            monkeypatch.setenv("BALM_SYRK", mode)
+            c = capi.Context(sc.W)
+            c.set_features(sc.clusters, None, sc.coeffs)
+            out[F, mode] = c.evaluate(0, sc.poses_init)[0]
+            c.close()
+    assert np.array_equal(out[4000, "dense"], out[4000, "int8"])
+    d = np.abs(out[4200, "dense"] - out[4200, "int8"]).max()
+    assert 0 < d <= 1e-10 * np.abs(np.diag(out[4200, "dense"])).max()
 
 
 def test_int8_product_on_a_feature_sub_range_and_after_a_wider_one():
@@ -80,6 +100,7 @@ def test_int8_lm_run_reproduces_the_reference_run(case, which, monkeypatch):
     from balm_amd import capi
     from test_north_star import CONSTANTS, check_run, load
     monkeypatch.setenv("BALM_SYRK", "int8")
+    monkeypatch.setenv("BALM_SYRK_INT8_MIN_COLS", "0")
     k = CONSTANTS[which]
     g, sc = load(case)
     c = capi.Context(sc.W)
