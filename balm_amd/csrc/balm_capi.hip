@@ -624,7 +624,8 @@ static void one_destroy(balm_ctx *ctx) {
 static int build_sparse_plan(balm_ctx *ctx, int F, const unsigned char *obs) {
   ctx->sparse = false;
   const char *mode = getenv("BALM_SYRK");
-  if (mode && (!strcmp(mode, "dense") || !strcmp(mode, "int8"))) return BALM_OK;      // (the INT8 product is a dense plan)
+  if (mode && !strcmp(mode, "dense")) return BALM_OK;
+  if (syrk_int8_for(3L * F)) return BALM_OK;      // (the INT8 product is a dense plan; below its threshold the 80 %-rule decides as ever)
   const int W = ctx->W, T = ctx->T, ntiles = ctx->ntiles;
   if (T > 128 || T <= 2 || F < 64) return BALM_OK;      // (two row blocks: three tile jobs, nothing a plan could skip -- and a 20-pose
                                                          //  sliding window installs a table per slide: the plan's host time is not free)

@@ -524,14 +524,20 @@ __device__ __forceinline__ void obs_factors(const FeatRec &fr, const double P[6]
 // product's digit slicing (kernels_syrk_i8.hip) without a pass of their own over Gt.  (One atomicMax per lane and row on rowmax itself: 512
 // workgroups x 1200 addresses, 512 device-scope atomics in a row on every address -- +48 us on the 407 us kernel, measured.)  The default
 // instantiations are MAXR = false.
-__device__ __forceinline__ void track_rowmax(double rm[6], const double col0[6], const double col1[6], const double col2[6]) {
+// (fmax drops a NaN: `bad` turns NaN at the first non-finite entry of the pose's rows -- 0 x inf, 0 x NaN -- and stays; such a pose's six maxima are
+//  published as NaN, the slicing gives its rows a NaN scale and H gets the non-finite rows and columns the FP64 product would give it)
+__device__ __forceinline__ void track_rowmax(double rm[6], double &bad, const double col0[6], const double col1[6], const double col2[6]) {
 #pragma unroll
-  for (int k = 0; k < 6; k++) rm[k] = fmax(rm[k], fmax(fabs(col0[k]), fmax(fabs(col1[k]), fabs(col2[k]))));
+  for (int k = 0; k < 6; k++) {
+    rm[k] = fmax(rm[k], fmax(fabs(col0[k]), fmax(fabs(col1[k]), fabs(col2[k]))));
+    bad = fma(col0[k] + col1[k] + col2[k], 0.0, bad);
+  }
 }
-__device__ __forceinline__ void publish_rowmax(double *__restrict__ part, int W, int pose, const double rm[6]) {
+__device__ __forceinline__ void publish_rowmax(double *__restrict__ part, int W, int pose, const double rm[6], double bad) {
 #pragma unroll
-  for (int k = 0; k < 6; k++) part[(size_t)(blockIdx.x * 6 + k) * W + pose] = rm[k];
+  for (int k = 0; k < 6; k++) part[(size_t)(blockIdx.x * 6 + k) * W + pose] = bad != bad ? bad : rm[k];
 }
+__device__ __forceinline__ double nanmax(double a, double b) { return (a != a || b != b) ? __longlong_as_double(0x7ff8000000000000ll) : fmax(a, b); }
 // rowmax[6 pose + r] = max over the workgroups, as the bit pattern the slicing kernel reads (non-negative doubles order like their bits);
 // rows beyond the window: 0
 __global__ __launch_bounds__(1024) void k_rowmax_reduce(const double *__restrict__ part, int nblk, int W, int npad, unsigned long long *__restrict__ rowmax) {
@@ -544,16 +550,16 @@ __global__ __launch_bounds__(1024) void k_rowmax_reduce(const double *__restrict
     int b = ty;
     for (; b + 48 < nblk; b += 64) {
 #pragma unroll
-      for (int u = 0; u < 4; u++) m[u] = fmax(m[u], part[(size_t)(b + 16 * u) * 6 * W + t]);
+      for (int u = 0; u < 4; u++) m[u] = nanmax(m[u], part[(size_t)(b + 16 * u) * 6 * W + t]);
     }
-    for (; b < nblk; b += 16) m[0] = fmax(m[0], part[(size_t)b * 6 * W + t]);
+    for (; b < nblk; b += 16) m[0] = nanmax(m[0], part[(size_t)b * 6 * W + t]);
   }
-  sm[ty][tx] = fmax(fmax(m[0], m[1]), fmax(m[2], m[3]));
+  sm[ty][tx] = nanmax(nanmax(m[0], m[1]), nanmax(m[2], m[3]));
   __syncthreads();
   if (ty == 0) {
     double v = sm[0][tx];
 #pragma unroll
-    for (int k = 1; k < 16; k++) v = fmax(v, sm[k][tx]);
+    for (int k = 1; k < 16; k++) v = nanmax(v, sm[k][tx]);
     if (t < 6 * W) {
       const int r = t / W, pose = t - r * W;
       rowmax[6 * pose + r] = (unsigned long long)__double_as_longlong(v);
@@ -571,7 +577,7 @@ __global__ __launch_bounds__(256) void k_feature_factors(const double *__restric
                                                          double *__restrict__ dpart, const int *__restrict__ slot, int staged,
                                                          double *__restrict__ rowmax_part = nullptr) {
   static_assert(!MAXR || REGS, "the row maxima live in the lane that owns the pose");
-  double rm[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  double rm[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0}, bad = 0.0;
   // staged (round 4, the default wherever the LDS has room): a lane's six values of a Gt column are 48 contiguous bytes, a wavefront's 64 poses
   // 3 KB -- written lane by lane as three 16-byte stores, every store instruction touches a THIRD of each 48-byte segment of 24 cache lines,
   // three times over.  Through a 3 KB staging block per wavefront in LDS the same bytes leave as three stores of 1 KB each, consecutive lanes
@@ -660,7 +666,7 @@ __global__ __launch_bounds__(256) void k_feature_factors(const double *__restric
       if (il == (int)threadIdx.x && a + a_step < a_end) fetch(a + a_step, i_first);
       if (REGS) obs_factors<FORM>(fr, P, v, N, preg, racc, 1, 0, col0, col1, col2);
       else obs_factors<FORM>(fr, P, v, N, sp, sacc, Wc, act ? il : wc - 1, col0, col1, col2);
-      if (MAXR) track_rowmax(rm, col0, col1, col2);
+      if (MAXR) track_rowmax(rm, bad, col0, col1, col2);
       // (Measured and rejected on the lane-by-lane stores, round 4, profiles/r04d_factors_ab.txt: streaming (nontemporal) stores -- 0.555 vs
       // 0.553 ms; the lane's pose in twelve registers instead of the LDS table, i.e. THREE workgroups per CU -- 0.565 vs 0.554.)
       if (!staged) {
@@ -697,7 +703,7 @@ __global__ __launch_bounds__(256) void k_feature_factors(const double *__restric
     if (threadIdx.x < (unsigned)wc) {
 #pragma unroll
       for (int k = 0; k < DACC; k++) dp[(size_t)k * W + threadIdx.x] = racc[k];
-      if (MAXR) publish_rowmax(rowmax_part, W, p0 + (int)threadIdx.x, rm);
+      if (MAXR) publish_rowmax(rowmax_part, W, p0 + (int)threadIdx.x, rm, bad);
     }
     return;
   }
@@ -725,7 +731,7 @@ __global__ __launch_bounds__(320, 3) void k_moments_factors(const double *__rest
                                                          const int *__restrict__ slot, double *__restrict__ feat_out,
                                                          double *__restrict__ rpart, double *__restrict__ rowmax_part = nullptr) {
   constexpr int DACC = FORM == 0 ? DACC_LEFT : DACC_RIGHT;
-  double rm[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};      // (MAXR: k_feature_factors)
+  double rm[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0}, bad = 0.0;      // (MAXR: k_feature_factors)
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int npl = (int)blockDim.x - 64, npw = npl >> 6;      // pose lanes / waves; the last wave is the eigen wave
   double *sp = sm;                                           // [12][W] poses
@@ -837,7 +843,7 @@ __global__ __launch_bounds__(320, 3) void k_moments_factors(const double *__rest
       if (has_pose) {
         double col0[6], col1[6], col2[6];
         obs_factors<FORM>(fr, cur, cur + 6, cur[9], sp, sacc, W, il, col0, col1, col2);
-        if (MAXR) track_rowmax(rm, col0, col1, col2);
+        if (MAXR) track_rowmax(rm, bad, col0, col1, col2);
         double *g0 = Gt + (size_t)(3 * (slot ? slot[a] : a)) * npad;
         store6(g0 + 6 * il, col0);
         store6(g0 + (size_t)npad + 6 * il, col1);
@@ -851,7 +857,7 @@ __global__ __launch_bounds__(320, 3) void k_moments_factors(const double *__rest
   }
   double *dp = dpart + (size_t)blockIdx.x * DACC * W;
   for (int t = tid; t < DACC * W; t += blockDim.x) dp[t] = sacc[t];
-  if (MAXR && has_pose) publish_rowmax(rowmax_part, W, il, rm);
+  if (MAXR && has_pose) publish_rowmax(rowmax_part, W, il, rm, bad);
   if (!is_pose && lane == 0) rpart[blockIdx.x] = res;
 }
 

@@ -39,17 +39,18 @@ __global__ __launch_bounds__(256) void k_i8_rowmax(const double *__restrict__ Gt
   const int row = blockIdx.x * 256 + threadIdx.x;
   if (row >= rows) return;
   const long k0 = (long)blockIdx.y * kchunk, k1 = min(K, k0 + kchunk);
-  double m = 0.0;
+  double m = 0.0, bad = 0.0;                       // (bad: NaN from the first non-finite entry on -- fmax drops a NaN; k_feature_factors' track_rowmax)
   long k = k0;
   for (; k + 8 <= k1; k += 8) {
     double v[8];
 #pragma unroll
     for (int u = 0; u < 8; u++) v[u] = Gt[(size_t)(k + u) * npad + row];
 #pragma unroll
-    for (int u = 0; u < 8; u++) m = fmax(m, fabs(v[u]));
+    for (int u = 0; u < 8; u++) { m = fmax(m, fabs(v[u])); bad = fma(v[u], 0.0, bad); }
   }
-  for (; k < k1; k++) m = fmax(m, fabs(Gt[(size_t)k * npad + row]));
-  if (m > 0.0) atomicMax(rowmax + row, (unsigned long long)__double_as_longlong(m));      // (non-negative doubles order like their bits)
+  for (; k < k1; k++) { const double v = Gt[(size_t)k * npad + row]; m = fmax(m, fabs(v)); bad = fma(v, 0.0, bad); }
+  if (bad != bad) m = __longlong_as_double(0x7ff8000000000000ll);
+  if (m > 0.0 || m != m) atomicMax(rowmax + row, (unsigned long long)__double_as_longlong(m));      // (non-negative doubles order like their bits, NaN above all)
 }
 
 // 64 rows x 64 columns per workgroup: coalesced loads along the rows, digits packed four columns to a word, out as 16-byte row pieces
@@ -62,12 +63,13 @@ __global__ __launch_bounds__(256) void k_i8_slice(const double *__restrict__ Gt,
   const int rl = threadIdx.x & 63, kg = threadIdx.x >> 6;  // the thread's row, its sixteen columns kg * 16 ..
   const int row = r0 + rl;
   int e = 0;
-  bool live = false;
+  bool live = false, nonfinite = false;
   if (row < npad && row < rows_p) {
     const double m = __longlong_as_double((long long)rowmax[row]);
-    if (m > 0.0 && isfinite(m)) { e = ilogb(m) + 2; live = true; }       // |x| / 2^e < 0.5: the first digit stays within +-64
+    if (m > 0.0 && isfinite(m)) { e = ilogb(m) + 2; live = true; }       // |x| / 2^e < 0.5: the first digit stays within +-127
+    else if (!(m == 0.0)) nonfinite = true;                              // a row with an infinite or NaN entry: NaN scale -> its row and column of H
   }
-  if (blockIdx.y == 0 && kg == 0 && row < rows_p) rowscale[row] = live ? ldexp(1.0, e) : 0.0;
+  if (blockIdx.y == 0 && kg == 0 && row < rows_p) rowscale[row] = live ? ldexp(1.0, e) : (nonfinite ? __longlong_as_double(0x7ff8000000000000ll) : 0.0);
 #pragma unroll
   for (int j = 0; j < 4; j++) {
     double x[4];

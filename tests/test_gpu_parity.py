@@ -6,6 +6,8 @@ Tolerances (FP64 on both sides; only the summation order differs, SURVEY.md 7 ha
   LM trace (r1, r2, u)          : 1e-8 relative
   final poses                   : BASELINE.json north_star: rotation <= 1e-5 rad, translation <= 1e-4 m
 """
+import os
+
 import numpy as np
 import pytest
 

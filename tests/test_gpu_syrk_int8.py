@@ -68,6 +68,27 @@ def test_int8_engages_from_12288_columns_on_by_itself(monkeypatch):
     assert 0 < d <= 1e-10 * np.abs(np.diag(out[4200, "dense"])).max()
 
 
+@pytest.mark.parametrize("W,form", [(40, 0), (40, 1)])
+def test_int8_product_keeps_a_non_finite_factor_non_finite(W, form):
+    """a feature that is ONE point (eight copies of a pose's origin, seen by that pose only) has the covariance 0 exactly: lambda_1 - lambda_0 = 0,
+    c_1 = sqrt(2 w / 0) / N = inf (bavoxel.hpp:371-378 divides the same way) and its columns of Gt are non-finite for that pose while g and the
+    residual stay finite.  The FP64 product leaves non-finite rows and columns in H for that pose; so must the sliced one (a NaN dropped by the
+    row maximum would slice the row to zeros) -- through the factor kernel's maxima (left form) and through the pass over Gt (right form)"""
+    sc = scene.generate(41, W, 300, 6, mode=1)
+    seen = np.array([17])
+    sc.clusters = sc.clusters.copy()
+    sc.clusters[123] = 0.0
+    sc.clusters[123, 17, 9] = 8.0
+    sc.coeffs = sc.clusters[..., 9].sum(1)
+    Hd = evaluate(sc, "dense", form)[0]
+    Hi = evaluate(sc, "int8", form)[0]
+    assert len(seen) > 0 and not np.isfinite(Hd).all()
+    rows = (6 * seen[:, None] + np.arange(6)[None, :]).reshape(-1)
+    bad_d, bad_i = ~np.isfinite(Hd), ~np.isfinite(Hi)
+    assert bad_d[rows].any(axis=1).all() and bad_i[rows].any(axis=1).all()
+    assert np.array_equal(bad_i.any(axis=1), bad_d.any(axis=1))        # the same rows are touched
+
+
 def test_int8_product_on_a_feature_sub_range_and_after_a_wider_one():
     """evaluate(head, end): the product over a sub-range of the columns (fewer k-steps, the same scratch)"""
     sc = scene.generate(21, 50, 900, 6, mode=1)

@@ -21,6 +21,7 @@ def run(sc, mode, reps):
         os.environ["BALM_SYRK"] = mode
     else:
         os.environ.pop("BALM_SYRK", None)
+    os.environ["BALM_SYRK_INT8_MIN_COLS"] = "0"      # (the INT8 product at every size: by itself the switch engages from 12 288 columns on)
     c = capi.Context(sc.W, 0, capi.FLAG_TIMING)
     c.set_features(sc.clusters, None, sc.coeffs)
     H, g, r = c.evaluate(0, sc.poses_init)
