@@ -1225,6 +1225,12 @@ static int one_pose_covariance(balm_ctx *ctx, const double *poses, const double 
   if ((rc = ensure(ctx, &ctx->d_part, &ctx->cap_part, (size_t)plan.SG * tiles))) return rc;
   const int nblk = cov_factors_grid(W, F > 0 ? F : 1);
   if ((rc = ensure(ctx, &ctx->d_dpart, &ctx->cap_dpart, (size_t)nblk * DACC_MAX * W))) return rc;
+  // BALM_SYRK=int8: X X^T and Y Y^T -- 79 % of the stage -- on the INT8 matrix cores as well (the scratch is the Hessian evaluation's: same n, same K)
+  const bool int8 = F > 0 && syrk_int8_for(3L * F);
+  if (int8) {
+    if ((rc = ensure(ctx, &ctx->d_i8, &ctx->cap_i8, syrk_i8_scratch_bytes(ctx->n, 3L * F, nullptr)))) return rc;
+    HIP_TRY(prepare_device_syrk_i8());
+  }
   // scratch: [redX | redY | S (21 W)] (one all-reduce payload) | Rraw | Rcov | T0, T1 (nA x nA each)
   const size_t pay = 2 * tiles + (size_t)21 * W, nn = (size_t)n * n;
   const size_t ncc = (cluster_cov && F > 0) ? (size_t)F * W * 81 : 0;
@@ -1248,10 +1254,17 @@ static int one_pose_covariance(balm_ctx *ctx, const double *poses, const double 
     launch_cov_factors(s, ctx->d_cl, d_cc, point_sigma * point_sigma, ctx->d_poses, ctx->d_feat, W, ctx->npad, F, Gx, Gy,
                        ctx->d_dpart, nblk);
     e = hipGetLastError();             // dynamic LDS above the 64 KiB default
-    launch_syrk(s, Gx, ctx->npad, ctx->ntiles, ctx->d_jobs, plan, ctx->d_part);
-    launch_cov_reduce_tiles(s, ctx->d_part, plan.SG, (long)tiles, redx);
-    launch_syrk(s, Gy, ctx->npad, ctx->ntiles, ctx->d_jobs, plan, ctx->d_part);
-    launch_cov_reduce_tiles(s, ctx->d_part, plan.SG, (long)tiles, redy);
+    if (int8) {
+      if (launch_syrk_i8(s, Gx, ctx->npad, ctx->n, 3L * F, ctx->d_sub, ctx->ntiles, ctx->d_i8, ctx->d_part)) e = hipErrorInvalidValue;
+      launch_cov_reduce_tiles(s, ctx->d_part, 1, (long)tiles, redx);
+      if (launch_syrk_i8(s, Gy, ctx->npad, ctx->n, 3L * F, ctx->d_sub, ctx->ntiles, ctx->d_i8, ctx->d_part)) e = hipErrorInvalidValue;
+      launch_cov_reduce_tiles(s, ctx->d_part, 1, (long)tiles, redy);
+    } else {
+      launch_syrk(s, Gx, ctx->npad, ctx->ntiles, ctx->d_jobs, plan, ctx->d_part);
+      launch_cov_reduce_tiles(s, ctx->d_part, plan.SG, (long)tiles, redx);
+      launch_syrk(s, Gy, ctx->npad, ctx->ntiles, ctx->d_jobs, plan, ctx->d_part);
+      launch_cov_reduce_tiles(s, ctx->d_part, plan.SG, (long)tiles, redy);
+    }
     launch_cov_reduce_dacc(s, ctx->d_dpart, nblk, W, sdiag);
   }
   if (e == hipSuccess) rc = hook_allreduce(ctx, buf, (long)pay);

@@ -630,7 +630,7 @@ def main(argv=None):
             rot8, tr8 = _pose_diff(poses8, poses_nat)
             out["int8_syrk"] = {
                 "what": "the same %d timed LM iterations with BALM_SYRK=int8: Gt Gt^T as eleven exact int32 digit products on v_mfma_i32_16x16x64_i8 "
-                        "(4 signed 7-bit digits per entry, one exponent per row), everything else unchanged; opt-in, not the default" % args.steps,
+                        "(4 signed radix-254 digits per entry, one exponent per row), everything else unchanged; opt-in, not the default" % args.steps,
                 "value": args.steps / dt8, "unit": "iter/s", "ms_per_step": dt8 / args.steps * 1e3,
                 "speedup_vs_value": (args.steps / dt8) / iters_per_s,
                 "dtype": "i8 digits x i8 digits -> i32 (exact), recombined in f64",

@@ -130,3 +130,24 @@ def test_int8_lm_run_reproduces_the_reference_run(case, which, monkeypatch):
     c.close()
     rot, tr = check_run(g, which, out, lg)
     print("%s %s under BALM_SYRK=int8: %d iterations, max pose difference to the reference %.2e rad %.2e m" % (case, which, len(lg), rot, tr))
+
+
+def test_int8_pose_covariance_against_the_fp64_stage():
+    """balm_pose_covariance (N4, benchmark consistency: Rcov = H^-1 (X X^T + Y Y^T + S) H^-T) with the Hessian's and the stage's two SYRKs on the
+    INT8 product against the FP64 stage: 1e-8 of the largest entry is what the stage's own tests ask of it against the reference"""
+    from balm_amd import capi
+    sc = scene.generate(51, 40, 5000, 6, mode=1)
+    fix = 0.3 * sc.clusters[:, 0]
+    fix[:, 9] = np.round(fix[:, 9])
+    out = {}
+    for mode in ("dense", "int8"):
+        os.environ["BALM_SYRK"] = mode
+        try:
+            c = capi.Context(sc.W)
+            c.set_features(sc.clusters, fix, np.ones(sc.F))
+            out[mode] = c.pose_covariance(sc.poses_init, point_sigma=0.02, want_raw=True)
+            c.close()
+        finally:
+            os.environ.pop("BALM_SYRK", None)
+    for a, b in zip(out["dense"], out["int8"]):
+        assert np.abs(a - b).max() <= 1e-8 * np.abs(a).max() and not np.array_equal(a, b)

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""N4 measurement: balm_pose_covariance at the consistency experiment's size (W=100) and at the bench window."""
+"""N4 measurement: balm_pose_covariance at the consistency experiment's size (W=100) and at the bench window
+(BALM_SYRK=int8 in the environment: the stage's two SYRKs and the Hessian's on the INT8 matrix cores)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

@@ -3,7 +3,8 @@
 # bench line with the CPU, real-data -- Python AND C++ -- legs; rocprofv3 kernel table; the three PMC passes -> pmc_traffic.json; ubench_f64),
 # the loopback-2 bench line, then the kernel tables of the paths beside the headline: the shipped window end to end under rocprofv3, the
 # covariance at W = 200 / F = 50 000 with FETCH / WRITE counters, the window map, the uploads (one context and eight shards), the C++ leg
-# three times cold and warm, the cold call's breakdown.  Every rocprofv3 run sits under `timeout`.
+# three times cold and warm, the cold call's breakdown; last, tools/gpu_i8prof.sh: everything about BALM_SYRK=int8 (accuracy, kernel tables with and
+# without the switch, counters, the whole suite with the switch exported) and the covariance stage under it.  Every rocprofv3 run sits under `timeout`.
 REPO=$(pwd); TAG=${TAG:-r06z}; OUT=$REPO/gpurun_out/$TAG; mkdir -p $OUT; export TMPDIR=/tmp PYTHONPATH=$REPO
 timeout 1800 python -m pytest tests -q -m gpu > $OUT/pytest_gpu.txt 2>&1 < /dev/null; echo "pytest rc=$?" | tee -a $OUT/pytest_gpu.txt; tail -3 $OUT/pytest_gpu.txt
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.txt 2>&1 < /dev/null; echo "smoke rc=$?"; tail -2 $OUT/smoke.txt
@@ -31,3 +32,5 @@ python tools/rocprof_kernels.py $OUT/trace_cov | sed -n '/# averages/,$p' > $OUT
 python tools/pmc_summary.py $OUT/pmc_cov > $OUT/cov_pmc_summary.csv 2>&1
 rm -rf $OUT/trace_rw $OUT/trace_cov $OUT/pmc_cov
 head -45 $OUT/realworld_kernels.txt; head -14 $OUT/cov_kernels_w200_f50000.txt; head -6 $OUT/cov_pmc_summary.csv | cut -c1-200
+TAG=$TAG timeout 1800 bash tools/gpu_i8prof.sh < /dev/null
+BALM_SYRK=int8 timeout 300 python tools/bench_cov.py 2>&1 | grep -v amdgpu.ids | tee $OUT/int8/cov_under_int8.txt
