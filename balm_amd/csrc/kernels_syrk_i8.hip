@@ -1,21 +1,21 @@
 // K3 on the INT8 matrix cores, FP64-exact to the parity tests' tolerance (round 6; OPT-IN: BALM_SYRK=int8, default off --
-// the shipped default, the bench line's dtype and every tolerance stay FP64).
+// the shipped default, the bench line's dtype and every tolerance stay FP64; DESIGN.md 8a).
 //
 // H -= Gt Gt^T  (bavoxel.hpp:404-418 as the rank-3 SYRK of DESIGN.md 2) by error-free slicing: every row i of Gt gets ONE exponent e_i
-// (|Gt[i][k]| < 2^(e_i - 1) for all k) and every entry four signed 7-bit digits,
-//     Gt[i][k] = 2^e_i * sum_{a < 4} d_a[i][k] 128^-(a+1)  (+ a remainder below 2^(e_i - 29)),   |d_a| <= 64,
-// so that a digit-by-digit product  sum_k d_a[i][k] d_b[j][k]  is EXACT in int32 (64^2 * 4 pairs * 18 752 columns per k-slice < 2^31) on
+// (|Gt[i][k]| < 2^(e_i - 1) for all k) and every entry four signed digits of radix 254,
+//     Gt[i][k] = 2^e_i * sum_{a < 4} d_a[i][k] 254^-(a+1)  (+ a remainder below 2^(e_i - 32)),   |d_a| <= 127,
+// so that a digit-by-digit product  sum_k d_a[i][k] d_b[j][k]  is EXACT in int32 (127^2 * 4 pairs * 32 704 columns per k-slice < 2^31) on
 // v_mfma_i32_16x16x64_i8.  Which products a 1e-10 Hessian needs was settled on the CPU (tools/study_int8_syrk.py, profiles/
 // r06_int8_syrk_study.txt): the pairs a + b <= 3 AND (2, 2) -- a dropped diagonal pair is a sum of squares and adds up coherently over
-// the 150 000 columns, the textbook truncation "a + b <= s - 1" fails by 3x -- eleven ordered pairs, error 5e-12 of the full-size test's
-// scale.  Pairs with equal a + b share an accumulator (same weight 128^-(a+b+2)): five int32 accumulator sets.
+// the 150 000 columns -- eleven ordered pairs; measured on the GPU: 1.4e-12 of the full-size test's scale.  Pairs with equal a + b share an
+// accumulator (same weight 254^-(a+b+2)): five int32 accumulator sets.
 //
-//   k_i8_rowmax   per row the largest |entry| (atomic max over k-chunks)                                    reads Gt once
+//   (row maxima)  left by the factor kernels where a lane owns a pose (kernels_accum.hip MAXR), else k_i8_rowmax: a pass over Gt
 //   k_i8_slice    digits, transposed from Gt's [k][row] to [digit][16 rows][64 columns] pieces of 1 KB laid out as the MFMA operand of a wavefront
-//   k_syrk_i8     one workgroup = one 128 x 128 output tile (I <= J) on one XCD's eighth of the columns; four wavefronts, 64 x 64 each,
+//   k_syrk_i8     one workgroup = one 128 x 128 output tile (I <= J) on one XCD's share of the columns; eight wavefronts, 32 x 64 each,
 //                 all eleven digit pairs on one pass over the operands: per 64-column step 64 KB go from memory straight into LDS
-//                 (global_load_lds, 1 KB pieces laid out as the operand fragments), 32 fragment reads and 176 MFMAs per wavefront
-//   k_i8_pack     sum over the eight k-slices and the five sets with their weights and the rows' scales -> FP64, written as ONE split-K
+//                 (global_load_lds, the 1 KB pieces as they lie), 24 fragment reads and 88 MFMAs per wavefront
+//   k_i8_pack     sum over the k-slices and the five sets with their weights and the rows' scales -> FP64, written as ONE split-K
 //                 slice in k_hessian_syrk's tile layout: k_reduce_all / k_assemble behind it are the FP64 path's
 #include <hip/hip_runtime.h>
 
@@ -167,7 +167,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     for (int d = 0; d < I8_DIGITS; d++)
 #pragma unroll
       for (int i = 0; i < 2; i++) A[d][i] = *reinterpret_cast<const v4i *>(bufA + (size_t)(d * 8 + i) * 1024);
-    // by B digit: (a, b) with a + b <= 3, and (2, 2); the accumulator set is a + b except (2, 2)'s, which is 4
+    // by B digit: (a, b) with a + b <= 3, and (2, 2); the accumulator set is a + b except (2, 2)'s, which is 4.  (The next digit's B fragments read
+    // before this digit's MFMAs, held there by a sched_barrier, 248 registers: 1.16 against 1.19 ms on the same box -- not kept.)
 #pragma unroll
     for (int b = 0; b < I8_DIGITS; b++) {
       v4i B[4];
@@ -255,7 +256,7 @@ hipError_t prepare_device_syrk_i8() {
 }
 
 // Gt [K][npad] (column k of the factor matrix = npad contiguous rows, as k_feature_factors writes it) -> part: one split-K slice of Gt Gt^T
-// in k_hessian_syrk's tile layout.  The int32 accumulators bound a k-slice: K / 8 * 4 * 64^2 < 2^31, i.e. K < 1.04 million columns.
+// in k_hessian_syrk's tile layout.  The int32 accumulators bound a k-slice at 32 704 columns: 8 x M slices (syrk_i8_scratch_bytes).
 // rowmax_known: the rows' largest |entries| where the factor kernel left them (k_feature_factors MAXR), else a pass over Gt finds them.
 int launch_syrk_i8(hipStream_t s, const double *Gt, int npad, int n, long K, const int *tileIJ, int ntiles, unsigned char *scratch, double *part,
                    const unsigned long long *rowmax_known) {
