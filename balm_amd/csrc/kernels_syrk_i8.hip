@@ -9,6 +9,8 @@
 // r06_int8_syrk_study.txt): the pairs a + b <= 3 AND (2, 2) -- a dropped diagonal pair is a sum of squares and adds up coherently over
 // the 150 000 columns -- eleven ordered pairs; measured on the GPU: 1.4e-12 of the full-size test's scale.  Pairs with equal a + b share an
 // accumulator (same weight 254^-(a+b+2)): five int32 accumulator sets.
+// (Tried: the (2, 2) pair only on the diagonal -- per-row sums of squares of the third digits from the slicing kernel, ten MFMA pairs and four
+// sets: k_syrk_i8 -7 %, but rows of neighbouring poses are nearly equal and their third digits correlate: off-diagonal error 1.4e-12 -> 6.9e-12.)
 //
 //   (row maxima)  left by the factor kernels where a lane owns a pose (kernels_accum.hip MAXR), else k_i8_rowmax: a pass over Gt
 //   k_i8_slice    digits, transposed from Gt's [k][row] to [digit][16 rows][64 columns] pieces of 1 KB laid out as the MFMA operand of a wavefront

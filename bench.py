@@ -612,6 +612,8 @@ def main(argv=None):
         # BALM_SYRK=int8 (opt-in): the same workload, the same timed loop, K3 on the INT8 matrix cores by error-free slicing.  An
         # EXTRA key: `value`, `dtype` and `roofline` above are the default FP64 path's.
         try:
+            ctx.close()          # (contexts of one process share the device's CUs among their persistent solve kernels: a second live context
+                                 #  shrinks the solve's helper grids -- 0.36 instead of 0.25 ms per step, measured -- so the leg runs alone)
             os.environ["BALM_SYRK"] = "int8"
             c8 = capi.Context(W, local_rank, capi.FLAG_TIMING)
             c8.set_features(sc.clusters, None, sc.coeffs)
@@ -645,6 +647,8 @@ def main(argv=None):
             out["int8_syrk"] = {"error": repr(e)}
         finally:
             os.environ.pop("BALM_SYRK", None)
+            ctx = capi.Context(W, local_rank, capi.FLAG_TIMING)
+            ctx.set_features(sc.clusters, None, sc.coeffs)
     if n_gpus == 1 and not multi and not args.no_cpu and not args.no_realworld:
         # the path the reference ships data for (benchmark_realworld.cpp:183-218), end to end from host memory; an extra key,
         # outside the timed region of `value`
