@@ -170,7 +170,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
       for (int i = 0; i < 2; i++) A[d][i] = *reinterpret_cast<const v4i *>(bufA + (size_t)(d * 8 + i) * 1024);
     // by B digit: (a, b) with a + b <= 3, and (2, 2); the accumulator set is a + b except (2, 2)'s, which is 4.  (The next digit's B fragments read
-    // before this digit's MFMAs, held there by a sched_barrier, 248 registers: 1.16 against 1.19 ms on the same box -- not kept.)
+    // before this digit's MFMAs, held there by a sched_barrier, 248 registers: 1.16 against 1.19 ms on the same box -- not kept.  The whole step
+    // pinned by sched_group_barriers -- A's first digit and B's first, then every read one MFMA group ahead of its use: 1.16-1.17, no change: the
+    // SIMD's other wavefront already covers these waits.)
 #pragma unroll
     for (int b = 0; b < I8_DIGITS; b++) {
       v4i B[4];
