@@ -16,6 +16,7 @@ OK, ERR_ARG, ERR_HIP, ERR_STATE, ERR_TOO_FEW_PLANES, ERR_NUMERIC = range(6)
 ABI_VERSION = 6            # include/balm_hip.h: BALM_ABI_VERSION
 FLAG_TIMING = 1
 FLAG_LOOPBACK_SHARDS = 2
+FLAG_SYRK_INT8 = 4        # opt-in: dense Gt Gt^T products on the INT8 matrix cores; default FP64
 T_MOMENTS, T_FACTORS, T_SYRK, T_ASSEMBLE, T_SOLVE, T_UPDATE, T_BUILD, T_VOXEL, T_COV, T_COMM, T_UPLOAD, T_COUNT = range(12)
 TIMING_NAMES = ["moments", "factors", "syrk", "assemble", "solve", "update", "build", "voxel", "cov", "comm", "upload"]
 

@@ -279,13 +279,17 @@ bool fuse_trial(const balm_ctx *ctx) {
   return ctx->W <= 256 && ctx->F > 0 && e && e[0] == '1';
 }
 
-// BALM_SYRK=int8: the dense SYRK on the INT8 matrix cores (kernels_syrk_i8.hip; opt-in, the default stays FP64 MFMA)
-static bool syrk_int8_mode() { const char *m = getenv("BALM_SYRK"); return m && !strcmp(m, "int8"); }
+// BALM_FLAG_SYRK_INT8 / BALM_SYRK=int8: the dense SYRK on the INT8 matrix cores (kernels_syrk_i8.hip; opt-in, the default stays FP64 MFMA)
+static bool syrk_int8_mode(const balm_ctx *ctx) {
+  if (ctx->flags & BALM_FLAG_SYRK_INT8) return true;
+  const char *m = getenv("BALM_SYRK");
+  return m && !strcmp(m, "int8");
+}
 // ... where it pays: from 12 288 columns (4 096 features) on -- below, the FP64 product is as fast (0.07 ms either way at 9 000 columns, measured)
 // and a short sum does not average the digits' truncation (1e-10 of the largest entry at 180 columns, 1e-12 at 150 000).
 // BALM_SYRK_INT8_MIN_COLS moves the threshold (tests: 0).
-static bool syrk_int8_for(long K) {
-  if (!syrk_int8_mode()) return false;
+static bool syrk_int8_for(const balm_ctx *ctx, long K) {
+  if (!syrk_int8_mode(ctx)) return false;
   const char *m = getenv("BALM_SYRK_INT8_MIN_COLS");
   return K >= (m ? atol(m) : 12288L);
 }
@@ -307,7 +311,7 @@ int prepare_evaluate(balm_ctx *ctx, int form, int nf) {
     if (ctx->d_Gt != before) ctx->gt_dirty_cols = ~(size_t)0;        // fresh memory: nothing is known to be zero
   }
   if ((rc = ensure(ctx, &ctx->d_part, &ctx->cap_part, parts * TILE_ELEMS))) return rc;
-  if (syrk_int8_for(3L * nf) && !(ctx->sparse && nf == ctx->F)) {
+  if (syrk_int8_for(ctx, 3L * nf) && !(ctx->sparse && nf == ctx->F)) {
     if ((rc = ensure(ctx, &ctx->d_i8, &ctx->cap_i8, syrk_i8_scratch_bytes(ctx->n, 3L * nf, nullptr)))) return rc;
     // the rows' largest |entries|, left by the factor kernels beside Gt / Gt2 (where their pose-per-lane variants run)
     if (!ctx->d_rowmax) ctx->rowmax_cur_valid = false;
@@ -366,7 +370,7 @@ int evaluate_device(balm_ctx *ctx, int form, const double *d_poses, int f0, int 
     }
     ctx->gt_dirty_cols = k0;
     ctx->rowmax_cur_valid = launch_factors(s, form, ctx->d_cl, d_poses, ctx->d_feat, W, ctx->npad, f0, f1, ctx->d_Gt, ctx->d_dpart, nblk,
-                                           sparse ? ctx->d_slot : nullptr, (!sparse && syrk_int8_for(3L * nf)) ? ctx->d_rowmax : nullptr, ctx->d_rowmax_part);
+                                           sparse ? ctx->d_slot : nullptr, (!sparse && syrk_int8_for(ctx, 3L * nf)) ? ctx->d_rowmax : nullptr, ctx->d_rowmax_part);
     ctx->gt_cur_valid = false;                // (set by the LM loop only, when an accepted trial's factors become current)
   }
   // the moments / factor kernels ask for up to 150 KB of dynamic LDS (above the 64 KiB default: granted per device by
@@ -374,7 +378,7 @@ int evaluate_device(balm_ctx *ctx, int form, const double *d_poses, int f0, int 
   HIP_TRY(hipGetLastError());
   // BALM_SYRK=int8 (opt-in, round 6): the dense product on the INT8 matrix cores by error-free slicing (kernels_syrk_i8.hip); it leaves ONE
   // split-K slice in d_part
-  const bool int8 = !sparse && syrk_int8_for(3L * nf);      // (its scratch: prepare_evaluate)
+  const bool int8 = !sparse && syrk_int8_for(ctx, 3L * nf);      // (its scratch: prepare_evaluate)
   {
     Span sp(ctx, BALM_T_SYRK);
     if (sparse) launch_syrk_sparse(s, ctx->d_Gt, ctx->npad, ctx->d_jobs, ctx->d_items, ctx->d_chunk_ids, ctx->sp_nsteps, ctx->sp_nitems, ctx->d_part);
@@ -417,8 +421,8 @@ int trial_device(balm_ctx *ctx, int form, const double *d_poses, int slot) {
                                (size_t)(ctx->npad - ctx->n) * sizeof(double), k0, s));
     ctx->nr_tmp = launch_moments_factors(s, form, ctx->d_cl, d_poses, ctx->has_fix ? ctx->d_fix : nullptr, ctx->d_coe, W, ctx->npad, F,
                                          ctx->d_Gt2, ctx->d_dpart2, nblk, sparse ? ctx->d_slot : nullptr, ctx->d_feat_tmp, ctx->d_rpart_tmp,
-                                         (!sparse && syrk_int8_for(3L * F) && ctx->d_rowmax2) ? ctx->d_rowmax2 : nullptr, ctx->d_rowmax_part);
-    ctx->rowmax_trial_valid = !sparse && syrk_int8_for(3L * F) && ctx->d_rowmax2;
+                                         (!sparse && syrk_int8_for(ctx, 3L * F) && ctx->d_rowmax2) ? ctx->d_rowmax2 : nullptr, ctx->d_rowmax_part);
+    ctx->rowmax_trial_valid = !sparse && syrk_int8_for(ctx, 3L * F) && ctx->d_rowmax2;
   }
   HIP_TRY(hipGetLastError());
   {
@@ -625,7 +629,7 @@ static int build_sparse_plan(balm_ctx *ctx, int F, const unsigned char *obs) {
   ctx->sparse = false;
   const char *mode = getenv("BALM_SYRK");
   if (mode && !strcmp(mode, "dense")) return BALM_OK;
-  if (syrk_int8_for(3L * F)) return BALM_OK;      // (the INT8 product is a dense plan; below its threshold the 80 %-rule decides as ever)
+  if (syrk_int8_for(ctx, 3L * F)) return BALM_OK;      // (the INT8 product is a dense plan; below its threshold the 80 %-rule decides as ever)
   const int W = ctx->W, T = ctx->T, ntiles = ctx->ntiles;
   if (T > 128 || T <= 2 || F < 64) return BALM_OK;      // (two row blocks: three tile jobs, nothing a plan could skip -- and a 20-pose
                                                          //  sliding window installs a table per slide: the plan's host time is not free)
@@ -1226,7 +1230,7 @@ static int one_pose_covariance(balm_ctx *ctx, const double *poses, const double 
   const int nblk = cov_factors_grid(W, F > 0 ? F : 1);
   if ((rc = ensure(ctx, &ctx->d_dpart, &ctx->cap_dpart, (size_t)nblk * DACC_MAX * W))) return rc;
   // BALM_SYRK=int8: X X^T and Y Y^T -- 79 % of the stage -- on the INT8 matrix cores as well (the scratch is the Hessian evaluation's: same n, same K)
-  const bool int8 = F > 0 && syrk_int8_for(3L * F);
+  const bool int8 = F > 0 && syrk_int8_for(ctx, 3L * F);
   if (int8) {
     if ((rc = ensure(ctx, &ctx->d_i8, &ctx->cap_i8, syrk_i8_scratch_bytes(ctx->n, 3L * F, nullptr)))) return rc;
     HIP_TRY(prepare_device_syrk_i8());

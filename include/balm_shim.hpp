@@ -33,6 +33,7 @@ class BALM2_HIP {
   int n_devices = 0;           // >= 1: balm_create_multi over devices device..device+n_devices-1 (features sharded, one RCCL
                                // all-reduce per evaluation inside the library; replaces the thread sum at bavoxel.hpp:1049-1056)
   bool timing = false;         // BALM_FLAG_TIMING: HIP-event spans per kernel class (balm_get_timing on context())
+  bool int8_syrk = false;      // BALM_FLAG_SYRK_INT8 (opt-in): the dense Hessian products on the INT8 matrix cores, FP64-exact to ~1e-12
   bool verbose = true;         // the reference always prints its per-iteration line (:1132)
   bool reanchor = true;        // bavoxel.hpp:1159-1164 (the consistency driver does not: BAs_left.hpp:1087)
   double abs_tol = 0;          // > 0: the consistency driver's stop rule |r1-r2| < 1e-9 (BAs_left.hpp:1083)
@@ -226,7 +227,7 @@ class BALM2_HIP {
   void ensure_ctx() {
     if (ctx_ && ctx_win_ == win_size) return;
     if (ctx_) balm_destroy(ctx_);
-    const int flags = timing ? BALM_FLAG_TIMING : 0;
+    const int flags = (timing ? BALM_FLAG_TIMING : 0) | (int8_syrk ? BALM_FLAG_SYRK_INT8 : 0);
     ctx_ = n_devices >= 1 ? balm_create_multi(win_size, device, n_devices, flags) : balm_create(win_size, device, flags);
     ctx_win_ = win_size;
     loaded_ = nullptr;

@@ -35,6 +35,7 @@ class BALM2_HIP {
   double rel_tol = 1e-6;
   int form = BALM_FORM_LEFT;   // :413 (left) vs :412 (right, commented out there)
   int device = 0;              // first device
+  bool int8_syrk = false;      // BALM_FLAG_SYRK_INT8 (opt-in): the dense Hessian products on the INT8 matrix cores, FP64-exact to ~1e-12
   int n_devices = 0;           // >= 1: balm_create_multi over devices device..device+n_devices-1 (features sharded, RCCL
                                // reduce inside the library); 0 = one device without a collective path
   bool verbose = true;         // the reference always prints its per-iteration line (:428)
@@ -54,7 +55,8 @@ class BALM2_HIP {
     const int W = winSize, F = (int)plSurfs.size();
     if (!ctx_ || ctx_win_ != W) {
       if (ctx_) balm_destroy(ctx_);
-      ctx_ = n_devices >= 1 ? balm_create_multi(W, device, n_devices, 0) : balm_create(W, device, 0);
+      const int flags = int8_syrk ? BALM_FLAG_SYRK_INT8 : 0;
+      ctx_ = n_devices >= 1 ? balm_create_multi(W, device, n_devices, flags) : balm_create(W, device, flags);
       ctx_win_ = W;
       if (!ctx_) {
         fprintf(stderr, "balm_hip: balm_create(win_size=%d, device=%d, n_devices=%d) failed: no MI355X / libbalm_hip.so?\n",

@@ -151,3 +151,18 @@ def test_int8_pose_covariance_against_the_fp64_stage():
             os.environ.pop("BALM_SYRK", None)
     for a, b in zip(out["dense"], out["int8"]):
         assert np.abs(a - b).max() <= 1e-8 * np.abs(a).max() and not np.array_equal(a, b)
+
+
+def test_int8_through_the_create_flag_is_the_environment_switch():
+    """BALM_FLAG_SYRK_INT8 at balm_create (the production form of the opt-in; include/balm_hip.h) selects the same product as BALM_SYRK=int8:
+    bit for bit the same Hessian, and not the FP64 one"""
+    from balm_amd import capi
+    sc = scene.generate(61, 30, 5000, 6, mode=1)
+    He = evaluate(sc, "int8")[0]
+    Hd = evaluate(sc, None)[0]
+    c = capi.Context(sc.W, 0, capi.FLAG_SYRK_INT8)
+    c.set_features(sc.clusters, None, sc.coeffs)
+    Hf = c.evaluate(0, sc.poses_init)[0]
+    c.close()
+    assert np.array_equal(Hf, He) and not np.array_equal(Hf, Hd)
+    assert np.abs(Hf - Hd).max() <= 1e-10 * np.abs(np.diag(Hd)).max()
