@@ -33,6 +33,7 @@ import numpy as np  # noqa: E402
 
 FP64_PEAK_TFLOPS = 78.6     # MI355X FP64 matrix = vector peak (MI355X_MICROARCH.md: 157.3 TF fp32 / 2)
 HBM_PEAK_TBS = 8.0          # MI355X_MICROARCH.md: HBM3E ~8 TB/s
+INT8_CEILING_TOPS = 3944.0  # MI355X_MICROARCH.md, matrix cores table: I8 >= 3944 TOPS dense (v_mfma_i32_16x16x64_i8 microbenchmark ceiling)
 COPY_RATE_TBS = 6.29        # what the best plain copy kernel moves on the box (read + write; float4, one element per thread): tools/ubench_f64.hip,
                             # profiles/r04k_small_build_and_write_rate.txt (6.21 in r04c; the guide: 6.29).  Round 3 quoted 4.99 = its double4 grid-stride
                             # copy.  Read-only 6.25, write-only 6.95 TB/s with one element per thread (4.0-4.2 in the grid-stride form).
@@ -637,6 +638,11 @@ def main(argv=None):
                 "speedup_vs_value": (args.steps / dt8) / iters_per_s,
                 "dtype": "i8 digits x i8 digits -> i32 (exact), recombined in f64",
                 "syrk_avg_launch_ms": t8["syrk"][0] / max(1, t8["syrk"][1]), "fp64_syrk_avg_launch_ms": syrk_s * 1e3 if syrk_s else None,
+                # eleven digit products over the upper triangle: 11 x 2 x n(n+1)/2 x 3F int8 operations, over the WHOLE span (slicing + product + packing:
+                # HIP events around the three kernels; k_syrk_i8 alone: profiles/r06z_int8_kernels_int8.txt) against the guide's INT8 MFMA ceiling
+                "roofline": (lambda ops, sec: {"kernel": "k_i8_slice + k_syrk_i8 + k_i8_pack", "bound": "mfma", "dtype": "i8", "achieved": ops / sec / 1e12,
+                                              "peak": INT8_CEILING_TOPS, "unit": "TOP/s", "frac": ops / sec / 1e12 / INT8_CEILING_TOPS,
+                                              "algorithmic_ops_per_launch": ops})(11.0 * n * (n + 1) * 3.0 * F_total, t8["syrk"][0] / max(1, t8["syrk"][1]) * 1e-3),
                 "kernel_ms_per_step": {k: v[0] / args.steps for k, v in t8.items()},
                 "max_abs_H_difference_over_max_abs_diag_H": float(np.abs(H8 - H_first).max() / np.abs(np.diag(H_first)).max()),
                 "natural_lm_run": {"iterations": int(len(lg8)), "iterations_fp64": int(len(lg_nat)), "final_residual": float(lg8[-1, 1]),
