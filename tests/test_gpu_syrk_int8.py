@@ -166,3 +166,20 @@ def test_int8_through_the_create_flag_is_the_environment_switch():
     c.close()
     assert np.array_equal(Hf, He) and not np.array_equal(Hf, Hd)
     assert np.abs(Hf - Hd).max() <= 1e-10 * np.abs(np.diag(Hd)).max()
+
+
+def test_int8_product_inside_replayed_lm_graphs(monkeypatch):
+    """BALM_GRAPH=1 captures the LM iteration -- with the switch: the slicing, the INT8 product and its packing among the captured launches -- and
+    replays it: the same poses and the same trace as plain launches, bit for bit"""
+    from balm_amd import capi
+    sc = scene.generate(3, 20, 600, 6, mode=1)
+    monkeypatch.setenv("BALM_SYRK", "int8")
+    monkeypatch.setenv("BALM_SYRK_INT8_MIN_COLS", "0")
+    out = []
+    for g in ("0", "1"):
+        monkeypatch.setenv("BALM_GRAPH", g)
+        c = capi.Context(sc.W)
+        c.set_features(sc.clusters, None, sc.coeffs)
+        out.append(c.damping_iter(sc.poses_init, form=0, u0=0.1, max_iter=12, force_hess=True, no_stop=True, reanchor=False))
+        c.close()
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1]) and len(out[1][1]) == 12
