@@ -183,3 +183,34 @@ def test_int8_product_inside_replayed_lm_graphs(monkeypatch):
         out.append(c.damping_iter(sc.poses_init, form=0, u0=0.1, max_iter=12, force_hess=True, no_stop=True, reanchor=False))
         c.close()
     assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1]) and len(out[1][1]) == 12
+
+
+@pytest.mark.parametrize("form", [0, 1])
+def test_int8_with_the_one_pass_trial_evaluation(form, monkeypatch):
+    """BALM_FUSE_TRIAL=1: the trial evaluation's k_moments_factors leaves the factors of the trial poses in the second Gt buffer -- under the
+    switch also their row maxima, which change hands with the buffer when the step is accepted.  The LM run must make the decisions of the
+    three-kernel path under the switch and land on its poses; then a plain evaluation must still be right (no stale maxima)"""
+    from balm_amd import capi
+    sc = scene.generate(71, 48, 1500, 6, mode=1)
+    scene.sparsify(sc, 171, 0.2)
+    monkeypatch.setenv("BALM_SYRK", "int8")
+    monkeypatch.setenv("BALM_SYRK_INT8_MIN_COLS", "0")
+    c = capi.Context(sc.W)
+    c.set_features(sc.clusters, None, sc.coeffs)
+    monkeypatch.delenv("BALM_FUSE_TRIAL", raising=False)
+    pa, la = c.damping_iter(sc.poses_init, form=form, u0=0.1, max_iter=8, min_planes=0)
+    monkeypatch.setenv("BALM_FUSE_TRIAL", "1")
+    pb, lb = c.damping_iter(sc.poses_init, form=form, u0=0.1, max_iter=8, min_planes=0)
+    monkeypatch.delenv("BALM_FUSE_TRIAL")
+    assert len(la) == len(lb) and np.array_equal(la[:, 6], lb[:, 6]) and la[:, 6].sum() >= 2
+    assert np.allclose(la[:, :2], lb[:, :2], rtol=1e-9, atol=0) and np.abs(pa - pb).max() < 1e-8
+    Hi = c.evaluate(form, sc.poses_init)[0]
+    c.close()
+    monkeypatch.setenv("BALM_SYRK", "dense")
+    d = capi.Context(sc.W)
+    d.set_features(sc.clusters, None, sc.coeffs)
+    Hd = d.evaluate(form, sc.poses_init)[0]
+    pd, ld = d.damping_iter(sc.poses_init, form=form, u0=0.1, max_iter=8, min_planes=0)
+    d.close()
+    assert np.abs(Hi - Hd).max() <= 5e-10 * np.abs(np.diag(Hd)).max()
+    assert len(ld) == len(la) and np.abs(pd - pa).max() < 1e-8
