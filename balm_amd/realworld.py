@@ -197,6 +197,7 @@ def end_to_end_cpp(npz_path=SHIPPED_WINDOW_NPZ, reps=5, exe=CPP_E2E_EXE, feature
                 "cold = first use in a fresh process, warm = median of %s further calls" % (kv["scans"], kv["point_bytes"], kv["reps"]),
         "optimizer_object_declared": kv["declared"] + (" in main: the device start-up runs behind the reading of the scans" if kv["declared"] == "first"
                                                          else " (after the scans are read, benchmark_realworld.cpp:217: no overlap)"),
+        "clouds_on_numa_nodes": kv.get("clouds_on_nodes"),      # how many of the clouds the scheduler placed on node 0/1/2/3 (profiles/r06_cpp_leg_numa.txt)
         "features": int(kv["features"]), "lm_iterations": int(kv["lm_iterations"]),
         "ms_total": float(kv["total"]), "ms_associate_call": float(kv["associate"]), "ms_lm_call": float(kv["lm"]),
         "ms_upload": float(kv["upload"]), "ms_associate_device": float(kv["assoc_device"]),

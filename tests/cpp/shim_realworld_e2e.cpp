@@ -11,6 +11,7 @@
 //                                           start-up (runtime, pinned ring, code objects) in the background while the scans are read.
 //                                           With a fourth argument "late" it is declared after the scans are in memory, right where the
 //                                           reference declares `BALM2 opt;` (benchmark_realworld.cpp:217): nothing overlaps.
+//   clouds_on_nodes                         how many of the scans' clouds live on NUMA node 0 / 1 / 2 / 3 (where the scheduler ran this reader)
 //   associate / lm / total                  median of `reps` further calls on the same object
 //   upload / assoc_device                   the library's own HIP-event spans of the median repetition (BALM_T_UPLOAD / BALM_T_VOXEL)
 // and, with a third argument, the installed feature table (F, then clusters F*W*10 doubles, coeffs F doubles) as a raw file for
@@ -21,11 +22,20 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <sys/syscall.h>
+#include <unistd.h>
 
 #include <ros/ros.h>
 #include "tools.hpp"
 #include "bavoxel.hpp"
 #include "balm_shim.hpp"
+
+// the NUMA node a page lives on (move_pages without target nodes only reports); -1: unknown
+static int node_of(const void *p) {
+  void *page = reinterpret_cast<void *>(reinterpret_cast<uintptr_t>(p) & ~(uintptr_t)4095);
+  int status = -1;
+  return (syscall(SYS_move_pages, 0, 1ul, &page, nullptr, &status, 0) == 0 && status >= 0) ? status : -1;
+}
 
 static double ms_since(std::chrono::steady_clock::time_point t0) {
   return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -135,9 +145,11 @@ int main(int argc, char **argv) {
   }
   size_t npts = 0;
   for (auto &p : pl_fulls) npts += p->size();
-  printf("SHIM_E2E declared=%s scans=%d points=%zu point_bytes=%zu features=%d lm_iterations=%zu reps=%d cold_create=%.3f cold_associate=%.3f cold_lm=%.3f "
+  int on_node[4] = {0, 0, 0, 0};
+  for (auto &p : pl_fulls) if (!p->empty()) { const int nd = node_of(&p->points[0]); if (nd >= 0 && nd < 4) on_node[nd]++; }
+  printf("SHIM_E2E declared=%s clouds_on_nodes=%d/%d/%d/%d scans=%d points=%zu point_bytes=%zu features=%d lm_iterations=%zu reps=%d cold_create=%.3f cold_associate=%.3f cold_lm=%.3f "
          "associate=%.3f lm=%.3f total=%.3f upload=%.3f assoc_device=%.3f max_rot=%.3e max_trans=%.3e\n",
-         late ? "late" : "first", W, npts, sizeof(PointType), F, iters, reps, cold_create, cold_associate, cold_lm, med(&Row::associate), med(&Row::lm),
+         late ? "late" : "first", on_node[0], on_node[1], on_node[2], on_node[3], W, npts, sizeof(PointType), F, iters, reps, cold_create, cold_associate, cold_lm, med(&Row::associate), med(&Row::lm),
          med(&Row::associate) + med(&Row::lm), med(&Row::upload), med(&Row::assoc_device), max_rot, max_tr);
   return (has_ref && !(max_rot <= 1e-5 && max_tr <= 1e-4)) ? 1 : 0;
 }
