@@ -104,6 +104,9 @@ inline GpuNode numa_node_cpus(int node) {
   return g;
 }
 
+#ifndef BALM_POOL_SPREAD
+#define BALM_POOL_SPREAD 1          // (tools/ubench_gather.hip: 0 = every pool thread floats over the whole node)
+#endif
 class HostPool {
  public:
   // Pool 0 is the process's pool.  The device threads of a one-process multi-GPU context (balm_create_multi) each get a pool of
@@ -169,7 +172,12 @@ class HostPool {
         seen = gen_; f = fn_; aff = aff_;
       }
       if (aff && (!have_aff || !CPU_EQUAL(&aff->cpus, &cur_aff))) {
+#if BALM_POOL_SPREAD
+        const cpu_set_t mine = spread_cpus(aff->cpus, t);      // this thread's own group of the node's cores
+        if (pthread_setaffinity_np(pthread_self(), sizeof(cpu_set_t), &mine) == 0) { cur_aff = aff->cpus; have_aff = true; }
+#else
         if (pthread_setaffinity_np(pthread_self(), sizeof(cpu_set_t), &aff->cpus) == 0) { cur_aff = aff->cpus; have_aff = true; }
+#endif
       }
       (*f)(t);
       {
@@ -177,6 +185,54 @@ class HostPool {
         if (--pending_ == 0) cv_done_.notify_all();
       }
     }
+  }
+  // The CPUs of pool thread t: the cores of `set` cut into one contiguous group per thread (a core = the CPUs of a thread_siblings_list), so that
+  // two fillers never share a core's hardware threads, the sixteen are spread over the socket's dies, and the scheduler still has a few cores to
+  // choose from when another tenant's thread sits on one (ONE core per thread: 6-10 ms uploads whenever that happens, measured).  Floating over the
+  // whole node instead, a process keeps the placement its threads started with -- uploads of 3.2, 3.6, 4.4, 4.7 ms from one process to the next;
+  // grouped: 3.1-3.3 (tools/ubench_gather.hip, profiles/r06_cpp_leg_numa.txt).  Read from sysfs once per CPU set.
+  std::vector<std::pair<cpu_set_t, std::vector<cpu_set_t>>> groups_;
+  std::mutex groups_mu_;
+  cpu_set_t spread_cpus(const cpu_set_t &set, int t) {
+    const int n = (int)th_.size();
+    std::lock_guard<std::mutex> lk(groups_mu_);
+    for (auto &g : groups_) if (CPU_EQUAL(&g.first, &set)) return g.second[(size_t)t];
+    std::vector<cpu_set_t> cores;                  // one entry per core: its hardware threads inside `set`
+    for (int c = 0; c < CPU_SETSIZE; c++) {
+      if (!CPU_ISSET(c, &set)) continue;
+      char path[128], line[128] = {0};
+      snprintf(path, sizeof(path), "/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list", c);
+      cpu_set_t sib;
+      CPU_ZERO(&sib);
+      CPU_SET(c, &sib);
+      int lead = c;
+      if (FILE *f = fopen(path, "r")) {
+        if (fgets(line, sizeof(line), f)) {
+          lead = -1;
+          for (char *p = line; *p && *p != '\n';) {          // "64,192" or "64-65"
+            char *e = nullptr;
+            const long x = strtol(p, &e, 10);
+            if (e == p) break;
+            long y = x;
+            p = e;
+            if (*p == '-') { y = strtol(p + 1, &e, 10); p = e; }
+            for (long q = x; q <= y && q < CPU_SETSIZE; q++) { if (lead < 0) lead = (int)q; if (CPU_ISSET((int)q, &set)) CPU_SET((int)q, &sib); }
+            if (*p == ',') p++;
+          }
+        }
+        fclose(f);
+      }
+      if (lead == c || lead < 0) cores.push_back(sib);
+    }
+    std::vector<cpu_set_t> per((size_t)std::max(n, 1), set);
+    const long nc = (long)cores.size();
+    if (nc >= n && n > 0)
+      for (int q = 0; q < n; q++) {
+        CPU_ZERO(&per[(size_t)q]);
+        for (long k = (long)q * nc / n; k < (long)(q + 1) * nc / n; k++) CPU_OR(&per[(size_t)q], &per[(size_t)q], &cores[(size_t)k]);
+      }
+    groups_.emplace_back(set, per);
+    return groups_.back().second[(size_t)t];
   }
   std::vector<std::thread> th_;
   std::mutex mu_, job_mu_;
