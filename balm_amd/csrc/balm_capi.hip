@@ -285,13 +285,14 @@ static bool syrk_int8_mode(const balm_ctx *ctx) {
   const char *m = getenv("BALM_SYRK");
   return m && !strcmp(m, "int8");
 }
-// ... where it pays: from 12 288 columns (4 096 features) on -- below, the FP64 product is as fast (0.07 ms either way at 9 000 columns, measured)
-// and a short sum does not average the digits' truncation (1e-10 of the largest entry at 180 columns, 1e-12 at 150 000).
-// BALM_SYRK_INT8_MIN_COLS moves the threshold (tests: 0).
+// ... where it pays: from 12 288 columns (4 096 features) and 96 poses on -- below, the FP64 product is as fast or faster (0.07 ms either way at
+// 9 000 columns; a 64-pose window is 6 tiles x 8 k-slices = 48 workgroups for 256 CUs: 0.085 against 0.053 ms at 15 000 columns, measured) and a
+// short sum does not average the digits' truncation (1e-10 of the largest entry at 180 columns, 1e-12 at 150 000).
+// BALM_SYRK_INT8_MIN_COLS replaces both thresholds by its column count (tests: 0).
 static bool syrk_int8_for(const balm_ctx *ctx, long K) {
   if (!syrk_int8_mode(ctx)) return false;
-  const char *m = getenv("BALM_SYRK_INT8_MIN_COLS");
-  return K >= (m ? atol(m) : 12288L);
+  if (const char *m = getenv("BALM_SYRK_INT8_MIN_COLS")) return K >= atol(m);
+  return K >= 12288L && ctx->W >= 96;
 }
 
 // scratch of one Hessian evaluation over nf features (grown, never shrunk): every allocation an evaluation can need

@@ -44,7 +44,7 @@ enum {
   BALM_FLAG_TIMING = 1,          /* record HIP events around every kernel class (balm_get_timing) */
   BALM_FLAG_LOOPBACK_SHARDS = 2, /* balm_create_multi: all n_devices shards on the ONE device `first_device`, summed by
                                     an in-library kernel instead of RCCL -- exercises the sharded path on a one-GPU box */
-  BALM_FLAG_SYRK_INT8 = 4        /* OPT-IN: the Hessian's (and the covariance's) dense Gt Gt^T products of 12 288 columns or more on
+  BALM_FLAG_SYRK_INT8 = 4        /* OPT-IN: the Hessian's (and the covariance's) dense Gt Gt^T products of 12 288 columns or more (windows of 96 poses or more) on
                                     the INT8 matrix cores by error-free digit slicing instead of FP64 MFMA: twice as
                                     fast; g and the residual bit-identical, H within ~1e-12 of the largest entry of the FP64 path's at
                                     the benchmark size (an entry's error is ~2^-32 of the product of its rows' largest |entries| per
