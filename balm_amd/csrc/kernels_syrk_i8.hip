@@ -245,6 +245,21 @@ size_t syrk_i8_scratch_bytes(int n, long K, I8Layout *lay) {
   // k-slices: eight (one per XCD) times M, M the smallest count that keeps a slice's int32 sums exact: 4 pairs x 128^2 x columns < 2^31
   L.M = 1;
   while ((K + (long)I8_XCDS * L.M * I8_KS - 1) / ((long)I8_XCDS * L.M * I8_KS) * I8_KS > 32704) L.M++;
+  // ... and, for windows of few tiles, the count that fills the chip's 256 CUs best: 8 M NT workgroups run in ceil(8 M NT / 256) rounds of 1 / M
+  // of the columns each (a 100-pose window: 15 tiles x 8 slices = 120 workgroups leave half of the CUs idle; M = 2: 240), against the extra
+  // int32 partial tiles written and read back (8 NT x 320 KB per unit of M).  Priced with the kernel's measured 1.4 us per 64-column step and
+  // 5 TB/s for the partials; a slice keeps sixteen steps.  (From 41 tiles on -- 177 poses -- M stays what the int32 sums ask for.)
+  if (L.NT <= 40) {
+    int best = L.M;
+    double best_cost = 1e30;
+    for (int m = L.M; m <= 8; m++) {
+      if (K / ((long)I8_XCDS * m) < 16 * I8_KS) break;
+      const double rounds = (double)((I8_XCDS * m * L.NT + 255) / 256), steps = (double)K / (I8_XCDS * m * I8_KS);
+      const double cost = rounds * steps * 1.4e-6 + (double)m * L.NT * I8_XCDS * I8_SETS * I8_TILE * I8_TILE * 4.0 * 2.0 / 5e12;
+      if (cost < best_cost * 0.97) { best_cost = cost; best = m; }      // (3 %: a tie keeps the smaller count)
+    }
+    L.M = best;
+  }
   L.Kp = (K + (long)I8_XCDS * L.M * I8_KS - 1) / ((long)I8_XCDS * L.M * I8_KS) * ((long)I8_XCDS * L.M * I8_KS);
   L.off_digits = 0;
   size_t off = (size_t)I8_DIGITS * L.rows_p * L.Kp;
