@@ -104,6 +104,46 @@ inline GpuNode numa_node_cpus(int node) {
   return g;
 }
 
+// The cores of `set` (a core = the CPUs of one thread_siblings_list, read from sysfs) cut into n contiguous groups: group q for pool thread q.
+// Fewer cores than threads: every group is the whole set.  (HostPool::spread_cpus says why; tests/cpp/host_stage_test.cpp checks the partition.)
+inline std::vector<cpu_set_t> core_groups(const cpu_set_t &set, int n) {
+  std::vector<cpu_set_t> cores;                  // one entry per core: its hardware threads inside `set`
+  for (int c = 0; c < CPU_SETSIZE; c++) {
+    if (!CPU_ISSET(c, &set)) continue;
+    char path[128], line[128] = {0};
+    snprintf(path, sizeof(path), "/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list", c);
+    cpu_set_t sib;
+    CPU_ZERO(&sib);
+    CPU_SET(c, &sib);
+    int lead = c;
+    if (FILE *f = fopen(path, "r")) {
+      if (fgets(line, sizeof(line), f)) {
+        lead = -1;
+        for (char *p = line; *p && *p != '\n';) {          // "64,192" or "64-65"
+          char *e = nullptr;
+          const long x = strtol(p, &e, 10);
+          if (e == p) break;
+          long y = x;
+          p = e;
+          if (*p == '-') { y = strtol(p + 1, &e, 10); p = e; }
+          for (long q = x; q <= y && q < CPU_SETSIZE; q++) if (CPU_ISSET((int)q, &set)) { if (lead < 0) lead = (int)q; CPU_SET((int)q, &sib); }      // (lead: the core's first CPU inside the set)
+          if (*p == ',') p++;
+        }
+      }
+      fclose(f);
+    }
+    if (lead == c || lead < 0) cores.push_back(sib);
+  }
+  std::vector<cpu_set_t> per((size_t)std::max(n, 1), set);
+  const long nc = (long)cores.size();
+  if (nc >= n && n > 0)
+    for (int q = 0; q < n; q++) {
+      CPU_ZERO(&per[(size_t)q]);
+      for (long k = (long)q * nc / n; k < (long)(q + 1) * nc / n; k++) CPU_OR(&per[(size_t)q], &per[(size_t)q], &cores[(size_t)k]);
+    }
+  return per;
+}
+
 #ifndef BALM_POOL_SPREAD
 #define BALM_POOL_SPREAD 1          // (tools/ubench_gather.hip: 0 = every pool thread floats over the whole node)
 #endif
@@ -197,40 +237,7 @@ class HostPool {
     const int n = (int)th_.size();
     std::lock_guard<std::mutex> lk(groups_mu_);
     for (auto &g : groups_) if (CPU_EQUAL(&g.first, &set)) return g.second[(size_t)t];
-    std::vector<cpu_set_t> cores;                  // one entry per core: its hardware threads inside `set`
-    for (int c = 0; c < CPU_SETSIZE; c++) {
-      if (!CPU_ISSET(c, &set)) continue;
-      char path[128], line[128] = {0};
-      snprintf(path, sizeof(path), "/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list", c);
-      cpu_set_t sib;
-      CPU_ZERO(&sib);
-      CPU_SET(c, &sib);
-      int lead = c;
-      if (FILE *f = fopen(path, "r")) {
-        if (fgets(line, sizeof(line), f)) {
-          lead = -1;
-          for (char *p = line; *p && *p != '\n';) {          // "64,192" or "64-65"
-            char *e = nullptr;
-            const long x = strtol(p, &e, 10);
-            if (e == p) break;
-            long y = x;
-            p = e;
-            if (*p == '-') { y = strtol(p + 1, &e, 10); p = e; }
-            for (long q = x; q <= y && q < CPU_SETSIZE; q++) { if (lead < 0) lead = (int)q; if (CPU_ISSET((int)q, &set)) CPU_SET((int)q, &sib); }
-            if (*p == ',') p++;
-          }
-        }
-        fclose(f);
-      }
-      if (lead == c || lead < 0) cores.push_back(sib);
-    }
-    std::vector<cpu_set_t> per((size_t)std::max(n, 1), set);
-    const long nc = (long)cores.size();
-    if (nc >= n && n > 0)
-      for (int q = 0; q < n; q++) {
-        CPU_ZERO(&per[(size_t)q]);
-        for (long k = (long)q * nc / n; k < (long)(q + 1) * nc / n; k++) CPU_OR(&per[(size_t)q], &per[(size_t)q], &cores[(size_t)k]);
-      }
+    std::vector<cpu_set_t> per = core_groups(set, n);
     groups_.emplace_back(set, per);
     return groups_.back().second[(size_t)t];
   }

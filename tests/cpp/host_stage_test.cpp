@@ -93,6 +93,27 @@ int main() {
   for (auto &h : hit) h.store(0);
   balm::parallel_ranges(hit.size(), 1000, [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi; i++) hit[i]++; });
   for (auto &h : hit) if (h.load() != 1) { printf("FAIL parallel_ranges\n"); rc = 1; break; }
+  // core_groups: the pool threads' CPU groups partition the set's cores -- pairwise disjoint, inside the set, none empty, together the whole set
+  {
+    cpu_set_t all;
+    sched_getaffinity(0, sizeof(all), &all);
+    for (int n : {1, 2, 3, 15}) {
+      const std::vector<cpu_set_t> g = balm::core_groups(all, n);
+      if ((int)g.size() != n) { printf("FAIL core_groups: %zu groups for %d threads\n", g.size(), n); rc = 1; continue; }
+      cpu_set_t uni;
+      CPU_ZERO(&uni);
+      bool whole = true, ok = true;                      // (fewer cores than threads: every group is the whole set)
+      for (auto &q : g) whole = whole && CPU_EQUAL(&q, &all);
+      for (int a = 0; a < n && !whole; a++) {
+        cpu_set_t in;
+        CPU_AND(&in, &g[(size_t)a], &all);
+        if (CPU_COUNT(&g[(size_t)a]) == 0 || !CPU_EQUAL(&in, &g[(size_t)a])) ok = false;
+        for (int b = a + 1; b < n; b++) { cpu_set_t x; CPU_AND(&x, &g[(size_t)a], &g[(size_t)b]); if (CPU_COUNT(&x)) ok = false; }
+        CPU_OR(&uni, &uni, &g[(size_t)a]);
+      }
+      if (!whole && (!ok || !CPU_EQUAL(&uni, &all))) { printf("FAIL core_groups(%d): not a partition of the process's CPUs\n", n); rc = 1; }
+    }
+  }
   if (!rc) printf("host_stage ok (%d pool threads)\n", balm::HostPool::get().workers());
   return rc;
 }
