@@ -174,7 +174,7 @@ struct balm_ctx {
   unsigned long long *d_rowmax = nullptr, *d_rowmax2 = nullptr; size_t cap_rowmax = 0, cap_rowmax2 = 0;      // ... the rows' maxima of Gt / Gt2
   double *d_rowmax_part = nullptr; size_t cap_rowmax_part = 0;      // ... per workgroup of the factor kernel, before their reduction
   bool rowmax_cur_valid = false, rowmax_trial_valid = false;
-  unsigned char *d_i8 = nullptr; size_t cap_i8 = 0;     // scratch of the INT8 SYRK (BALM_SYRK=int8): digits, row scales, int32 partial tiles
+  unsigned char *d_i8 = nullptr; size_t cap_i8 = 0;     // scratch of the INT8 SYRK (BALM_SYRK=int8): digits, row scales, partial tiles
   struct balm_multi *multi = nullptr;   // set on every device context of a balm_create_multi context
   double *d_pre = nullptr;          // [W + 2] pre-loop all-reduce: planes per pose, error flag
 };

@@ -17,7 +17,7 @@
 //   k_syrk_i8     one workgroup = one 128 x 128 output tile (I <= J) on one XCD's share of the columns; eight wavefronts, 32 x 64 each,
 //                 all eleven digit pairs on one pass over the operands: per 64-column step 64 KB go from memory straight into LDS
 //                 (global_load_lds, the 1 KB pieces as they lie), 24 fragment reads and 88 MFMAs per wavefront
-//   k_i8_pack     sum over the k-slices and the five sets with their weights and the rows' scales -> FP64, written as ONE split-K
+//   k_i8_pack     sum over the k-slices (each slice's five sets leave k_syrk_i8 weighted and added: one double) x the rows' scales -> ONE split-K
 //                 slice in k_hessian_syrk's tile layout: k_reduce_all / k_assemble behind it are the FP64 path's
 #include <hip/hip_runtime.h>
 
@@ -120,7 +120,7 @@ __device__ __forceinline__ void i8_glds16(const signed char *src, void *lds_wave
 // four wavefronts of 64 x 64 the 320 accumulator registers do not fit the 256 AGPRs and the compiler shuttles the rest through
 // v_accvgpr moves, 768 per step: 2.05 ms, measured), the second wavefront of a SIMD covers the other's LDS waits.
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_syrk_i8(const signed char *__restrict__ D, long Kp, int rows_p, int T,
-                                                                                           int NT, int M, int *__restrict__ P) {
+                                                                                           int NT, int M, double *__restrict__ P) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];      // two stages of [side 2][digit 4][row group 8][1 KB]: 128 KB
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, wr = wv >> 1, wc = wv & 1;      // rows wr * 32 .., columns wc * 64 .. of the tile
   const int xcd = blockIdx.x & 7;                 // (the hardware places workgroup b on XCD b mod 8: an XCD's workgroups share its eighth of the columns)
@@ -189,23 +189,25 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       }
     }
   }
-  // C/D layout of the 16 x 16 forms: col = lane & 15, row = (lane >> 4) * 4 + reg
-  int *out = P + ((size_t)ksl * NT + tix) * I8_SETS * (I8_TILE * I8_TILE);
+  // C/D layout of the 16 x 16 forms: col = lane & 15, row = (lane >> 4) * 4 + reg.  The five exact int32 sums of an element leave as ONE double,
+  // sum_s radix^-(s+2) sum_s, smallest weight first (2^-53 of the slice's value: FP64's own rounding) -- 8 bytes per element and slice instead
+  // of 20, 16 lanes x 8 bytes = a full cache line per store
+  double *out = P + ((size_t)ksl * NT + tix) * (I8_TILE * I8_TILE);
+  constexpr double W0 = 1.0 / (I8_RADIX * I8_RADIX), W1 = W0 / I8_RADIX, W2 = W1 / I8_RADIX, W3 = W2 / I8_RADIX, W4 = W3 / I8_RADIX;
 #pragma unroll
-  for (int s = 0; s < I8_SETS; s++)
+  for (int i = 0; i < 2; i++)
 #pragma unroll
-    for (int i = 0; i < 2; i++)
+    for (int j = 0; j < 4; j++)
 #pragma unroll
-      for (int j = 0; j < 4; j++)
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-          const int ri = wr * 32 + i * 16 + (lane >> 4) * 4 + r, cj = wc * 64 + j * 16 + (lane & 15);
-          out[(size_t)s * (I8_TILE * I8_TILE) + ri * I8_TILE + cj] = acc[s][i][j][r];
-        }
+      for (int r = 0; r < 4; r++) {
+        const int ri = wr * 32 + i * 16 + (lane >> 4) * 4 + r, cj = wc * 64 + j * 16 + (lane & 15);
+        out[ri * I8_TILE + cj] = (((W4 * (double)acc[4][i][j][r] + W3 * (double)acc[3][i][j][r]) + W2 * (double)acc[2][i][j][r]) + W1 * (double)acc[1][i][j][r]) +
+                                 W0 * (double)acc[0][i][j][r];
+      }
 }
 
-// sum over k-slices and sets -> FP64 in k_hessian_syrk's tile layout (one split-K slice): part[tile * 6400 + (mt * 4 + reg) * 64 + lane]
-__global__ __launch_bounds__(256) void k_i8_pack(const int *__restrict__ P, int NT, int T, const double *__restrict__ rowscale, const int *__restrict__ tileIJ,
+// sum over k-slices -> FP64 in k_hessian_syrk's tile layout (one split-K slice): part[tile * 6400 + (mt * 4 + reg) * 64 + lane]
+__global__ __launch_bounds__(256) void k_i8_pack(const double *__restrict__ P, int NT, int T, const double *__restrict__ rowscale, const int *__restrict__ tileIJ,
                                                  int ntiles, int n, int nslices, double *__restrict__ part) {
   const long total = (long)ntiles * TILE_ELEMS;
   for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
@@ -221,13 +223,7 @@ __global__ __launch_bounds__(256) void k_i8_pack(const int *__restrict__ P, int 
       const int I = row / I8_TILE, J = col / I8_TILE;
       const int tix = I * T - I * (I - 1) / 2 + (J - I);
       const int ri = row - I * I8_TILE, cj = col - J * I8_TILE;
-      double w = 1.0 / (I8_RADIX * I8_RADIX);                    // radix^-(a+b+2) for a + b = 0
-      for (int s = 0; s < I8_SETS; s++) {
-        long long sum = 0;
-        for (int x = 0; x < nslices; x++) sum += P[(((size_t)x * NT + tix) * I8_SETS + s) * (I8_TILE * I8_TILE) + ri * I8_TILE + cj];
-        val += w * (double)sum;
-        w *= 1.0 / I8_RADIX;
-      }
+      for (int x = 0; x < nslices; x++) val += P[((size_t)x * NT + tix) * (I8_TILE * I8_TILE) + ri * I8_TILE + cj];
       val *= rowscale[row] * rowscale[col];
     }
     part[t] = val;
@@ -236,7 +232,7 @@ __global__ __launch_bounds__(256) void k_i8_pack(const int *__restrict__ P, int 
 
 }  // namespace
 
-// scratch of the INT8 product for n rows and K columns (bytes): digits | row maxima | row scales | int32 partial tiles
+// scratch of the INT8 product for n rows and K columns (bytes): digits | row maxima | row scales | the k-slices' partial tiles (one double per element)
 size_t syrk_i8_scratch_bytes(int n, long K, I8Layout *lay) {
   I8Layout L;
   L.T = (n + I8_TILE - 1) / I8_TILE;
@@ -247,7 +243,7 @@ size_t syrk_i8_scratch_bytes(int n, long K, I8Layout *lay) {
   while ((K + (long)I8_XCDS * L.M * I8_KS - 1) / ((long)I8_XCDS * L.M * I8_KS) * I8_KS > 32704) L.M++;
   // ... and, for windows of few tiles, the count that fills the chip's 256 CUs best: 8 M NT workgroups run in ceil(8 M NT / 256) rounds of 1 / M
   // of the columns each (a 100-pose window: 15 tiles x 8 slices = 120 workgroups leave half of the CUs idle; M = 2: 240), against the extra
-  // int32 partial tiles written and read back (8 NT x 320 KB per unit of M).  Priced with the kernel's measured 1.4 us per 64-column step and
+  // partial tiles written and read back (8 NT x 128 KB per unit of M).  Priced with the kernel's measured 1.4 us per 64-column step and
   // 5 TB/s for the partials; a slice keeps sixteen steps.  (From 41 tiles on -- 177 poses -- M stays what the int32 sums ask for: at 200 poses, 55 tiles,
   // M = 2 / 4 / 5 measured 1.23 / 1.20 / 2.69 ms against 1.19 for the product and 0.09 / 0.18 / 0.23 against 0.05 for the packing.)
   if (L.NT <= 40) {
@@ -256,7 +252,7 @@ size_t syrk_i8_scratch_bytes(int n, long K, I8Layout *lay) {
     for (int m = L.M; m <= 8; m++) {
       if (K / ((long)I8_XCDS * m) < 16 * I8_KS) break;
       const double rounds = (double)((I8_XCDS * m * L.NT + 255) / 256), steps = (double)K / (I8_XCDS * m * I8_KS);
-      const double cost = rounds * steps * 1.4e-6 + (double)m * L.NT * I8_XCDS * I8_SETS * I8_TILE * I8_TILE * 4.0 * 2.0 / 5e12;
+      const double cost = rounds * steps * 1.4e-6 + (double)m * L.NT * I8_XCDS * I8_TILE * I8_TILE * 8.0 * 2.0 / 5e12;
       if (cost < best_cost * 0.97) { best_cost = cost; best = m; }      // (3 %: a tie keeps the smaller count)
     }
     L.M = best;
@@ -266,7 +262,7 @@ size_t syrk_i8_scratch_bytes(int n, long K, I8Layout *lay) {
   size_t off = (size_t)I8_DIGITS * L.rows_p * L.Kp;
   off = (off + 255) & ~(size_t)255; L.off_rowmax = off; off += (size_t)L.rows_p * 8;
   off = (off + 255) & ~(size_t)255; L.off_scale = off; off += (size_t)L.rows_p * 8;
-  off = (off + 255) & ~(size_t)255; L.off_part = off; off += (size_t)I8_XCDS * L.M * L.NT * I8_SETS * I8_TILE * I8_TILE * sizeof(int);
+  off = (off + 255) & ~(size_t)255; L.off_part = off; off += (size_t)I8_XCDS * L.M * L.NT * I8_TILE * I8_TILE * sizeof(double);
   if (lay) *lay = L;
   return off;
 }
@@ -286,7 +282,7 @@ int launch_syrk_i8(hipStream_t s, const double *Gt, int npad, int n, long K, con
   signed char *D = reinterpret_cast<signed char *>(scratch + L.off_digits);
   auto *rowmax = reinterpret_cast<unsigned long long *>(scratch + L.off_rowmax);
   double *rowscale = reinterpret_cast<double *>(scratch + L.off_scale);
-  int *P = reinterpret_cast<int *>(scratch + L.off_part);
+  double *P = reinterpret_cast<double *>(scratch + L.off_part);
   const int kchunk = 512;
   if (rowmax_known) rowmax = const_cast<unsigned long long *>(rowmax_known);
   else if (hipMemsetAsync(rowmax, 0, (size_t)L.rows_p * 8, s) != hipSuccess) return -1;
